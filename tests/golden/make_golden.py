@@ -1,0 +1,409 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  Runs ONLY in the build container: it imports the
+real reference from /root/reference (read-only) and drives its inner functions
+exactly as SURVEY.md section 8(c) prescribes.  Nothing from the reference is copied;
+only inputs and the outputs it produced are written, as .npz, next to this
+script.  The GPU box never runs this file (the reference does not travel).
+
+Harness conventions:
+  * `ot` is not installed: a stub module is registered.  For the OT goldens its
+    `emd` is an exact LP (HiGHS dual simplex through scipy), cross-checked by
+    `linear_sum_assignment` when k | n.
+  * params carry dis_type='nor', attr=[] (D2) and n_user/n_item of the toy set.
+  * `torch.manual_seed(seed)` once immediately before every top-level call
+    (Scratch.train for full MF, Sisa.learn, Sisa.unlearn)  (D7).
+  * np.argsort is forced to kind='stable' while metrics are computed (the
+    default kind is host-specific, SURVEY section 7 "NDCG tie-breaking"); the as-is
+    value is stored beside it as information.
+
+usage: python tests/golden/make_golden.py [full] [sisa] [eval] [ot]
+"""
+import contextlib
+import io
+import os
+import sys
+import tempfile
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference'
+TOY_TRAIN = os.path.join(HERE, 'toy', '0_train.csv')
+TOY_TEST = os.path.join(HERE, 'toy', '0_test.csv')
+N_USER, N_ITEM = 1508, 2071          # toy: ids 0..1507 / 0..2070
+
+# --------------------------------------------------------------------------
+# `ot` stub: exact EMD through HiGHS
+# --------------------------------------------------------------------------
+EMD_CALLS = []
+
+
+def _emd_highs(a, b, M, numItermax=100000, **kw):
+    """Exact optimal transport plan G[n,k] (float64) for marginals a, b, cost M."""
+    from scipy.optimize import linprog
+    from scipy.sparse import coo_matrix
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    n, k = M.shape
+    b = b * (a.sum() / b.sum())
+    nv = n * k
+    rows = np.concatenate([np.repeat(np.arange(n), k), n + np.tile(np.arange(k), n)])
+    cols = np.concatenate([np.arange(nv), np.arange(nv)])
+    A = coo_matrix((np.ones(2 * nv), (rows, cols)), shape=(n + k, nv)).tocsr()
+    # drop the last (redundant) equality for a full-rank system
+    res = linprog(M.reshape(-1), A_eq=A[:-1], b_eq=np.concatenate([a, b])[:-1],
+                  bounds=(0, None), method='highs-ds',
+                  options={'primal_feasibility_tolerance': 1e-10,
+                           'dual_feasibility_tolerance': 1e-10})
+    assert res.status == 0, res.message
+    G = res.x.reshape(n, k)
+    EMD_CALLS.append({'M': M.copy(), 'G': G.copy(), 'numItermax': numItermax})
+    return G
+
+
+ot_stub = types.ModuleType('ot')
+ot_stub.emd = _emd_highs
+sys.modules['ot'] = ot_stub
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+from torch import nn  # noqa: E402
+
+with contextlib.redirect_stdout(io.StringIO()):
+    import method.utils as RU  # noqa: E402
+    import method.scratch as RS  # noqa: E402
+    import method.sisa as RSI  # noqa: E402
+    import read as RR  # noqa: E402
+
+_argsort = np.argsort
+
+
+def _stable_argsort(a, *args, **kw):
+    kw.setdefault('kind', 'stable')
+    return _argsort(a, *args, **kw)
+
+
+@contextlib.contextmanager
+def stable_sort():
+    np.argsort = _stable_argsort
+    try:
+        yield
+    finally:
+        np.argsort = _argsort
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+class Param:
+    """Plain carrier of the InsParam fields (config.py:17-49) + D2 additions."""
+
+    def __init__(self, epochs, k=16, batch=3000):
+        self.k = k
+        self.lam = 0.1
+        self.layers = [32]
+        self.seed = 42
+        self.n_worker = 0
+        self.batch = batch
+        self.lr = 0.001
+        self.lr_decay = 0.95
+        self.momentum = 0.9
+        self.epochs = epochs
+        self.n_group = 1
+        self.max_rating = 5
+        self.n_user = N_USER
+        self.n_item = N_ITEM
+        self.dis_type = 'nor'
+        self.attr = []
+
+
+# ---- hooks that expose the RNG-derived state the reference never returns ----
+INIT_LOG = []     # (U0, V0) per MF construction
+PERM_LOG = []     # first 16 entries + length + checksum of every randperm
+
+
+class _SpyMF(RU.MF):
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        INIT_LOG.append((self.user_mat.weight.detach().clone().numpy(),
+                         self.item_mat.weight.detach().clone().numpy()))
+
+
+RS.MF = _SpyMF
+_randperm = torch.randperm
+
+
+def _spy_randperm(n, *a, **kw):
+    p = _randperm(n, *a, **kw)
+    PERM_LOG.append((int(n), p[:16].numpy().copy(), int((p * torch.arange(1, n + 1)).sum() % (2 ** 61 - 1))))
+    return p
+
+
+torch.randperm = _spy_randperm
+
+
+def loaders(train_arr, test_arr, batch):
+    tr = RR.loadData(RR.RatingData(train_arr), batch, 0)
+    te = RR.loadData(RR.RatingData(test_arr), batch, 0, False)
+    return tr, te
+
+
+def read_full():
+    with quiet():
+        tr, idx = RR.readRating(TOY_TRAIN, N_USER, 5, [], [], 1, [])
+        te, _ = RR.readRating(TOY_TEST, N_USER, 5, [], [], 1, idx)
+    return tr[0], te[0]
+
+
+def metrics_both(test_loader, models):
+    """(rmse, ndcg, hr) with stable argsort and with the host's default argsort."""
+    with stable_sort():
+        st = RU.baseTest(test_loader, models, nn.MSELoss(reduction='sum'), 'cpu', 0)
+    asis = RU.baseTest(test_loader, models, nn.MSELoss(reduction='sum'), 'cpu', 0)
+    return np.array(st, dtype=np.float64), np.array(asis, dtype=np.float64)
+
+
+# --------------------------------------------------------------------------
+def gen_full():
+    tr_arr, te_arr = read_full()
+    out = {'train_n': tr_arr.shape[1], 'test_n': te_arr.shape[1]}
+    for E in (1, 3, 50):
+        del INIT_LOG[:], PERM_LOG[:]
+        p = Param(E)
+        tr, te = loaders(tr_arr, te_arr, p.batch)
+        sc = RS.Scratch(p, 'mf')
+        t0 = time.time()
+        torch.manual_seed(p.seed)
+        with quiet(), stable_sort():
+            model = sc.train(tr, te, [], 0, '')
+        dt = time.time() - t0
+        U = model.user_mat.weight.detach().numpy().copy()
+        V = model.item_mat.weight.detach().numpy().copy()
+        U0, V0 = INIT_LOG[0]
+        st, asis = metrics_both(te, [model])
+        tag = f'E{E}'
+        out[tag + '_U'] = U
+        out[tag + '_V'] = V
+        out[tag + '_train_loss'] = np.array(sc.log['train_loss'], dtype=np.float64)
+        out[tag + '_test_rmse'] = np.array(sc.log['test_rmse'], dtype=np.float64)
+        out[tag + '_test_ndcg'] = np.array(sc.log['test_ndcg'], dtype=np.float64)
+        out[tag + '_test_hr'] = np.array(sc.log['test_hr'], dtype=np.float64)
+        out[tag + '_final_stable'] = st
+        out[tag + '_final_asis'] = asis
+        out[tag + '_ref_seconds'] = dt
+        if E == 1:
+            out['U0_head'] = U0[:8].copy()
+            out['V0_head'] = V0[:8].copy()
+            out['U0_sum'] = np.float64(U0.astype(np.float64).sum())
+            out['V0_sum'] = np.float64(V0.astype(np.float64).sum())
+            out['U0_abs_sum'] = np.float64(np.abs(U0.astype(np.float64)).sum())
+            out['perm0_n'] = PERM_LOG[0][0]
+            out['perm0_head'] = PERM_LOG[0][1]
+            out['perm0_check'] = np.int64(PERM_LOG[0][2])
+        print(f'full E={E}: {dt:.1f}s  final(stable)={st}  asis={asis}', flush=True)
+        out[tag + '_n_randperm'] = len(PERM_LOG)
+    np.savez_compressed(os.path.join(HERE, 'full_mf_toy.npz'), **out)
+
+
+# --------------------------------------------------------------------------
+def uniform_groups(S):
+    """read.py:22-33 uniform grouping (np.random.seed(0) shuffle)."""
+    with quiet():
+        tr, idx = RR.readRating(TOY_TRAIN, N_USER, 5, [], [], S, [])
+    return tr, idx
+
+
+def gen_sisa():
+    out = {}
+    for S, E in ((3, 2), (4, 3)):
+        p = Param(E)
+        p.n_group = S
+        tr_l, idx = uniform_groups(S)
+        with quiet():
+            te_l, _ = RR.readRating(TOY_TEST, N_USER, 5, [], [], S, idx)
+        test_total = np.hstack(te_l)
+        tag = f'S{S}'
+        for i in range(S):
+            out[f'{tag}_index{i}'] = np.array(idx[i], dtype=np.int64)
+            out[f'{tag}_ntrain{i}'] = tr_l[i].shape[1]
+            out[f'{tag}_ntest{i}'] = te_l[i].shape[1]
+
+        def mk(train_lists):
+            trd = [RR.loadData(RR.RatingData(a), p.batch, 0) for a in train_lists]
+            ted = [RR.loadData(RR.RatingData(a), p.batch, 0, False) for a in te_l]
+            tot = RR.loadData(RR.RatingData(test_total), p.batch, 0, False)
+            return trd, ted, tot
+
+        trd, ted, tot = mk(tr_l)
+        sisa = RSI.Sisa(p, 'mf', S, idx)
+        save = tempfile.mkdtemp()
+        del INIT_LOG[:], PERM_LOG[:]
+        torch.manual_seed(p.seed)
+        t0 = time.time()
+        with quiet(), stable_sort():
+            ml = sisa.learn(trd, ted, tot, 0, save)
+        out[f'{tag}_learn_seconds'] = time.time() - t0
+        out[f'{tag}_learn_U0sum'] = np.array([float(u.astype(np.float64).sum()) for u, _ in INIT_LOG])
+        out[f'{tag}_learn_perm_heads'] = np.array([h for _, h, _ in PERM_LOG])
+        for i in range(S):
+            out[f'{tag}_learn_V{i}'] = ml[i].item_mat.weight.detach().numpy().copy()
+            out[f'{tag}_learn_Upre{i}'] = np.load(f'{save}/user_mat{i + 1}.npy')
+        out[f'{tag}_learn_Umerged'] = ml[0].user_mat.weight.detach().numpy().copy()
+        log0 = np.load(f'{save}/log0.npy', allow_pickle=True).item()
+        out[f'{tag}_learn_log0'] = np.array([log0['total_rmse'], log0['total_ndcg'], log0['total_hr']], dtype=np.float64)
+        lg = sisa.log   # D8: one dict appended by every shard
+        for key in ('train_loss', 'test_rmse', 'test_ndcg', 'test_hr', 'total_rmse', 'total_ndcg', 'total_hr'):
+            out[f'{tag}_learn_log_{key}'] = np.array(lg[key], dtype=np.float64)
+        _, asis = metrics_both(tot, ml)
+        out[f'{tag}_learn_log0_asis'] = asis
+        print(f'sisa S={S} learn log0={out[tag + "_learn_log0"]}', flush=True)
+
+        # ---- unlearn: two deletion sets ----
+        np.random.seed(0)
+        del_a = np.random.choice(N_USER, 30, replace=False)          # D12: all inside uniform shard 0
+        rs = np.random.RandomState(7)
+        del_b = rs.choice(N_USER, 12, replace=False)                  # spread over shards
+        for name, del_user in (('A', del_a), ('B', del_b)):
+            with quiet():
+                tr_d, idx_d = RR.readRating(TOY_TRAIN, N_USER, 5, list(del_user), [], S, idx)
+            assert all(list(x) == list(y) for x, y in zip(idx, idx_d))
+            trd2, ted2, tot2 = mk(tr_d)
+            # fresh learner state: reuse learned models (cloned so set A and B start identically)
+            import copy
+            ml_c = [copy.deepcopy(m) for m in ml]
+            s2 = RSI.Sisa(p, 'mf', S, idx)
+            save2 = tempfile.mkdtemp()
+            del INIT_LOG[:], PERM_LOG[:]
+            torch.manual_seed(p.seed)
+            with quiet(), stable_sort():
+                ml2 = s2.unlearn(ml_c, trd2, ted2, tot2, list(del_user), 0, save2)
+            t = f'{tag}_un{name}'
+            out[t + '_del_user'] = np.array(del_user, dtype=np.int64)
+            out[t + '_ntrain'] = np.array([a.shape[1] for a in tr_d])
+            out[t + '_n_retrained'] = len(INIT_LOG)
+            out[t + '_Umerged'] = ml2[0].user_mat.weight.detach().numpy().copy()
+            for i in range(S):
+                out[f'{t}_V{i}'] = ml2[i].item_mat.weight.detach().numpy().copy()
+            l0 = np.load(f'{save2}/log0.npy', allow_pickle=True).item()
+            out[t + '_log0'] = np.array([l0['total_rmse'], l0['total_ndcg'], l0['total_hr']], dtype=np.float64)
+            for key in ('train_loss', 'test_rmse', 'total_rmse', 'total_ndcg', 'total_hr'):
+                out[f'{t}_log_{key}'] = np.array(s2.log[key], dtype=np.float64)
+            print(f'  unlearn {name}: retrained {len(INIT_LOG)} shards, log0={out[t + "_log0"]}', flush=True)
+    np.savez_compressed(os.path.join(HERE, 'sisa_toy.npz'), **out)
+
+
+# --------------------------------------------------------------------------
+class _TableModel:
+    """Stand-in 'model' for baseTest unit vectors: returns prescribed scores."""
+
+    def __init__(self, table):
+        self.table = table   # dict (u,i)->score
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def __call__(self, user, item):
+        return torch.tensor([self.table[(int(u), int(i))] for u, i in zip(user, item)], dtype=torch.float32)
+
+
+def gen_eval():
+    """baseTest unit vectors (utils.py:115-210), stable argsort."""
+    rs = np.random.RandomState(123)
+    cases = []
+    # case 0: tiny hand-built, users with <10 items, ties in ratings, threshold edges
+    u = [5, 5, 5, 2, 2, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9, 7]
+    i = list(range(len(u)))
+    r = [0.8, 0.8, 0.6, 1.0, 0.8, 0.2, 0.4, 0.6, 0.8, 1.0, 0.8, 0.8, 0.6, 1.0, 0.2, 0.8, 1.0, 0.79999]
+    cases.append((u, i, r, 1, 7))
+    # case 1..3: random, several models, batch smaller than data (users straddle batches)
+    for n_u, n_rows, n_models, batch in ((13, 200, 1, 64), (40, 900, 3, 250), (6, 300, 2, 1000)):
+        uu = np.sort(rs.randint(0, n_u, n_rows))
+        ii = rs.randint(0, 50, n_rows)
+        rr = rs.choice([0.2, 0.4, 0.6, 0.8, 1.0], n_rows)
+        cases.append((uu.tolist(), ii.tolist(), rr.tolist(), n_models, batch))
+    out = {'n_cases': len(cases)}
+    for c, (u, i, r, n_models, batch) in enumerate(cases):
+        u = np.asarray(u); i = np.asarray(i); r = np.asarray(r, dtype=np.float64)
+        # make (u,i) unique so the score table is well defined
+        i = np.arange(len(u)) if len(set(zip(u.tolist(), i.tolist()))) < len(u) else i
+        scores = rs.standard_normal((n_models, len(u))).astype(np.float32) * 0.5 + 0.6
+        models = [_TableModel({(int(a), int(b)): float(s) for a, b, s in zip(u, i, scores[m])})
+                  for m in range(n_models)]
+        arr = np.vstack([u.astype(np.float64), i.astype(np.float64), r])
+        ld = RR.loadData(RR.RatingData(arr), batch, 0, False)
+        st, asis = metrics_both(ld, models)
+        out[f'c{c}_u'] = u.astype(np.int64)
+        out[f'c{c}_i'] = i.astype(np.int64)
+        out[f'c{c}_r'] = r.astype(np.float32)
+        out[f'c{c}_scores'] = scores
+        out[f'c{c}_batch'] = batch
+        out[f'c{c}_expect'] = st
+        out[f'c{c}_expect_asis'] = asis
+        print(f'eval case {c}: {st}', flush=True)
+    # computeNDCG direct vectors
+    vecs = [np.array([]), np.array([1.0]), np.array([0.8, 0.0, 1.0]), rs.choice([0, 0.8, 1.0], 10)]
+    out['ndcg_in'] = np.array([np.pad(v, (0, 10 - len(v))) for v in vecs])
+    out['ndcg_len'] = np.array([len(v) for v in vecs])
+    out['ndcg_out'] = np.array([RU.computeNDCG(v.copy(), 10) for v in vecs], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, 'eval_vectors.npz'), **out)
+
+
+# --------------------------------------------------------------------------
+def gen_ot():
+    from scipy.optimize import linear_sum_assignment
+    g = np.load(os.path.join(HERE, 'full_mf_toy.npz'))
+    X = g['E50_U'].astype(np.float32)
+    out = {'X': X}
+    for k in (4, 5, 7):
+        # numpy RNG state on the CLI path: seed(0) -> choice(n_user, n_del) -> ot_cluster
+        np.random.seed(0)
+        n_del = int(2 / 100 * N_USER)
+        np.random.choice(N_USER, n_del, replace=False)
+        state_probe = np.random.get_state()
+        cent_idx = np.random.choice(N_USER, size=k, replace=False)
+        np.random.set_state(state_probe)
+        del EMD_CALLS[:]
+        t0 = time.time()
+        with quiet():
+            inertia, label = RU.ot_cluster.__wrapped__(X, k)
+        dt = time.time() - t0
+        tag = f'k{k}'
+        out[tag + '_cent_idx'] = cent_idx.astype(np.int64)
+        out[tag + '_label'] = label.astype(np.int64)
+        out[tag + '_inertia'] = np.float64(inertia)
+        out[tag + '_rounds'] = len(EMD_CALLS)
+        out[tag + '_numItermax'] = np.float64(EMD_CALLS[0]['numItermax'])
+        out[tag + '_round_labels'] = np.array([np.argmax(c['G'], axis=1) for c in EMD_CALLS], dtype=np.int64)
+        out[tag + '_round_dist_sum'] = np.array([c['M'].sum() for c in EMD_CALLS], dtype=np.float64)
+        out[tag + '_round0_dist'] = EMD_CALLS[0]['M'].astype(np.float32)         # [n,k] = dist.T of round 0
+        out[tag + '_last_dist'] = EMD_CALLS[-1]['M'].astype(np.float32)
+        out[tag + '_last_plan_nk'] = (EMD_CALLS[-1]['G'] * (N_USER * k)).round(6)   # units of 1/(n k)
+        out[tag + '_round_cost'] = np.array([(c['M'] * c['G']).sum() for c in EMD_CALLS], dtype=np.float64)
+        agree = -1
+        if N_USER % k == 0:
+            agree = 1
+            for c in EMD_CALLS:
+                rep = np.repeat(c['M'], N_USER // k, axis=1)
+                _, col = linear_sum_assignment(rep)
+                if not np.array_equal(col // (N_USER // k), np.argmax(c['G'], axis=1)):
+                    agree = 0
+        out[tag + '_lsa_agree'] = agree
+        print(f'ot k={k}: rounds={len(EMD_CALLS)} inertia={inertia:.4f} counts={np.bincount(label)} '
+              f'lsa_agree={agree} {dt:.1f}s', flush=True)
+    np.savez_compressed(os.path.join(HERE, 'ot_toy.npz'), **out)
+
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['full', 'sisa', 'eval', 'ot']
+    torch.set_num_threads(1)
+    for w in what:
+        {'full': gen_full, 'sisa': gen_sisa, 'eval': gen_eval, 'ot': gen_ot}[w]()
