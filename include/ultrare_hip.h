@@ -1,0 +1,149 @@
+/*
+ * ultrare_hip.h -- C ABI of libultrare_hip.so, the MI355X (gfx950) engine behind
+ * UltraRE's SISA hot path.
+ *
+ * The reference has no FFI: its boundary is the Python operator surface
+ * (SURVEY.md 8b).  This header is the boundary *beneath* ultrare_amd's mirror of
+ * that surface -- what a maintainer of the reference would bind with ctypes in
+ * place of the torch calls cited on each entry point.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, no torch / C++ types.
+ *   - every `dev_*` / device pointer is caller-owned HIP device memory (the Python
+ *     host passes torch tensors' data_ptr()); the library never frees it.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *     work is enqueued on it; nothing here synchronises unless it says so.
+ *   - return value: 0 = success, otherwise a hipError_t (or -1 for argument
+ *     errors); ure_last_error() returns a thread-local message.
+ *   - fp32 tables are row-major [rows][d]; d is a power of two, 4 <= d <= 256
+ *     (the host pads other widths with zero columns, which stay zero).
+ *   - citations are file:line under the reference repository.
+ */
+#ifndef ULTRARE_HIP_H
+#define ULTRARE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define URE_ABI_VERSION 1
+#define URE_MAX_MODELS_PER_CALL 32
+
+int ure_abi_version(void);
+const char *ure_last_error(void);
+/* Number of compute units, wavefront size and gcnArchName of device `dev`. */
+int ure_device_info(int dev, int *n_cu, int *wave_size, char *arch, int arch_len);
+
+/* ---------------------------------------------------------------------------
+ * One SISA shard = one MF model trained in isolation (sisa.py:33-36).
+ *
+ * The shard's interactions are held twice, as CSR grouped by user and as CSR
+ * grouped by item (both built once by the host, stable in file order), so that a
+ * wavefront that owns a destination row can sum that row's gradient in registers
+ * and apply the optimizer to it immediately -- no atomics, no gradient tables.
+ * `*_pos` map an interaction's file-order index to its slot in each CSR;
+ * `*_b` receive, once per epoch, the batch number every interaction falls in
+ * under that epoch's permutation (read.py:133: batch s = perm[s*B : (s+1)*B]).
+ * ------------------------------------------------------------------------- */
+typedef struct ure_shard {
+    /* interactions, grouped by user */
+    const int32_t *u_off;   /* [n_user+1] row offsets                               */
+    const int32_t *u_oid;   /* [N] item id of the entry                             */
+    const float   *u_r;     /* [N] rating / max_rating (read.py:66)                 */
+    uint16_t      *u_b;     /* [N] batch number this epoch (written by the engine)  */
+    const int32_t *u_pos;   /* [N] file-order index -> slot in the by-user arrays   */
+    /* interactions, grouped by item */
+    const int32_t *i_off;   /* [n_item+1]                                           */
+    const int32_t *i_oid;   /* [N] user id of the entry                             */
+    const float   *i_r;     /* [N]                                                  */
+    uint16_t      *i_b;     /* [N]                                                  */
+    const int32_t *i_pos;   /* [N]                                                  */
+    /* row schedule: destination rows (user u -> u, item i -> n_user + i) ordered
+     * heaviest first; the first n_heavy get a whole 4-wave workgroup each          */
+    const int32_t *row_sched;  /* [n_user + n_item]                                 */
+    int32_t        n_heavy;
+    /* model state (utils.py:31-40, scratch.py:64-69) */
+    float *U[2];            /* [n_user][d] ping-pong: step t reads [t&1], writes [(t+1)&1] */
+    float *V[2];            /* [n_item][d]                                          */
+    float *mU;              /* [n_user][d] SGD momentum buffer                      */
+    float *mV;              /* [n_item][d]                                          */
+    /* per-epoch inputs / outputs */
+    const int32_t *perm;    /* [epochs][N] the epoch permutations (RandomSampler)   */
+    const float   *lr;      /* [epochs] learning rate of each epoch (StepLR)        */
+    double        *sse;     /* [epochs] sum over the epoch of (pred - r)^2          */
+    int32_t N, n_user, n_item, d;
+    int32_t batch;          /* B (config.py:26)                                     */
+    int32_t epochs;
+    float   lam, mu;        /* weight decay, momentum (config.py:20,29)             */
+} ure_shard_t;
+
+typedef struct ure_job ure_job_t;   /* a set of shards trained side by side */
+
+/* Copies the n descriptors to the device (small hipMalloc owned by the job). */
+int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out);
+int ure_job_destroy(ure_job_t *job);
+/* Number of optimizer steps shard `s` needs in total = epochs * ceil(N/B), and
+ * the maximum over the job's shards (the number of ticks to run). */
+int64_t ure_job_shard_steps(const ure_job_t *job, int s);
+int64_t ure_job_ticks(const ure_job_t *job);
+
+/* Replaces baseTrain's loop (utils.py:58-91) + opt.step() (scratch.py:64-69) for
+ * every shard of the job: tick t performs optimizer step t of each shard that
+ * still has one (a shard's step t belongs to epoch t / ceil(N/B)); at the first
+ * step of an epoch the shard's batch numbers are re-derived from perm[epoch].
+ * Ticks [tick0, tick1) are enqueued on `stream`; tick0 must continue where the
+ * previous call stopped (0 for a fresh model).  After the last tick the trained
+ * tables are U[ticks_done & 1] / V[ticks_done & 1] of each shard, where
+ * ticks_done = min(tick1, shard steps). */
+int ure_job_train(ure_job_t *job, int64_t tick0, int64_t tick1, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Evaluation (baseTest, utils.py:115-187)
+ * ------------------------------------------------------------------------- */
+/* utils.py:140-145: pred[j] = (sum_m U_m[uid[j]] . V_m[iid[j]]) / n_models_total.
+ * Up to URE_MAX_MODELS_PER_CALL tables per call; for larger ensembles call
+ * repeatedly with `first`/`last` marking the first and last chunk (pred holds the
+ * running sum in between).  When `sse` is non-NULL the last chunk also adds
+ * sum_j (pred[j] - rating[j])^2 to *sse (utils.py:148; double, device memory). */
+int ure_score(const float *const *U_tables, const float *const *V_tables, int n_models,
+              int n_models_total, int first, int last,
+              const int32_t *uid, const int32_t *iid, const float *rating, int64_t n, int d,
+              float *pred, double *sse, void *stream);
+
+/* utils.py:165-184 for users whose entries are contiguous: user t owns entries
+ * [off[t], off[t+1]).  For each user: top-10 by prediction and by rating (ties:
+ * higher position first = stable argsort reversed), hits[t] = #(rating[top_pred]
+ * >= 4/5), ndcg[t] = the reference's positional NDCG@10 (utils.py:190-210).
+ * `inv_log2` = 1/log2(2..10) is NOT used; `log2_tab` [9] = log2(2..10) as float64
+ * computed by the host with numpy so that the division matches bit for bit. */
+int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const float *rating,
+                   const double *log2_tab, int32_t *hits, double *ndcg, void *stream);
+
+/* sisa.py:55-56,110-111: dst[rows[t]][:] = src[rows[t]][:]. */
+int ure_merge_rows(float *dst, const float *src, const int64_t *rows, int64_t n_rows, int d, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * OT balanced grouping (utils.py:628-656)
+ * ------------------------------------------------------------------------- */
+/* utils.py:637: dist[c][i] = sum_j (X[i][j] - C[c][j])^2 in numpy's fp32 pairwise
+ * order (bit-exact), any 1 <= d <= 256. */
+int ure_ot_cost(const float *X, const float *C, int64_t n, int k, int d, float *dist, void *stream);
+/* utils.py:648: C[c] = mean of the rows with label c, fp32 sequential in ascending
+ * row id then one division by the count (bit-exact).  counts [k] receives sizes. */
+int ure_ot_centroids(const float *X, const int32_t *label, int64_t n, int k, int d, float *C,
+                     int32_t *counts, void *stream);
+/* utils.py:642-647: exact optimal transport between n points of mass 1/n and k
+ * clusters of mass 1/k for cost dist [k][n] (HOST memory, fp32 widened to double
+ * exactly), followed by label = argmax of each point's plan row (first maximum).
+ * Exact integer min-cost-flow on the k-node cluster graph; runs on the host (the
+ * LP is sequential and tiny next to training).  plan_nk (optional, [n][k]) receives
+ * the plan in units of 1/(n*k); total_cost (optional) the objective <G, M>. */
+int ure_ot_assign(const float *dist_host, int64_t n, int k, int32_t *label_host,
+                  int32_t *plan_nk, double *total_cost);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ULTRARE_HIP_H */

@@ -1,0 +1,142 @@
+"""GPU parity of the engine layer (TrainJob / EvalSet through the C ABI) against the
+CPU oracle and against goldens produced by the real reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+N_USER, N_ITEM = 1508, 2071
+RTOL = 1e-4     # BASELINE.json north_star: 1e-4 relative on learned embeddings / metrics
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(b).max())
+
+
+@pytest.fixture(scope='module')
+def toy():
+    tr = O.load_csv(os.path.join(G, 'toy', '0_train.csv'))
+    te = O.load_csv(os.path.join(G, 'toy', '0_test.csv'))
+    full = [list(range(N_USER))]
+    return O.partition(*tr, full)[0], O.partition(*te, full)[0]
+
+
+def _train_gpu(train, k, batch, epochs, seed=42, heavy=None, lr=1e-3, lam=0.1, mu=0.9):
+    from ultrare_amd import engine, rng
+    torch.manual_seed(seed)
+    U0, V0 = rng.mf_init(N_USER, N_ITEM, k)
+    seeds = rng.epoch_seeds(epochs, False)
+    perms = rng.epoch_perms(seeds, len(train[0]))
+    sh = engine.ShardData(*train, N_USER, N_ITEM, heavy_nnz=heavy)
+    job = engine.TrainJob([sh], [(U0, V0)], [perms], k, batch, epochs, lr, lam, mu, 0.95)
+    job.run()
+    torch.cuda.synchronize()
+    U, V = job.tables(0)
+    return U.cpu().numpy(), V.cpu().numpy(), job, (U0.numpy(), V0.numpy(), perms.numpy())
+
+
+@pytest.mark.parametrize('E', [1, 3, 50])
+def test_full_mf_vs_reference_golden(toy, E):
+    g = np.load(os.path.join(G, 'full_mf_toy.npz'))
+    train, test = toy
+    U, V, job, _ = _train_gpu(train, 16, 3000, E)
+    assert rel(U, g[f'E{E}_U']) < RTOL
+    assert rel(V, g[f'E{E}_V']) < RTOL
+    loss = np.sqrt(job.epoch_sse(0) / len(train[0]))
+    np.testing.assert_allclose(loss, g[f'E{E}_train_loss'], rtol=RTOL)
+
+
+@pytest.mark.parametrize('k,batch,heavy', [(4, 1000, None), (8, 3000, 64), (16, 3000, 0), (32, 5000, 100000),
+                                           (64, 3000, 128), (128, 30000, 256), (20, 3000, None)])
+def test_step_kernel_vs_oracle(toy, k, batch, heavy):
+    """Every table width (incl. a padded one), heavy-row threshold extremes, batch
+    larger than the shard; 2 epochs against the C oracle on identical init/perms."""
+    train, _ = toy
+    E = 2
+    U, V, job, (U0, V0, perms) = _train_gpu(train, k, batch, E, heavy=heavy)
+    st = O.MFState(U0.copy(), V0.copy())
+    losses = []
+    for t in range(E):
+        losses.append(O.train_epoch(st, train, perms[t], batch, 1e-3, 0.1, 0.9)[0])
+    assert rel(U, st.U) < 1e-5
+    assert rel(V, st.V) < 1e-5
+    np.testing.assert_allclose(np.sqrt(job.epoch_sse(0) / len(train[0])), losses, rtol=1e-5)
+
+
+def test_bitwise_reproducible(toy):
+    train, _ = toy
+    a = _train_gpu(train, 32, 3000, 2)
+    b = _train_gpu(train, 32, 3000, 2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_shards_side_by_side_equal_alone(toy):
+    """A job's shards share launches but must train exactly as if alone."""
+    from ultrare_amd import engine, rng
+    (tu, ti, tr), _ = toy
+    idx = O.uniform_groups(N_USER, 3)
+    raw = O.load_csv(os.path.join(G, 'toy', '0_train.csv'))
+    parts = O.partition(*raw, idx)
+    k, B, E = 16, 3000, 3
+    torch.manual_seed(7)
+    inits, perms = [], []
+    for p in parts:
+        inits.append(rng.mf_init(N_USER, N_ITEM, k))
+        perms.append(rng.epoch_perms(rng.epoch_seeds(E, True), len(p[0])))
+    shards = [engine.ShardData(*p, N_USER, N_ITEM) for p in parts]
+    job = engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9)
+    job.run()
+    for s, p in enumerate(parts):
+        solo = engine.TrainJob([engine.ShardData(*p, N_USER, N_ITEM)], [inits[s]], [perms[s]], k, B, E, 1e-3, 0.1, 0.9)
+        solo.run()
+        torch.cuda.synchronize()
+        for a, b in zip(job.tables(s), solo.tables(0)):
+            assert torch.equal(a, b)
+        st = O.MFState(inits[s][0].numpy().copy(), inits[s][1].numpy().copy())
+        for t in range(E):
+            O.train_epoch(st, p, perms[s][t].numpy(), B, 1e-3, 0.1, 0.9)
+        assert rel(job.tables(s)[0].cpu().numpy(), st.U) < 1e-5
+        assert rel(job.tables(s)[1].cpu().numpy(), st.V) < 1e-5
+
+
+def test_eval_unit_vectors_exact():
+    """HR exact, NDCG to 1e-12, on the reference's own baseTest outputs; the scores are
+    injected through 1-wide 'tables' so that the ranking kernel sees prescribed values."""
+    from ultrare_amd import engine
+    g = np.load(os.path.join(G, 'eval_vectors.npz'))
+    for c in range(int(g['n_cases'])):
+        u, i, r, scores = g[f'c{c}_u'], g[f'c{c}_i'], g[f'c{c}_r'], g[f'c{c}_scores']
+        S, n = scores.shape
+        ev = engine.EvalSet(u, np.arange(n), r)            # item id = row id -> V row holds the score
+        models = []
+        for m in range(S):
+            U = torch.zeros(int(u.max()) + 1, 4, device='cuda')
+            U[:, 0] = 1.0
+            V = torch.zeros(n, 4, device='cuda')
+            V[:, 0] = torch.from_numpy(scores[m]).cuda()
+            models.append((U, V))
+        rmse, ndcg, hr = ev.evaluate(models, 4)
+        want = g[f'c{c}_expect']
+        assert abs(rmse - want[0]) < 1e-6 * want[0]
+        assert abs(ndcg - want[1]) < 1e-12, (c, ndcg, want[1])
+        assert abs(hr - want[2]) < 1e-12
+
+
+@pytest.mark.parametrize('E', [1, 50])
+def test_eval_on_reference_models(toy, E):
+    """Score + rank the reference's own trained tables: metrics vs its baseTest."""
+    from ultrare_amd import engine
+    g = np.load(os.path.join(G, 'full_mf_toy.npz'))
+    _, test = toy
+    ev = engine.EvalSet(*test)
+    U = torch.from_numpy(g[f'E{E}_U']).cuda()
+    V = torch.from_numpy(g[f'E{E}_V']).cuda()
+    got = ev.evaluate([(U, V)], 16)
+    np.testing.assert_allclose(got, g[f'E{E}_final_stable'], rtol=RTOL)
+    pred = ev.predictions()
+    assert rel(pred, O.score([(g[f'E{E}_U'], g[f'E{E}_V'])], test[0], test[1])) < 1e-5

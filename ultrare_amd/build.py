@@ -1,0 +1,46 @@
+"""Build libultrare_hip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
+
+    python -m ultrare_amd.build [--force]
+
+The library is compiled for MI355X only (--offload-arch=gfx950); hipcc
+cross-compiles without a GPU.  The built .so is git-ignored but travels with the
+tree to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, 'csrc')
+LIB = os.path.join(PKG, 'libultrare_hip.so')
+SOURCES = ['ure_common.hip', 'mf_train.hip', 'mf_eval.hip', 'ot.hip', 'ot_solver.cpp']
+FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-munsafe-fp-atomics',
+         '-ffp-contract=off', '-Wall', '-Wno-unused-result']
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, 'include', 'ultrare_hip.h')]
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        raise RuntimeError('hipcc not found: libultrare_hip.so cannot be built')
+    cmd = [hipcc] + FLAGS + ['-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-o', LIB] + \
+          [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,230 @@
+// mf_eval.hip -- ensemble scoring, per-user HR@10 / NDCG@10 and the SISA user-row
+// merge for gfx950.
+//
+// Replaces
+//   baseTest scoring    method/utils.py:140-148  pred = stack(preds).mean(0); sum (pred-r)^2
+//   baseTest ranking    method/utils.py:165-184  per-user argsort top-10, HR, positional NDCG
+//   computeNDCG / DCG   method/utils.py:190-210
+//   user-row merge      method/sisa.py:52-58, 107-113
+//
+// The reference walks Python dicts per user; here one wavefront owns one user and
+// extracts the two top-10 lists by repeated wave-wide arg-max over (value, position)
+// keys -- exactly the order of a stable ascending argsort read backwards -- and one
+// lane finishes the float64 DCG in numpy's summation order so that HR is exact and
+// NDCG is bit-identical whenever the two rankings agree with the reference's.
+#include "ure_internal.h"
+
+#include <cfloat>
+#include <climits>
+
+namespace ure {
+
+struct TableList {
+    const float *U[URE_MAX_MODELS_PER_CALL];
+    const float *V[URE_MAX_MODELS_PER_CALL];
+};
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void score_kernel(TableList T, int n_models, int n_total, int first, int last,
+                                                        const int32_t *__restrict__ uid, const int32_t *__restrict__ iid,
+                                                        const float *__restrict__ rating, int64_t n,
+                                                        float *__restrict__ pred, double *__restrict__ sse)
+{
+    constexpr int D = LPR * 4;
+    constexpr int G = kWave / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (LPR - 1), grp = lane / LPR;
+    const int64_t wave_id = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+    float sq = 0.f;
+    for (int64_t base = wave_id * G; base < n; base += n_waves * G) {
+        const int64_t j = base + grp;
+        const bool act = j < n;
+        const int u = act ? uid[j] : 0, i = act ? iid[j] : 0;
+        float acc = (act && !first) ? pred[j] : 0.f;
+        for (int m = 0; m < n_models; ++m) {
+            const float4 a = *reinterpret_cast<const float4 *>(T.U[m] + (size_t)u * D + sub * 4);
+            const float4 b = *reinterpret_cast<const float4 *>(T.V[m] + (size_t)i * D + sub * 4);
+            float p = a.x * b.x;
+            p = fmaf(a.y, b.y, p);
+            p = fmaf(a.z, b.z, p);
+            p = fmaf(a.w, b.w, p);
+            acc += group_sum<LPR>(p);
+        }
+        if (last) {
+            acc = acc / (float)n_total;
+            if (act && sub == 0 && sse) {
+                const float e = acc - rating[j];
+                sq = fmaf(e, e, sq);
+            }
+        }
+        if (act && sub == 0) pred[j] = acc;
+    }
+    if (last && sse) {
+        sq = wave_sum(sq);
+        if (lane == 0 && sq != 0.f) atomicAdd(sse, (double)sq);
+    }
+}
+
+// (value, position) keys ordered lexicographically; "better" = later in a stable
+// ascending argsort, i.e. earlier in its reverse (utils.py:169-170).
+__device__ __forceinline__ bool key_gt(float v, int i, float bv, int bi) { return v > bv || (v == bv && i > bi); }
+
+__device__ __forceinline__ void wave_argmax(float &v, int &i)
+{
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const float ov = __shfl_xor(v, o, kWave);
+        const int oi = __shfl_xor(i, o, kWave);
+        if (key_gt(ov, oi, v, i)) { v = ov; i = oi; }
+    }
+}
+
+// Positions (within the user's segment) of the top-K keys of `val`, best first.
+template <int K>
+__device__ __forceinline__ void top_k_positions(const float *__restrict__ val, int cnt, int lane, int (&top)[K])
+{
+    float pv = FLT_MAX;   // previous pick: everything is "less" than it on the first round
+    int pi = INT_MAX;
+    bool pinf = true;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float bv = -FLT_MAX;
+        int bi = -1;
+        for (int t = lane; t < cnt; t += kWave) {
+            const float v = val[t];
+            const bool below_prev = pinf || v < pv || (v == pv && t < pi);
+            if (below_prev && (bi < 0 || key_gt(v, t, bv, bi))) { bv = v; bi = t; }
+        }
+        // lanes without a candidate carry (−FLT_MAX, −1), which loses to any real key
+        wave_argmax(bv, bi);
+        top[k] = bi;
+        pv = bv; pi = bi; pinf = false;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__restrict__ off, int32_t n_users,
+                                                            const float *__restrict__ pred, const float *__restrict__ rating,
+                                                            const double *__restrict__ log2_tab,
+                                                            int32_t *__restrict__ hits, double *__restrict__ ndcg)
+{
+    constexpr int K = 10;
+    const int lane = threadIdx.x & 63;
+    const int user = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+    if (user >= n_users) return;
+    const int beg = off[user], cnt = off[user + 1] - beg;
+    int tp[K], tr[K];
+    top_k_positions<K>(pred + beg, cnt, lane, tp);
+    top_k_positions<K>(rating + beg, cnt, lane, tr);
+    if (lane != 0) return;
+    const int n_top = cnt < K ? cnt : K;
+    double val[K];
+    int n_hit = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        val[j] = 0.0;
+        if (j < n_top) {
+            const double rel = (double)rating[beg + tp[j]];          // float32 widened (utils.py:132,153)
+            const bool hit = rel >= (4.0 / 5.0);                     // utils.py:175
+            n_hit += hit ? 1 : 0;
+            bool common = false;                                     // np.in1d(top_rating, top_pred)[j]
+#pragma unroll
+            for (int q = 0; q < K; ++q) common = common || (q < n_top && tp[q] == tr[j]);
+            val[j] = (hit && common) ? rel : 0.0;
+        }
+    }
+    // computeDCG (utils.py:209-210): r[0] + np.sum(r[1:] / log2(2..10)); np.sum of 9
+    // float64 = numpy pairwise: 8 lanes combined as a tree, then the 9th added.
+    double a[K - 1], b[K - 1];
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {
+        a[j] = val[j + 1] / log2_tab[j];
+        b[j] = 1.0 / log2_tab[j];
+    }
+    const double dcg = val[0] + ((((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + a[8]);
+    const double idcg = 1.0 + ((((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]))) + b[8]);
+    hits[user] = n_hit;
+    ndcg[user] = dcg / idcg;
+}
+
+__global__ __launch_bounds__(kBlock) void merge_rows_kernel(float *__restrict__ dst, const float *__restrict__ src,
+                                                            const int64_t *__restrict__ rows, int64_t n_rows, int d4)
+{
+    const int64_t total = n_rows * d4;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = rows[t / d4];
+        const int c = (int)(t % d4);
+        reinterpret_cast<float4 *>(dst)[r * d4 + c] = reinterpret_cast<const float4 *>(src)[r * d4 + c];
+    }
+}
+
+template <int LPR>
+static void launch_score(const TableList &T, int nm, int nt, int first, int last, const int32_t *uid, const int32_t *iid,
+                         const float *rating, int64_t n, float *pred, double *sse, hipStream_t st)
+{
+    constexpr int G = kWave / LPR;
+    const int64_t waves = (n + G - 1) / G;
+    const unsigned blocks = (unsigned)std::min<int64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 8);
+    hipLaunchKernelGGL(score_kernel<LPR>, dim3(blocks ? blocks : 1), dim3(kBlock), 0, st, T, nm, nt, first, last, uid, iid,
+                       rating, n, pred, sse);
+}
+
+}  // namespace ure
+
+using namespace ure;
+
+extern "C" {
+
+int ure_score(const float *const *U_tables, const float *const *V_tables, int n_models, int n_models_total, int first,
+              int last, const int32_t *uid, const int32_t *iid, const float *rating, int64_t n, int d, float *pred,
+              double *sse, void *stream)
+{
+    URE_ARG(U_tables && V_tables && n_models > 0 && n_models <= URE_MAX_MODELS_PER_CALL && n_models_total >= n_models);
+    URE_ARG(uid && iid && pred && n >= 0 && pow2(d) && d >= 4 && d <= 256 && (!sse || rating));
+    if (n == 0) return 0;
+    TableList T;
+    for (int m = 0; m < n_models; ++m) {
+        URE_ARG(U_tables[m] && V_tables[m]);
+        T.U[m] = U_tables[m];
+        T.V[m] = V_tables[m];
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (d / 4) {
+        case 1: launch_score<1>(T, n_models, n_models_total, first, last, uid, iid, rating, n, pred, sse, st); break;
+        case 2: launch_score<2>(T, n_models, n_models_total, first, last, uid, iid, rating, n, pred, sse, st); break;
+        case 4: launch_score<4>(T, n_models, n_models_total, first, last, uid, iid, rating, n, pred, sse, st); break;
+        case 8: launch_score<8>(T, n_models, n_models_total, first, last, uid, iid, rating, n, pred, sse, st); break;
+        case 16: launch_score<16>(T, n_models, n_models_total, first, last, uid, iid, rating, n, pred, sse, st); break;
+        case 32: launch_score<32>(T, n_models, n_models_total, first, last, uid, iid, rating, n, pred, sse, st); break;
+        case 64: launch_score<64>(T, n_models, n_models_total, first, last, uid, iid, rating, n, pred, sse, st); break;
+        default: return fail(-1, "ure_score: unsupported d=%d", d);
+    }
+    URE_HIP(hipGetLastError());
+    return 0;
+}
+
+int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const float *rating, const double *log2_tab,
+                   int32_t *hits, double *ndcg, void *stream)
+{
+    URE_ARG(off && pred && rating && log2_tab && hits && ndcg && n_users >= 0);
+    if (n_users == 0) return 0;
+    const unsigned blocks = (unsigned)((n_users + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(eval_users_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), off, n_users, pred,
+                       rating, log2_tab, hits, ndcg);
+    URE_HIP(hipGetLastError());
+    return 0;
+}
+
+int ure_merge_rows(float *dst, const float *src, const int64_t *rows, int64_t n_rows, int d, void *stream)
+{
+    URE_ARG(dst && src && rows && n_rows >= 0 && d >= 4 && d % 4 == 0);
+    if (n_rows == 0) return 0;
+    const int64_t total = n_rows * (d / 4);
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 2048);
+    hipLaunchKernelGGL(merge_rows_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), dst, src, rows,
+                       n_rows, d / 4);
+    URE_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// Internal helpers shared by the HIP translation units of libultrare_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "ultrare_hip.h"
+
+namespace ure {
+
+constexpr int kWave = 64;            // gfx950 wavefront
+constexpr int kBlock = 256;          // 4 wavefronts per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+char *err_buf();                     // thread-local message buffer (1 KiB)
+int fail(int code, const char *fmt, ...);
+
+#define URE_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return ::ure::fail((int)e_, "%s:%d %s -> %s", __FILE__, __LINE__, #call,          \
+                               hipGetErrorString(e_));                                        \
+    } while (0)
+
+#define URE_ARG(cond)                                                                         \
+    do {                                                                                      \
+        if (!(cond)) return ::ure::fail(-1, "%s:%d argument check failed: %s", __FILE__,      \
+                                        __LINE__, #cond);                                     \
+    } while (0)
+
+inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// Sum over the LPR consecutive lanes that share one table row (LPR = d/4 lanes,
+// one float4 each).  xor-butterfly: every lane of the group ends with the total.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// Sum across the 64/LPR groups of a wavefront (lanes with equal lane % LPR).
+template <int LPR>
+__device__ __forceinline__ float cross_group_sum(float v)
+{
+#pragma unroll
+    for (int o = LPR; o < kWave; o <<= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+}  // namespace ure

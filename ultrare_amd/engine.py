@@ -1,0 +1,259 @@
+"""Host side of the MI355X engine: HBM layout of a shard, training jobs, evaluation.
+
+This file holds no arithmetic of the hot path -- that lives in csrc/*.hip behind
+include/ultrare_hip.h -- only layout building (numpy, once per shard), device memory
+(torch tensors) and launches.
+
+HBM layout of one shard:
+  by-user CSR  u_off[n_user+1] i32 | u_oid[N] i32 (item ids) | u_r[N] f32 | u_b[N] u16 | u_pos[N] i32
+  by-item CSR  i_off[n_item+1] i32 | i_oid[N] i32 (user ids) | i_r[N] f32 | i_b[N] u16 | i_pos[N] i32
+  row_sched[n_user+n_item] i32   destination rows, heaviest first (first n_heavy: one workgroup each)
+  U[2][n_user][d] V[2][n_item][d] f32 ping-pong weights ; mU, mV momentum
+  perm[epochs][N] i32 ; lr[epochs] f32 ; sse[epochs] f64
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _native as nv
+
+HEAVY_NNZ = int(os.environ.get('URE_HEAVY_NNZ', '512'))
+
+
+def pad_dim(d):
+    """Table width used on the device: next power of two >= max(d, 4).  Padding
+    columns are zero at init; their gradient and decay keep them exactly zero."""
+    p = 4
+    while p < d:
+        p *= 2
+    if p > 256:
+        raise ValueError(f'embedding width {d} > 256 is not supported by the gfx950 kernels')
+    return p
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise nv.NativeError('no HIP device visible: the SISA hot path has no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _csr(keys, n_rows):
+    """Stable grouping of file-order entries by key -> (offsets, order, inverse)."""
+    order = np.argsort(keys, kind='stable').astype(np.int32)
+    counts = np.bincount(keys, minlength=n_rows)
+    off = np.zeros(n_rows + 1, dtype=np.int32)
+    np.cumsum(counts, out=off[1:])
+    pos = np.empty(len(keys), dtype=np.int32)
+    pos[order] = np.arange(len(keys), dtype=np.int32)
+    return off, order, pos, counts
+
+
+class ShardData:
+    """One shard's interactions laid out for the step kernel (both CSR views)."""
+
+    def __init__(self, uid, iid, rating, n_user, n_item, device=None, heavy_nnz=None):
+        uid = np.ascontiguousarray(uid, dtype=np.int32)
+        iid = np.ascontiguousarray(iid, dtype=np.int32)
+        rating = np.ascontiguousarray(rating, dtype=np.float32)
+        n = len(uid)
+        if n == 0:
+            raise ValueError('a shard needs at least one interaction')
+        if not (len(iid) == n and len(rating) == n):
+            raise ValueError('uid / iid / rating lengths differ')
+        if uid.min() < 0 or uid.max() >= n_user or iid.min() < 0 or iid.max() >= n_item:
+            raise ValueError('user or item id outside [0, n_user) x [0, n_item)')
+        self.N, self.n_user, self.n_item = n, int(n_user), int(n_item)
+        self.device = device or _device()
+        u_off, u_ord, u_pos, u_cnt = _csr(uid, n_user)
+        i_off, i_ord, i_pos, i_cnt = _csr(iid, n_item)
+        nnz = np.concatenate([u_cnt, i_cnt])
+        sched = np.argsort(-nnz, kind='stable').astype(np.int32)
+        thr = HEAVY_NNZ if heavy_nnz is None else heavy_nnz
+        self.n_heavy = int((nnz > thr).sum())
+        self.max_row = int(nnz.max())
+        dev = self.device
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.u_off, self.u_oid, self.u_r, self.u_pos = to(u_off), to(iid[u_ord]), to(rating[u_ord]), to(u_pos)
+        self.i_off, self.i_oid, self.i_r, self.i_pos = to(i_off), to(uid[i_ord]), to(rating[i_ord]), to(i_pos)
+        self.u_b = torch.zeros(n, dtype=torch.int16, device=dev)
+        self.i_b = torch.zeros(n, dtype=torch.int16, device=dev)
+        self.row_sched = to(sched)
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in
+                   (self.u_off, self.u_oid, self.u_r, self.u_pos, self.u_b, self.i_off, self.i_oid, self.i_r,
+                    self.i_pos, self.i_b, self.row_sched))
+
+
+class TrainJob:
+    """A set of shards trained side by side, one optimizer step of each per launch.
+
+    shards : list[ShardData]
+    inits  : list of (U0 [n_user,k], V0 [n_item,k]) float32 numpy / CPU tensors
+    perms  : list of int32 [epochs, N_s] arrays (numpy or torch; CPU or device)
+    """
+
+    def __init__(self, shards, inits, perms, k, batch, epochs, lr, lam, momentum, lr_decay=1.0, lr_step=50):
+        assert len(shards) == len(inits) == len(perms) and len(shards) > 0
+        self.shards, self.k, self.d = shards, int(k), pad_dim(int(k))
+        self.batch, self.epochs = int(batch), int(epochs)
+        dev = shards[0].device
+        self.device = dev
+        # StepLR(step_size=50, gamma): lr of epoch t (scratch.py:69,79-80)
+        lr_host = np.array([lr * (lr_decay ** (t // lr_step)) for t in range(self.epochs)], dtype=np.float32)
+        self.lr = torch.from_numpy(lr_host).to(dev)
+        self.state = []
+        descs = (nv.UreShard * len(shards))()
+        for s, (sh, (U0, V0), perm) in enumerate(zip(shards, inits, perms)):
+            U0 = torch.as_tensor(U0, dtype=torch.float32)
+            V0 = torch.as_tensor(V0, dtype=torch.float32)
+            assert U0.shape == (sh.n_user, self.k) and V0.shape == (sh.n_item, self.k)
+            U = torch.zeros(2, sh.n_user, self.d, dtype=torch.float32, device=dev)
+            V = torch.zeros(2, sh.n_item, self.d, dtype=torch.float32, device=dev)
+            U[0, :, :self.k] = U0.to(dev)
+            V[0, :, :self.k] = V0.to(dev)
+            mU = torch.zeros(sh.n_user, self.d, dtype=torch.float32, device=dev)
+            mV = torch.zeros(sh.n_item, self.d, dtype=torch.float32, device=dev)
+            perm = torch.as_tensor(perm)
+            assert perm.shape == (self.epochs, sh.N), f'perm of shard {s} must be [epochs, N]'
+            perm = perm.to(device=dev, dtype=torch.int32).contiguous()
+            sse = torch.zeros(self.epochs, dtype=torch.float64, device=dev)
+            self.state.append({'U': U, 'V': V, 'mU': mU, 'mV': mV, 'perm': perm, 'sse': sse})
+            D = descs[s]
+            for name in ('u_off', 'u_oid', 'u_r', 'u_b', 'u_pos', 'i_off', 'i_oid', 'i_r', 'i_b', 'i_pos', 'row_sched'):
+                setattr(D, name, nv.ptr(getattr(sh, name)))
+            D.n_heavy = sh.n_heavy
+            D.U[0], D.U[1] = nv.ptr(U[0]), nv.ptr(U[1])
+            D.V[0], D.V[1] = nv.ptr(V[0]), nv.ptr(V[1])
+            D.mU, D.mV = nv.ptr(mU), nv.ptr(mV)
+            D.perm, D.lr, D.sse = nv.ptr(perm), nv.ptr(self.lr), nv.ptr(sse)
+            D.N, D.n_user, D.n_item, D.d = sh.N, sh.n_user, sh.n_item, self.d
+            D.batch, D.epochs = self.batch, self.epochs
+            D.lam, D.mu = float(lam), float(momentum)
+        self._descs = descs
+        self._job = ctypes.c_void_p()
+        nv.check(nv.lib().ure_job_create(descs, len(shards), ctypes.byref(self._job)), 'ure_job_create')
+        self.ticks = int(nv.lib().ure_job_ticks(self._job))
+        self.shard_steps = [int(nv.lib().ure_job_shard_steps(self._job, s)) for s in range(len(shards))]
+        self.done = 0
+
+    def steps_per_epoch(self, s):
+        return self.shard_steps[s] // self.epochs
+
+    def run(self, n_ticks=None, stream=None):
+        """Enqueue the next n_ticks optimizer steps of every shard (default: all)."""
+        t1 = self.ticks if n_ticks is None else min(self.ticks, self.done + int(n_ticks))
+        if t1 > self.done:
+            nv.check(nv.lib().ure_job_train(self._job, self.done, t1, nv.stream_handle(stream)), 'ure_job_train')
+            self.done = t1
+        return self.done
+
+    def run_epochs(self, n_epochs, stream=None):
+        """Single-shard convenience: advance by whole epochs."""
+        assert len(self.shards) == 1
+        return self.run(n_epochs * self.steps_per_epoch(0), stream)
+
+    def tables(self, s):
+        """Current (U, V) of shard s as device views [rows, k]."""
+        cur = min(self.done, self.shard_steps[s]) & 1
+        st = self.state[s]
+        return st['U'][cur, :, :self.k], st['V'][cur, :, :self.k]
+
+    def padded_tables(self, s):
+        cur = min(self.done, self.shard_steps[s]) & 1
+        st = self.state[s]
+        return st['U'][cur], st['V'][cur]
+
+    def epoch_sse(self, s):
+        """Per-epoch sum of squared training errors (host float64 array; synchronises)."""
+        return self.state[s]['sse'].cpu().numpy()
+
+    def close(self):
+        if self._job:
+            nv.lib().ure_job_destroy(self._job)
+            self._job = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_LOG2_TAB = np.log2(np.arange(2, 11)).astype(np.float64)      # utils.py:210
+
+
+class EvalSet:
+    """Test interactions grouped by user (first-appearance order, utils.py:156-163)
+    and resident on the device, plus the output buffers of the two eval kernels."""
+
+    def __init__(self, uid, iid, rating, device=None):
+        uid = np.ascontiguousarray(uid, dtype=np.int32)
+        iid = np.ascontiguousarray(iid, dtype=np.int32)
+        rating = np.ascontiguousarray(rating, dtype=np.float32)
+        self.n = len(uid)
+        self.device = device or _device()
+        if self.n:
+            _, first = np.unique(uid, return_index=True)
+            users = uid[np.sort(first)]                       # first-appearance order
+            rank = np.empty(int(uid.max()) + 1, dtype=np.int64)
+            rank[users] = np.arange(len(users))
+            order = np.argsort(rank[uid], kind='stable')
+            counts = np.bincount(rank[uid], minlength=len(users))
+        else:
+            users, order, counts = np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0, np.int64)
+        off = np.zeros(len(users) + 1, dtype=np.int32)
+        np.cumsum(counts, out=off[1:])
+        self.users, self.n_users = users, len(users)
+        dev = self.device
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.uid, self.iid, self.rating, self.off = to(uid[order]), to(iid[order]), to(rating[order]), to(off)
+        self.pred = torch.zeros(max(self.n, 1), dtype=torch.float32, device=dev)
+        self.hits = torch.zeros(max(self.n_users, 1), dtype=torch.int32, device=dev)
+        self.ndcg = torch.zeros(max(self.n_users, 1), dtype=torch.float64, device=dev)
+        self.sse = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.log2 = to(_LOG2_TAB)
+        self.order = order
+
+    def evaluate(self, models, d, stream=None, top_k=10):
+        """baseTest (utils.py:115-187) for an ensemble: `models` = list of (U, V) device
+        tensors with row stride d (the padded width).  Returns (rmse, ndcg, hr)."""
+        assert top_k == 10, 'the kernel implements the reference default top_k=10'
+        if self.n == 0:
+            return float('nan'), float('nan'), float('nan')
+        L, st = nv.lib(), nv.stream_handle(stream)
+        self.sse.zero_()
+        S = len(models)
+        for c0 in range(0, S, nv.MAX_MODELS_PER_CALL):
+            chunk = models[c0:c0 + nv.MAX_MODELS_PER_CALL]
+            for U, V in chunk:
+                assert U.is_contiguous() and V.is_contiguous() and U.shape[1] == d and V.shape[1] == d
+            Up = (ctypes.c_void_p * len(chunk))(*[U.data_ptr() for U, _ in chunk])
+            Vp = (ctypes.c_void_p * len(chunk))(*[V.data_ptr() for _, V in chunk])
+            nv.check(L.ure_score(Up, Vp, len(chunk), S, int(c0 == 0), int(c0 + len(chunk) >= S),
+                                 nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating), self.n, d,
+                                 nv.ptr(self.pred), nv.ptr(self.sse), st), 'ure_score')
+        nv.check(L.ure_eval_users(nv.ptr(self.off), self.n_users, nv.ptr(self.pred), nv.ptr(self.rating),
+                                  nv.ptr(self.log2), nv.ptr(self.hits), nv.ptr(self.ndcg), st), 'ure_eval_users')
+        sse = float(self.sse.cpu().item())
+        hits = self.hits[:self.n_users].cpu().numpy()
+        ndcg = self.ndcg[:self.n_users].cpu().numpy()
+        rmse = float(np.sqrt(sse / self.n))
+        return rmse, float(np.mean(ndcg)), float(np.mean(hits / top_k))
+
+    def predictions(self):
+        """Ensemble predictions of the last evaluate() in the caller's original row order."""
+        out = np.empty(self.n, dtype=np.float32)
+        out[self.order] = self.pred[:self.n].cpu().numpy()
+        return out
+
+
+def merge_rows(dst, src, rows, stream=None):
+    """dst[rows] = src[rows] on the device (sisa.py:55-56)."""
+    rows = torch.as_tensor(np.asarray(rows, dtype=np.int64)).to(dst.device)
+    assert dst.is_contiguous() and src.is_contiguous() and dst.shape == src.shape
+    nv.check(nv.lib().ure_merge_rows(nv.ptr(dst), nv.ptr(src), nv.ptr(rows), rows.numel(), dst.shape[1],
+                                     nv.stream_handle(stream)), 'ure_merge_rows')
+    return dst

@@ -1,0 +1,169 @@
+"""Model, evaluation and OT grouping with the reference's names (method/utils.py of
+the reference), backed by the HIP engine.
+
+  seed_all     utils.py:21-25
+  MF           utils.py:30-43    two embedding tables; forward = row-wise dot
+  baseTest     utils.py:115-187  ensemble mean score, RMSE, HR@10, NDCG@10
+  computeNDCG / computeDCG  utils.py:190-210
+  ot_cluster   utils.py:628-656  OT balanced clustering (exact EMD)
+  saveObject / loadObject / timefn  utils.py:319-326, 616-626
+
+Training does not go through a `baseTrain(dataloader, model, loss_fn, opt, ...)` loop:
+the per-batch forward / backward / SGD step of utils.py:58-91 is one fused kernel
+launch per step, driven by engine.TrainJob from Scratch.train.
+"""
+import pickle
+import time
+from functools import wraps
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _native as nv
+from .. import engine
+from ..read import as_loader
+from ..rng import seed_all  # noqa: F401  (re-exported under the reference's name)
+
+STD = 1
+
+
+class MF(nn.Module):
+    """utils.py:30-43.  Constructed on the CPU with exactly the reference's four normal
+    fills (so the global torch stream advances identically); `.to('cuda')` moves the
+    tables to HBM.  forward() scores (uid, iid) pairs with the HIP scoring kernel."""
+
+    def __init__(self, n_user, n_item, k=16):
+        super().__init__()
+        self.k = k
+        self.user_mat = nn.Embedding(n_user, k)
+        self.item_mat = nn.Embedding(n_item, k)
+        self.init_weight()
+
+    def init_weight(self):
+        nn.init.normal_(self.user_mat.weight, std=STD)
+        nn.init.normal_(self.item_mat.weight, std=STD)
+
+    @classmethod
+    def from_tables(cls, U, V):
+        """Wrap trained device tables without drawing from any generator."""
+        m = cls.__new__(cls)
+        nn.Module.__init__(m)
+        m.k = U.shape[1]
+        m.user_mat = nn.Embedding(U.shape[0], U.shape[1], _weight=U)
+        m.item_mat = nn.Embedding(V.shape[0], V.shape[1], _weight=V)
+        m.requires_grad_(False)
+        return m
+
+    def forward(self, uid, iid):
+        U, V, d = padded_tables(self)
+        uid = uid.to(device=U.device, dtype=torch.int32).contiguous()
+        iid = iid.to(device=U.device, dtype=torch.int32).contiguous()
+        pred = torch.empty(uid.numel(), dtype=torch.float32, device=U.device)
+        import ctypes
+        Up = (ctypes.c_void_p * 1)(U.data_ptr())
+        Vp = (ctypes.c_void_p * 1)(V.data_ptr())
+        nv.check(nv.lib().ure_score(Up, Vp, 1, 1, 1, 1, nv.ptr(uid), nv.ptr(iid), None, uid.numel(), d,
+                                    nv.ptr(pred), None, nv.stream_handle()), 'ure_score')
+        return pred
+
+
+def padded_tables(model):
+    """(U, V, d) as contiguous device tensors whose width is the kernels' padded d."""
+    U, V = model.user_mat.weight.detach(), model.item_mat.weight.detach()
+    if not U.is_cuda:
+        raise nv.NativeError('model tables are not on the HIP device (call model.to("cuda")): no CPU fallback')
+    d = engine.pad_dim(U.shape[1])
+
+    def fix(t):
+        if t.shape[1] == d and t.is_contiguous() and t.dtype == torch.float32:
+            return t
+        out = torch.zeros(t.shape[0], d, dtype=torch.float32, device=t.device)
+        out[:, :t.shape[1]] = t
+        return out
+    return fix(U), fix(V), d
+
+
+def baseTest(dataloader, models, loss_fn=None, device=None, verbose=0, top_k=10):
+    """utils.py:115-187: (rmse, ndcg, hr) of the mean-ensemble of `models` on a test
+    loader.  loss_fn / device are accepted for signature compatibility."""
+    ev = as_loader(dataloader).eval_set()
+    tabs = [padded_tables(m) for m in models]
+    d = tabs[0][2]
+    rmse, ndcg, hr = ev.evaluate([(U, V) for U, V, _ in tabs], d, top_k=top_k)
+    if verbose == 2:
+        print(f'Test - RMSE: {rmse:>.4f}, NDCG: {ndcg:>.3f}, HR: {hr:>.3f}')
+    return rmse, ndcg, hr
+
+
+def computeNDCG(r, top_k):
+    """utils.py:190-207 (host helper; the device kernel computes the same value)."""
+    r = np.asarray(r, dtype=np.float64)
+    if len(r) == 0:
+        return 0
+    r = np.concatenate([r, np.zeros(top_k - len(r))])
+    return computeDCG(r) / computeDCG(np.ones(top_k))
+
+
+def computeDCG(r):
+    """utils.py:209-210."""
+    return r[0] + np.sum(r[1:] / np.log2(np.arange(2, len(r) + 1)))
+
+
+def saveObject(filename, obj):
+    with open(filename + '.pkl', 'wb') as output:
+        pickle.dump(obj, output, pickle.HIGHEST_PROTOCOL)
+
+
+def loadObject(filename):
+    with open(filename + '.pkl', 'rb') as input:
+        return pickle.load(input)
+
+
+def timefn(fn):
+    """utils.py:616-626."""
+    @wraps(fn)
+    def measure_time(*args, **kwargs):
+        t1 = time.time()
+        result = fn(*args, **kwargs)
+        print(f"@time: {time.time() - t1: .5f} s")
+        return result
+    return measure_time
+
+
+def _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d):
+    """One round of utils.py:637-648 on the device + the exact host LP."""
+    L, st = nv.lib(), nv.stream_handle()
+    cd = torch.from_numpy(np.ascontiguousarray(centroid, dtype=np.float32)).to(Xd.device)
+    nv.check(L.ure_ot_cost(nv.ptr(Xd), nv.ptr(cd), n, k, d, nv.ptr(dist_d), st), 'ure_ot_cost')
+    dist = dist_d.cpu().numpy()                                       # [k, n] fp32 (synchronises)
+    label, _, _ = nv.ot_assign(dist)                                  # exact EMD + argmax (host)
+    label_d.copy_(torch.from_numpy(label))
+    nv.check(L.ure_ot_centroids(nv.ptr(Xd), nv.ptr(label_d), n, k, d, nv.ptr(cent_d), nv.ptr(counts_d), st),
+             'ure_ot_centroids')
+    return dist, label, cent_d.cpu().numpy()
+
+
+@timefn
+def ot_cluster(X, k, max_iters=10):
+    """utils.py:628-656.  Initial centroids come from the global numpy generator, as in
+    the reference.  Returns (inertia, label[int64])."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    n, d = X.shape
+    if k < 1 or k > n:
+        raise ValueError('need 1 <= k <= n clusters')
+    centroid = X[np.random.choice(n, size=k, replace=False)]
+    dev = engine._device()
+    Xd = torch.from_numpy(X).to(dev)
+    dist_d = torch.empty(k, n, dtype=torch.float32, device=dev)
+    label_d = torch.empty(n, dtype=torch.int32, device=dev)
+    cent_d = torch.empty(k, d, dtype=torch.float32, device=dev)
+    counts_d = torch.empty(k, dtype=torch.int32, device=dev)
+    for _ in range(max_iters):
+        dist, label, new_centroid = _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d)
+        inertia = np.min(dist, axis=0).sum()
+        if np.allclose(centroid, new_centroid):
+            break
+        centroid = new_centroid
+    print(f'{inertia:.3f}', end=' ')
+    return inertia, label.astype(np.int64)

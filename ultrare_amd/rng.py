@@ -1,0 +1,75 @@
+"""RNG stream contract of the reference, host logic.
+
+Everything random on the hot path comes from torch's process-global CPU generator
+(model init, DataLoader base seeds, RandomSampler seeds) plus numpy's global state
+(grouping, deletion set).  To match the reference for a fixed seed the engine must
+consume those streams draw for draw; the draws are data independent, so they can
+be taken up front and the permutations expanded later (or on other threads).
+
+  method/utils.py:31-40   two nn.Embedding constructors + init_weight  -> mf_init
+  torch DataLoader        _base_seed per iterator                      -> draw_seed
+  torch RandomSampler     seed -> Generator -> randperm(N)             -> epoch_perm
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+
+def mf_init(n_user, n_item, k):
+    """The four N(0,1) fills of `MF(n_user, n_item, k)`; the first two (Embedding
+    constructors) are overwritten by init_weight but still advance the stream."""
+    torch.empty(n_user, k).normal_(0, 1)
+    torch.empty(n_item, k).normal_(0, 1)
+    U0 = torch.empty(n_user, k).normal_(0, 1)
+    V0 = torch.empty(n_item, k).normal_(0, 1)
+    return U0, V0
+
+
+def draw_seed():
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
+def epoch_seeds(epochs, with_total_test):
+    """Per epoch the reference draws: train loader base seed, sampler seed, group-test
+    loader base seed and (SISA only) total-test loader base seed (scratch.py:78-97).
+    Returns the sampler seeds; the others only advance the stream."""
+    seeds = []
+    for _ in range(epochs):
+        draw_seed()
+        seeds.append(draw_seed())
+        draw_seed()
+        if with_total_test:
+            draw_seed()
+    return seeds
+
+
+def epoch_perm(seed, n):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randperm(n, generator=g).to(torch.int32)
+
+
+def epoch_perms(seeds, n, threads=0):
+    """[len(seeds), n] int32 permutations; each has its own generator, so they are
+    independent and can be expanded concurrently (torch releases the GIL)."""
+    out = torch.empty(len(seeds), n, dtype=torch.int32)
+
+    def fill(t):
+        out[t] = epoch_perm(seeds[t], n)
+
+    if threads and threads > 1 and len(seeds) > 1:
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(fill, range(len(seeds))))
+    else:
+        for t in range(len(seeds)):
+            fill(t)
+    return out
+
+
+def seed_all(seed):
+    """method/utils.py:21-25 as written (numpy + the device generator; NOT the torch
+    CPU generator -- SURVEY D7: the harness seeds that one)."""
+    np.random.seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
