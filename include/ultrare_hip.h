@@ -98,6 +98,12 @@ int64_t ure_job_ticks(const ure_job_t *job);
  * tables are U[ticks_done & 1] / V[ticks_done & 1] of each shard, where
  * ticks_done = min(tick1, shard steps). */
 int ure_job_train(ure_job_t *job, int64_t tick0, int64_t tick1, void *stream);
+/* Measurement aid (bench.py's roofline leg): the same ticks, each kernel launch
+ * bracketed by a pair of HIP events on `stream`; synchronises the stream and returns
+ * the summed durations and launch counts of the step kernel and of the per-epoch
+ * batch-tag kernel. */
+int ure_job_train_profiled(ure_job_t *job, int64_t tick0, int64_t tick1, void *stream, double *step_ms,
+                           int64_t *n_step, double *assign_ms, int64_t *n_assign);
 
 /* ---------------------------------------------------------------------------
  * Evaluation (baseTest, utils.py:115-187)

@@ -262,22 +262,31 @@ int64_t ure_job_ticks(const ure_job_t *j)
     return job ? job->ticks : -1;
 }
 
-int ure_job_train(ure_job_t *j, int64_t tick0, int64_t tick1, void *stream)
+static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStream_t st, std::vector<hipEvent_t> *step_ev,
+                       std::vector<hipEvent_t> *assign_ev)
 {
-    auto *job = reinterpret_cast<ure::ure_job *>(j);
-    URE_ARG(job && tick0 >= 0 && tick1 >= tick0);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    tick1 = std::min(tick1, job->ticks);
     const unsigned n_shards = (unsigned)job->host.size();
     const unsigned assign_blocks = (unsigned)std::min((job->max_n + kBlock - 1) / kBlock, 2048);
+    auto mark = [&](std::vector<hipEvent_t> *v) -> int {
+        if (!v) return 0;
+        hipEvent_t e;
+        URE_HIP(hipEventCreate(&e));
+        v->push_back(e);
+        URE_HIP(hipEventRecord(e, st));
+        return 0;
+    };
     for (int64_t t = tick0; t < tick1; ++t) {
         bool epoch_start = false;
         for (const ure_shard_t &S : job->host) {
             const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
             if (t < steps * S.epochs && t % steps == 0) { epoch_start = true; break; }
         }
-        if (epoch_start)
+        if (epoch_start) {
+            if (int rc = mark(assign_ev)) return rc;
             hipLaunchKernelGGL(assign_batches_kernel, dim3(assign_blocks, n_shards), dim3(kBlock), 0, st, job->dev, t);
+            if (int rc = mark(assign_ev)) return rc;
+        }
+        if (int rc = mark(step_ev)) return rc;
         switch (job->d / 4) {
             case 1: launch_step<1>(job, t, st); break;
             case 2: launch_step<2>(job, t, st); break;
@@ -288,9 +297,44 @@ int ure_job_train(ure_job_t *j, int64_t tick0, int64_t tick1, void *stream)
             case 64: launch_step<64>(job, t, st); break;
             default: return fail(-1, "ure_job_train: unsupported d=%d", job->d);
         }
+        if (int rc = mark(step_ev)) return rc;
     }
     URE_HIP(hipGetLastError());
     return 0;
+}
+
+int ure_job_train(ure_job_t *j, int64_t tick0, int64_t tick1, void *stream)
+{
+    auto *job = reinterpret_cast<ure::ure_job *>(j);
+    URE_ARG(job && tick0 >= 0 && tick1 >= tick0);
+    return train_ticks(job, tick0, std::min(tick1, job->ticks), static_cast<hipStream_t>(stream), nullptr, nullptr);
+}
+
+int ure_job_train_profiled(ure_job_t *j, int64_t tick0, int64_t tick1, void *stream, double *step_ms, int64_t *n_step,
+                           double *assign_ms, int64_t *n_assign)
+{
+    auto *job = reinterpret_cast<ure::ure_job *>(j);
+    URE_ARG(job && tick0 >= 0 && tick1 >= tick0 && step_ms && n_step && assign_ms && n_assign);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    std::vector<hipEvent_t> se, ae;
+    int rc = train_ticks(job, tick0, std::min(tick1, job->ticks), st, &se, &ae);
+    if (rc == 0) {
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail((int)e, "ure_job_train_profiled: %s", hipGetErrorString(e));
+    }
+    *step_ms = *assign_ms = 0.0;
+    *n_step = (int64_t)se.size() / 2;
+    *n_assign = (int64_t)ae.size() / 2;
+    for (int which = 0; which < 2 && rc == 0; ++which) {
+        auto &v = which ? ae : se;
+        for (size_t q = 0; q + 1 < v.size(); q += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, v[q], v[q + 1]) == hipSuccess) (which ? *assign_ms : *step_ms) += ms;
+        }
+    }
+    for (hipEvent_t e : se) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ae) (void)hipEventDestroy(e);
+    return rc;
 }
 
 }  // extern "C"

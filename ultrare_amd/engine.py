@@ -150,6 +150,18 @@ class TrainJob:
             self.done = t1
         return self.done
 
+    def run_profiled(self, n_ticks, stream=None):
+        """Like run(), with every launch bracketed by HIP events (synchronises).
+        -> (step kernel ms, launches, tag kernel ms, launches)."""
+        t1 = min(self.ticks, self.done + int(n_ticks))
+        sm, am = ctypes.c_double(), ctypes.c_double()
+        ns, na = ctypes.c_int64(), ctypes.c_int64()
+        nv.check(nv.lib().ure_job_train_profiled(self._job, self.done, t1, nv.stream_handle(stream), ctypes.byref(sm),
+                                                 ctypes.byref(ns), ctypes.byref(am), ctypes.byref(na)),
+                 'ure_job_train_profiled')
+        self.done = t1
+        return sm.value, ns.value, am.value, na.value
+
     def run_epochs(self, n_epochs, stream=None):
         """Single-shard convenience: advance by whole epochs."""
         assert len(self.shards) == 1
