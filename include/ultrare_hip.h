@@ -39,31 +39,32 @@ int ure_device_info(int dev, int *n_cu, int *wave_size, char *arch, int arch_len
 /* ---------------------------------------------------------------------------
  * One SISA shard = one MF model trained in isolation (sisa.py:33-36).
  *
- * The shard's interactions are held twice, as CSR grouped by user and as CSR
- * grouped by item (both built once by the host, stable in file order), so that a
- * wavefront that owns a destination row can sum that row's gradient in registers
- * and apply the optimizer to it immediately -- no atomics, no gradient tables.
- * `*_pos` map an interaction's file-order index to its slot in each CSR;
- * `*_b` receive, once per epoch, the batch number every interaction falls in
- * under that epoch's permutation (read.py:133: batch s = perm[s*B : (s+1)*B]).
+ * The shard's interactions are held twice, grouped by user and grouped by item
+ * (built once by the host, stable in file order), so that whoever owns a
+ * destination row can sum that row's gradient in registers and apply the
+ * optimizer to it immediately -- no atomics, no gradient tables.
+ * `*_pos` map an interaction's file-order index to its two slots; `ent_tag`
+ * receives, once per epoch, the batch number every interaction falls in under that
+ * epoch's permutation (read.py:133: batch s = perm[s*B : (s+1)*B]).
  * ------------------------------------------------------------------------- */
 typedef struct ure_shard {
-    /* interactions, grouped by user */
-    const int32_t *u_off;   /* [n_user+1] row offsets                               */
-    const int32_t *u_oid;   /* [N] item id of the entry                             */
-    const float   *u_r;     /* [N] rating / max_rating (read.py:66)                 */
-    uint16_t      *u_b;     /* [N] batch number this epoch (written by the engine)  */
-    const int32_t *u_pos;   /* [N] file-order index -> slot in the by-user arrays   */
-    /* interactions, grouped by item */
-    const int32_t *i_off;   /* [n_item+1]                                           */
-    const int32_t *i_oid;   /* [N] user id of the entry                             */
-    const float   *i_r;     /* [N]                                                  */
-    uint16_t      *i_b;     /* [N]                                                  */
-    const int32_t *i_pos;   /* [N]                                                  */
-    /* row schedule: destination rows (user u -> u, item i -> n_user + i) ordered
-     * heaviest first; the first n_heavy get a whole 4-wave workgroup each          */
-    const int32_t *row_sched;  /* [n_user + n_item]                                 */
-    int32_t        n_heavy;
+    /* Interactions.  Every destination row (user u -> row id u, item i -> row id
+     * n_user + i) owns a segment of slots; the segments of all rows sit in ONE slot
+     * array in schedule order (heaviest row first), each starting on a multiple of 8
+     * slots and padded to a multiple of 8 with slots that never match a batch.      */
+    const int32_t *ent_oid;  /* [n_slots] opposite id: item id in a user row, user id in an item row */
+    const float   *ent_r;    /* [n_slots] rating / max_rating (read.py:66)                */
+    uint16_t      *ent_tag;  /* [n_slots] batch number this epoch (written by the engine;
+                              * the caller initialises every slot to 0xFFFF)              */
+    const int32_t *u_pos;    /* [N] file-order index -> its slot in the user's segment    */
+    const int32_t *i_pos;    /* [N] file-order index -> its slot in the item's segment    */
+    /* Row schedule, heaviest first: {row id, first slot, end slot (padded), nnz}.
+     * [0, n_block) one workgroup per row | [n_block, n_wave) one wavefront per row |
+     * [n_wave, n_active) one lane group (d/4 lanes) per row | [n_active, rows) rows with
+     * no interaction in this shard: they only decay.                                  */
+    const int32_t *sched;    /* [n_user + n_item][4]                                      */
+    int32_t        n_block, n_wave, n_active;
+    int64_t        n_slots;
     /* model state (utils.py:31-40, scratch.py:64-69) */
     float *U[2];            /* [n_user][d] ping-pong: step t reads [t&1], writes [(t+1)&1] */
     float *V[2];            /* [n_item][d]                                          */
@@ -72,7 +73,8 @@ typedef struct ure_shard {
     /* per-epoch inputs / outputs */
     const int32_t *perm;    /* [epochs][N] the epoch permutations (RandomSampler)   */
     const float   *lr;      /* [epochs] learning rate of each epoch (StepLR)        */
-    double        *sse;     /* [epochs] sum over the epoch of (pred - r)^2          */
+    float         *sse;     /* [epochs][n_user] per-user sum over the epoch of (pred - r)^2;
+                             * the epoch's training loss is the sum over users       */
     int32_t N, n_user, n_item, d;
     int32_t batch;          /* B (config.py:26)                                     */
     int32_t epochs;

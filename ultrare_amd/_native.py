@@ -22,9 +22,8 @@ _i64 = ctypes.c_int64
 class UreShard(ctypes.Structure):
     """struct ure_shard (include/ultrare_hip.h)."""
     _fields_ = [
-        ('u_off', _vp), ('u_oid', _vp), ('u_r', _vp), ('u_b', _vp), ('u_pos', _vp),
-        ('i_off', _vp), ('i_oid', _vp), ('i_r', _vp), ('i_b', _vp), ('i_pos', _vp),
-        ('row_sched', _vp), ('n_heavy', _i32),
+        ('ent_oid', _vp), ('ent_r', _vp), ('ent_tag', _vp), ('u_pos', _vp), ('i_pos', _vp),
+        ('sched', _vp), ('n_block', _i32), ('n_wave', _i32), ('n_active', _i32), ('n_slots', _i64),
         ('U', _vp * 2), ('V', _vp * 2), ('mU', _vp), ('mV', _vp),
         ('perm', _vp), ('lr', _vp), ('sse', _vp),
         ('N', _i32), ('n_user', _i32), ('n_item', _i32), ('d', _i32),

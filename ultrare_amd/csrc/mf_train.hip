@@ -16,9 +16,16 @@
 //     is written once into the *other* half of a ping-pong weight pair, so gathers
 //     of this step always see step-t weights.  No atomics, no gradient tables, and
 //     the result is bitwise reproducible run to run.
-//   * Rows with many entries ("heavy", first n_heavy of row_sched) get a whole
-//     4-wave workgroup; partial sums meet in LDS in a fixed order.
-//   * Batch membership is a 2-byte tag per CSR slot, refreshed once per epoch by
+//   * Work is sized to the row: the heaviest rows get a whole 4-wave workgroup (partial
+//     sums meet in LDS in a fixed order), medium rows one wavefront, and the many small
+//     rows one LANE GROUP each (d/4 lanes), so a wavefront advances 64/(d/4) rows at
+//     once with private accumulators and no cross-lane reduction; rows the shard never
+//     touches only decay and are updated 64/(d/4) per wave instruction.  The kernel is
+//     bound by dependent-load latency at ml-1m scale, so every path issues its
+//     independent loads (tags, ids, ratings; four row gathers) together.
+//   * Row segments live in one slot array in schedule order, 8-aligned and padded, so
+//     a lane scans 8 slots with one 16-byte load per array.
+//   * Batch membership is a 2-byte tag per slot, refreshed once per epoch by
 //     assign_batches_kernel from the epoch's permutation.
 //   * Shards are independent (sisa.py:33-36), so a job's shards share each launch
 //     (blockIdx.y = shard): one tick advances every shard by one optimizer step.
@@ -32,7 +39,10 @@
 
 namespace ure {
 
-constexpr int kQueue = 128;   // per-wave ring of matched entries (>= 64 + 64/LPR - 1)
+constexpr int kSuper = 4;       // 64-slot chunks scanned together on the wave / block path
+constexpr int kQueue = 512;     // per-wave match queue: ring of 512 on the wave path,
+                                // 64/LPR private queues of 8*LPR on the group path
+constexpr int kSegPerLane = 8;  // slots one lane scans per segment on the group path
 
 struct ure_job {
     std::vector<ure_shard_t> host;
@@ -45,8 +55,9 @@ struct ure_job {
 
 __device__ __forceinline__ int shard_steps(const ure_shard_t &S) { return (S.N + S.batch - 1) / S.batch; }
 
-// Once per epoch and shard: tag every CSR slot with the batch its interaction is
-// drawn into.  perm[b] = file-order index of the b-th sample of the epoch.
+// Once per epoch and shard: tag every slot with the batch its interaction is drawn
+// into.  perm[b] = file-order index of the b-th sample of the epoch (read.py:133).
+// Four samples per thread so that the eight dependent position look-ups overlap.
 __global__ __launch_bounds__(kBlock) void assign_batches_kernel(const ure_shard_t *__restrict__ shards, int64_t tick)
 {
     const ure_shard_t &S = shards[blockIdx.y];
@@ -55,12 +66,23 @@ __global__ __launch_bounds__(kBlock) void assign_batches_kernel(const ure_shard_
     const int epoch = (int)(tick / steps);
     if (tick - (int64_t)epoch * steps != 0) return;
     const int32_t *__restrict__ perm = S.perm + (size_t)epoch * S.N;
-    for (int b = blockIdx.x * kBlock + threadIdx.x; b < S.N; b += gridDim.x * kBlock) {
-        const int j = perm[b];
-        if ((unsigned)j >= (unsigned)S.N) continue;   // malformed permutation: never index outside the shard
-        const uint16_t s = (uint16_t)(b / S.batch);
-        S.u_b[S.u_pos[j]] = s;
-        S.i_b[S.i_pos[j]] = s;
+    const int n = S.N;
+    for (int b0 = (blockIdx.x * kBlock + threadIdx.x) * 4; b0 < n; b0 += gridDim.x * kBlock * 4) {
+        int j[4], pu[4], pi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) j[k] = b0 + k < n ? perm[b0 + k] : -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = (unsigned)j[k] < (unsigned)n;   // malformed permutation: never index outside the shard
+            pu[k] = ok ? S.u_pos[j[k]] : -1;
+            pi[k] = ok ? S.i_pos[j[k]] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint16_t s = (uint16_t)((b0 + k) / S.batch);
+            if (pu[k] >= 0) S.ent_tag[pu[k]] = s;
+            if (pi[k] >= 0) S.ent_tag[pi[k]] = s;
+        }
     }
 }
 
@@ -68,7 +90,9 @@ template <int LPR>
 __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__restrict__ shards, int64_t tick)
 {
     constexpr int D = LPR * 4;
-    constexpr int G = kWave / LPR;           // entries gathered per wave instruction
+    constexpr int G = kWave / LPR;           // table rows one wave instruction gathers
+    constexpr int R4 = 4 * G;
+    constexpr int CAP = kSegPerLane * LPR;   // group path: slots per segment = queue capacity per group
     __shared__ int q_oid[kWavesPerBlock][kQueue];
     __shared__ float q_r[kWavesPerBlock][kQueue];
     __shared__ float4 part_acc[kWavesPerBlock][LPR];
@@ -83,77 +107,246 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     const bool first = tick == 0;
     const int n_rows = S.n_user + S.n_item;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool heavy = (int)blockIdx.x < S.n_heavy;
-    const int sched = heavy ? (int)blockIdx.x : S.n_heavy + ((int)blockIdx.x - S.n_heavy) * kWavesPerBlock + wave;
-    if (sched >= n_rows) return;             // whole wave (light) or whole block (past the shard's rows)
+    const int sub = lane & (LPR - 1), grp = lane / LPR;
+    const float lam = S.lam, mu = S.mu, lr = S.lr[epoch];
+    const int4 *__restrict__ sched = reinterpret_cast<const int4 *>(S.sched);
+    const int32_t *__restrict__ ent_oid = S.ent_oid;
+    const float *__restrict__ ent_r = S.ent_r;
+    const uint16_t *__restrict__ ent_tag = S.ent_tag;
+    int *qo = q_oid[wave];
+    float *qr = q_r[wave];
+
+    // torch.optim.SGD single-tensor path: g = g + lam*w ; buf = mu*buf + g (buf = g on the
+    // first step) ; w = w - lr*buf.   Writes buf and the step-(t+1) weights of one row slice.
+    auto sgd_update = [&](const float4 &w, const float4 &m4, const float4 &acc, float *mom_p, float *next_p) {
+        float4 g, wn;
+        g.x = fmaf(lam, w.x, acc.x); g.y = fmaf(lam, w.y, acc.y);
+        g.z = fmaf(lam, w.z, acc.z); g.w = fmaf(lam, w.w, acc.w);
+        if (!first) {
+            g.x = __fadd_rn(__fmul_rn(mu, m4.x), g.x); g.y = __fadd_rn(__fmul_rn(mu, m4.y), g.y);
+            g.z = __fadd_rn(__fmul_rn(mu, m4.z), g.z); g.w = __fadd_rn(__fmul_rn(mu, m4.w), g.w);
+        }
+        wn.x = fmaf(-lr, g.x, w.x); wn.y = fmaf(-lr, g.y, w.y);
+        wn.z = fmaf(-lr, g.z, w.z); wn.w = fmaf(-lr, g.w, w.w);
+        *reinterpret_cast<float4 *>(mom_p) = g;
+        *reinterpret_cast<float4 *>(next_p) = wn;
+    };
+
+    // Schedule prefixes -> block ranges:
+    //   [0, n_block)         one row per workgroup   (4 waves scan the segment together)
+    //   [n_block, n_wave)    one row per wavefront
+    //   [n_wave, n_active)   one row per lane group  (64/LPR rows per wavefront)
+    //   [n_active, n_rows)   rows without interactions in this shard: decay only
+    const int nbB = S.n_block;
+    const int nbW = (S.n_wave - S.n_block + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int nbG = (S.n_active - S.n_wave + kWavesPerBlock * G - 1) / (kWavesPerBlock * G);
+    const int blk = (int)blockIdx.x;
+
+    if (blk >= nbB + nbW) {
+        // ------------------------------------------------ group path and decay-only path
+        const bool dense_only = blk >= nbB + nbW + nbG;
+        const int idx = dense_only ? S.n_active + ((blk - nbB - nbW - nbG) * kWavesPerBlock + wave) * G + grp
+                                   : S.n_wave + ((blk - nbB - nbW) * kWavesPerBlock + wave) * G + grp;
+        const bool have = idx < (dense_only ? n_rows : S.n_active);
+        int4 ds = make_int4(0, 0, 0, 0);
+        if (have) ds = sched[idx];
+        const bool is_user = ds.x < S.n_user;
+        const size_t row_off = (size_t)(is_user ? ds.x : ds.x - S.n_user) * D + sub * 4;
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f), m4 = w, acc = w;
+        if (have) {
+            w = *reinterpret_cast<const float4 *>((is_user ? S.U[cur] : S.V[cur]) + row_off);
+            if (!first) m4 = *reinterpret_cast<const float4 *>((is_user ? S.mU : S.mV) + row_off);
+        }
+        float sse = 0.f;
+        if (!dense_only) {
+            const float *__restrict__ other = is_user ? S.V[cur] : S.U[cur];
+            int *gq = qo + grp * CAP;
+            float *gr = qr + grp * CAP;
+            const int beg = ds.y, end = have ? ds.z : 0;
+            for (int seg = beg;; seg += CAP) {
+                if (!__any(seg < end)) break;
+                // every lane scans 8 consecutive slots of its group's row (segments are 8-aligned)
+                const int p0 = seg + sub * kSegPerLane;
+                const bool valid = p0 < end;
+                uint4 t4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                int4 o0 = make_int4(0, 0, 0, 0), o1 = o0;
+                float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+                if (valid) {
+                    t4 = *reinterpret_cast<const uint4 *>(ent_tag + p0);
+                    o0 = *reinterpret_cast<const int4 *>(ent_oid + p0);
+                    o1 = *reinterpret_cast<const int4 *>(ent_oid + p0 + 4);
+                    r0 = *reinterpret_cast<const float4 *>(ent_r + p0);
+                    r1 = *reinterpret_cast<const float4 *>(ent_r + p0 + 4);
+                }
+                const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+                const int ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+                const float rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                unsigned mb = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned tg = (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+                    mb |= (tg == (unsigned)s ? 1u : 0u) << k;
+                }
+                // position of this lane's matches in its group's queue: CSR order = lane-major
+                const int c = __popc(mb);
+                int inc = c;
+#pragma unroll
+                for (int o = 1; o < LPR; o <<= 1) {
+                    const int t = __shfl_up(inc, o, LPR);
+                    if (sub >= o) inc += t;
+                }
+                const int qn = __shfl(inc, LPR - 1, LPR);      // matches of the whole group
+                int wpos = inc - c;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if ((mb >> k) & 1u) {
+                        gq[wpos] = ov[k];
+                        gr[wpos] = rv[k];
+                        ++wpos;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // every group walks its own queue in order, four gathers in flight
+                for (int t0 = 0; __any(t0 < qn); t0 += 4) {
+                    int o[4];
+                    float r[4];
+                    bool act[4];
+                    float4 v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        act[k] = t0 + k < qn;
+                        o[k] = act[k] ? gq[t0 + k] : 0;
+                        r[k] = act[k] ? gr[t0 + k] : 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (act[k]) v[k] = *reinterpret_cast<const float4 *>(other + (size_t)o[k] * D + sub * 4);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float p = w.x * v[k].x;
+                        p = fmaf(w.y, v[k].y, p);
+                        p = fmaf(w.z, v[k].z, p);
+                        p = fmaf(w.w, v[k].w, p);
+                        p = group_sum<LPR>(p);
+                        const float e = p - r[k];
+                        const float ge = act[k] ? 2.0f * e : 0.0f;
+                        if (act[k]) sse = fmaf(e, e, sse);
+                        acc.x = fmaf(ge, v[k].x, acc.x);
+                        acc.y = fmaf(ge, v[k].y, acc.y);
+                        acc.z = fmaf(ge, v[k].z, acc.z);
+                        acc.w = fmaf(ge, v[k].w, acc.w);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (have) {
+            sgd_update(w, m4, acc, (is_user ? S.mU : S.mV) + row_off, (is_user ? S.U[cur ^ 1] : S.V[cur ^ 1]) + row_off);
+            if (is_user && sub == 0 && sse != 0.f) S.sse[(size_t)epoch * S.n_user + ds.x] += sse;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------- block path and wave path
+    const bool heavy = blk < nbB;
+    const int sidx = heavy ? blk : S.n_block + (blk - nbB) * kWavesPerBlock + wave;
+    if (sidx >= S.n_wave) return;            // whole wave (wave path only)
     const int wpr = heavy ? kWavesPerBlock : 1;
     const int wir = heavy ? wave : 0;
 
-    const int row_id = S.row_sched[sched];
-    const bool is_user = row_id < S.n_user;
-    const int row = is_user ? row_id : row_id - S.n_user;
-    const int32_t *__restrict__ off = is_user ? S.u_off : S.i_off;
-    const int32_t *__restrict__ oid = is_user ? S.u_oid : S.i_oid;
-    const float *__restrict__ rat = is_user ? S.u_r : S.i_r;
-    const uint16_t *__restrict__ tag = is_user ? S.u_b : S.i_b;
+    const int4 ds = sched[sidx];
+    const bool is_user = ds.x < S.n_user;
+    const int row = is_user ? ds.x : ds.x - S.n_user;
     const float *__restrict__ w_cur = is_user ? S.U[cur] : S.V[cur];
     float *__restrict__ w_next = is_user ? S.U[cur ^ 1] : S.V[cur ^ 1];
     float *__restrict__ mom = is_user ? S.mU : S.mV;
     const float *__restrict__ other = is_user ? S.V[cur] : S.U[cur];
 
-    const int sub = lane & (LPR - 1), grp = lane / LPR;
     const size_t row_off = (size_t)row * D + sub * 4;
+    const int beg = ds.y, end = ds.z;
     const float4 w = *reinterpret_cast<const float4 *>(w_cur + row_off);
+    float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!first && lane < LPR && wir == 0) m4 = *reinterpret_cast<const float4 *>(mom + row_off);   // early: hides under the scan
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float sse = 0.f;
-
-    int *qo = q_oid[wave];
-    float *qr = q_r[wave];
     int qh = 0, qt = 0;
 
-    auto round = [&](int head, int tail) {
-        const int idx = head + grp;
-        const bool act = idx < tail;
-        const int slot = idx & (kQueue - 1);
-        const int o = act ? qo[slot] : 0;
-        const float r = qr[slot];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (act) v = *reinterpret_cast<const float4 *>(other + (size_t)o * D + sub * 4);
-        float p = w.x * v.x;
-        p = fmaf(w.y, v.y, p);
-        p = fmaf(w.z, v.z, p);
-        p = fmaf(w.w, v.w, p);
-        p = group_sum<LPR>(p);
-        const float e = p - r;
-        const float ge = act ? 2.0f * e : 0.0f;
-        if (act && sub == 0) sse = fmaf(e, e, sse);
-        acc.x = fmaf(ge, v.x, acc.x);
-        acc.y = fmaf(ge, v.y, acc.y);
-        acc.z = fmaf(ge, v.z, acc.z);
-        acc.w = fmaf(ge, v.w, acc.w);
+    // Up to 4 rounds (4*G queued entries) with all four row gathers in flight together.
+    auto gather4 = [&](int head, int tail) {
+        int o[4];
+        float r[4];
+        bool act[4];
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = head + k * G + grp;
+            act[k] = idx < tail;
+            const int slot = idx & (kQueue - 1);
+            o[k] = act[k] ? qo[slot] : 0;
+            r[k] = qr[slot];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act[k]) v[k] = *reinterpret_cast<const float4 *>(other + (size_t)o[k] * D + sub * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float p = w.x * v[k].x;
+            p = fmaf(w.y, v[k].y, p);
+            p = fmaf(w.z, v[k].z, p);
+            p = fmaf(w.w, v[k].w, p);
+            p = group_sum<LPR>(p);
+            const float e = p - r[k];
+            const float ge = act[k] ? 2.0f * e : 0.0f;
+            if (act[k] && sub == 0) sse = fmaf(e, e, sse);
+            acc.x = fmaf(ge, v[k].x, acc.x);
+            acc.y = fmaf(ge, v[k].y, acc.y);
+            acc.z = fmaf(ge, v[k].z, acc.z);
+            acc.w = fmaf(ge, v[k].w, acc.w);
+        }
     };
 
-    const int beg = off[row], end = off[row + 1];
-    for (int base = beg + wir * kWave; base < end; base += kWave * wpr) {
-        const int p = base + lane;
-        const bool m = p < end && tag[p] == (uint16_t)s;
-        const unsigned long long mask = __ballot(m);
-        if (mask == 0) continue;
-        if (m) {
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-            const int slot = (qt + rank) & (kQueue - 1);
-            qo[slot] = oid[p];
-            qr[slot] = rat[p];
+    // Scan the row's segment 4 chunks (256 slots) at a time: tags, ids and ratings of a
+    // super-chunk are independent loads; matches are appended to the wave's ring in order.
+    for (int base = beg + wir * (kSuper * kWave); base < end; base += kSuper * kWave * wpr) {
+        bool m[kSuper];
+        int o[kSuper];
+        float r[kSuper];
+#pragma unroll
+        for (int c = 0; c < kSuper; ++c) {
+            const int p = base + c * kWave + lane;
+            m[c] = false; o[c] = 0; r[c] = 0.f;
+            if (p < end) {
+                m[c] = ent_tag[p] == (uint16_t)s;
+                o[c] = ent_oid[p];
+                r[c] = ent_r[p];
+            }
         }
-        qt += __popcll(mask);
+#pragma unroll
+        for (int c = 0; c < kSuper; ++c) {
+            const unsigned long long mask = __ballot(m[c]);
+            if (m[c]) {
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                const int slot = (qt + rank) & (kQueue - 1);
+                qo[slot] = o[c];
+                qr[slot] = r[c];
+            }
+            qt += __popcll(mask);
+        }
         __builtin_amdgcn_wave_barrier();
-        while (qt - qh >= G) {
-            round(qh, qt);
-            qh += G;
+        while (qt - qh >= R4) {
+            gather4(qh, qt);
+            qh += R4;
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (qt > qh) round(qh, qt);
+    while (qt > qh) {
+        gather4(qh, qt);
+        qh += R4;
+    }
 
     acc.x = cross_group_sum<LPR>(acc.x);
     acc.y = cross_group_sum<LPR>(acc.y);
@@ -177,25 +370,10 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
         sse = (part_sse[0] + part_sse[1]) + (part_sse[2] + part_sse[3]);
     }
 
-    if (lane < LPR) {
-        // torch.optim.SGD single-tensor path: g = g + lam*w ; buf = mu*buf + g (buf = g on
-        // the first step) ; w = w - lr*buf
-        const float lam = S.lam, mu = S.mu, lr = S.lr[epoch];
-        float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!first) m4 = *reinterpret_cast<const float4 *>(mom + row_off);
-        float4 g, wn;
-        g.x = fmaf(lam, w.x, acc.x); g.y = fmaf(lam, w.y, acc.y);
-        g.z = fmaf(lam, w.z, acc.z); g.w = fmaf(lam, w.w, acc.w);
-        if (!first) {
-            g.x = __fadd_rn(__fmul_rn(mu, m4.x), g.x); g.y = __fadd_rn(__fmul_rn(mu, m4.y), g.y);
-            g.z = __fadd_rn(__fmul_rn(mu, m4.z), g.z); g.w = __fadd_rn(__fmul_rn(mu, m4.w), g.w);
-        }
-        wn.x = fmaf(-lr, g.x, w.x); wn.y = fmaf(-lr, g.y, w.y);
-        wn.z = fmaf(-lr, g.z, w.z); wn.w = fmaf(-lr, g.w, w.w);
-        *reinterpret_cast<float4 *>(mom + row_off) = g;
-        *reinterpret_cast<float4 *>(w_next + row_off) = wn;
-    }
-    if (is_user && lane == 0 && sse != 0.f) atomicAdd(&S.sse[epoch], (double)sse);
+    if (lane < LPR) sgd_update(w, m4, acc, mom + row_off, w_next + row_off);
+    // train loss (utils.py:82): each user row adds its own squared errors to its own slot of
+    // the epoch -- owner-only read-modify-write, so no atomics and a reproducible sum
+    if (is_user && lane == 0 && sse != 0.f) S.sse[(size_t)epoch * S.n_user + row] += sse;
 }
 
 template <int LPR>
@@ -218,17 +396,21 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
     job->host.assign(shards, shards + n_shards);
     for (int k = 0; k < n_shards; ++k) {
         const ure_shard_t &S = shards[k];
+        const int n_rows = S.n_user + S.n_item;
         const bool ok = S.N > 0 && S.n_user > 0 && S.n_item > 0 && S.batch > 0 && S.epochs > 0 && pow2(S.d) && S.d >= 4 &&
-                        S.d <= 256 && S.n_heavy >= 0 && S.n_heavy <= S.n_user + S.n_item && S.u_off && S.u_oid && S.u_r &&
-                        S.u_b && S.u_pos && S.i_off && S.i_oid && S.i_r && S.i_b && S.i_pos && S.row_sched && S.U[0] &&
-                        S.U[1] && S.V[0] && S.V[1] && S.mU && S.mV && S.perm && S.lr && S.sse;
+                        S.d <= 256 && S.n_block >= 0 && S.n_block <= S.n_wave && S.n_wave <= S.n_active &&
+                        S.n_active <= n_rows && S.n_slots >= S.N && S.ent_oid && S.ent_r && S.ent_tag && S.u_pos &&
+                        S.i_pos && S.sched && S.U[0] && S.U[1] && S.V[0] && S.V[1] && S.mU && S.mV && S.perm && S.lr && S.sse;
         if (!ok) { delete job; return fail(-1, "ure_job_create: shard %d has an invalid descriptor", k); }
         if (S.d != shards[0].d) { delete job; return fail(-1, "ure_job_create: all shards of a job share d"); }
         const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
-        if (steps > 65535) { delete job; return fail(-1, "ure_job_create: shard %d needs %lld steps/epoch (> 65535)", k, (long long)steps); }
+        if (steps > 65534) { delete job; return fail(-1, "ure_job_create: shard %d needs %lld steps/epoch (> 65534)", k, (long long)steps); }
         job->ticks = std::max(job->ticks, steps * S.epochs);
-        const int n_rows = S.n_user + S.n_item;
-        job->max_blocks = std::max(job->max_blocks, S.n_heavy + (n_rows - S.n_heavy + kWavesPerBlock - 1) / kWavesPerBlock);
+        const int per_wave = kWave / (S.d / 4);
+        const int per_block = per_wave * kWavesPerBlock;
+        const int blocks = S.n_block + (S.n_wave - S.n_block + kWavesPerBlock - 1) / kWavesPerBlock +
+                           (S.n_active - S.n_wave + per_block - 1) / per_block + (n_rows - S.n_active + per_block - 1) / per_block;
+        job->max_blocks = std::max(job->max_blocks, blocks);
         job->max_n = std::max(job->max_n, S.N);
     }
     job->d = shards[0].d;
@@ -266,7 +448,7 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
                        std::vector<hipEvent_t> *assign_ev)
 {
     const unsigned n_shards = (unsigned)job->host.size();
-    const unsigned assign_blocks = (unsigned)std::min((job->max_n + kBlock - 1) / kBlock, 2048);
+    const unsigned assign_blocks = (unsigned)std::min((job->max_n + kBlock * 4 - 1) / (kBlock * 4), 2048);
     auto mark = [&](std::vector<hipEvent_t> *v) -> int {
         if (!v) return 0;
         hipEvent_t e;

@@ -5,11 +5,12 @@ include/ultrare_hip.h -- only layout building (numpy, once per shard), device me
 (torch tensors) and launches.
 
 HBM layout of one shard:
-  by-user CSR  u_off[n_user+1] i32 | u_oid[N] i32 (item ids) | u_r[N] f32 | u_b[N] u16 | u_pos[N] i32
-  by-item CSR  i_off[n_item+1] i32 | i_oid[N] i32 (user ids) | i_r[N] f32 | i_b[N] u16 | i_pos[N] i32
-  row_sched[n_user+n_item] i32   destination rows, heaviest first (first n_heavy: one workgroup each)
+  slot arrays  ent_oid[n_slots] i32 | ent_r[n_slots] f32 | ent_tag[n_slots] u16 -- one 8-aligned,
+               padded segment per destination row (users and items), in schedule order
+  u_pos[N], i_pos[N] i32   file-order index -> slot in the user's / the item's segment
+  sched[n_user+n_item][4] i32   {row id, first slot, end slot, nnz}, heaviest row first
   U[2][n_user][d] V[2][n_item][d] f32 ping-pong weights ; mU, mV momentum
-  perm[epochs][N] i32 ; lr[epochs] f32 ; sse[epochs] f64
+  perm[epochs][N] i32 ; lr[epochs] f32 ; sse[epochs][n_user] f32 (per-user squared error)
 """
 import ctypes
 import os
@@ -19,7 +20,10 @@ import torch
 
 from . import _native as nv
 
-HEAVY_NNZ = int(os.environ.get('URE_HEAVY_NNZ', '512'))
+# rows with more entries than BLOCK_NNZ get a workgroup, more than GROUP_NNZ a wavefront,
+# the rest one lane group (d/4 lanes) each
+BLOCK_NNZ = int(os.environ.get('URE_BLOCK_NNZ', '1024'))
+GROUP_NNZ = int(os.environ.get('URE_GROUP_NNZ', '128'))
 
 
 def pad_dim(d):
@@ -39,21 +43,24 @@ def _device():
     return torch.device('cuda', torch.cuda.current_device())
 
 
-def _csr(keys, n_rows):
-    """Stable grouping of file-order entries by key -> (offsets, order, inverse)."""
-    order = np.argsort(keys, kind='stable').astype(np.int32)
-    counts = np.bincount(keys, minlength=n_rows)
-    off = np.zeros(n_rows + 1, dtype=np.int32)
-    np.cumsum(counts, out=off[1:])
-    pos = np.empty(len(keys), dtype=np.int32)
-    pos[order] = np.arange(len(keys), dtype=np.int32)
-    return off, order, pos, counts
+def _segment_slots(keys, row_beg):
+    """Slot of every file-order entry inside its row's segment (stable in file order)."""
+    order = np.argsort(keys, kind='stable')
+    counts = np.bincount(keys, minlength=len(row_beg))
+    first = np.zeros(len(row_beg), dtype=np.int64)
+    np.cumsum(counts[:-1], out=first[1:])
+    sk = keys[order]
+    pos = np.empty(len(keys), dtype=np.int64)
+    pos[order] = row_beg[sk] + (np.arange(len(keys), dtype=np.int64) - first[sk])
+    return pos
 
 
 class ShardData:
-    """One shard's interactions laid out for the step kernel (both CSR views)."""
+    """One shard's interactions laid out for the step kernel: every destination row
+    (users, then items) owns an 8-aligned, padded segment of one slot array; segments
+    follow the row schedule (heaviest first)."""
 
-    def __init__(self, uid, iid, rating, n_user, n_item, device=None, heavy_nnz=None):
+    def __init__(self, uid, iid, rating, n_user, n_item, device=None, block_nnz=None, group_nnz=None):
         uid = np.ascontiguousarray(uid, dtype=np.int32)
         iid = np.ascontiguousarray(iid, dtype=np.int32)
         rating = np.ascontiguousarray(rating, dtype=np.float32)
@@ -66,25 +73,39 @@ class ShardData:
             raise ValueError('user or item id outside [0, n_user) x [0, n_item)')
         self.N, self.n_user, self.n_item = n, int(n_user), int(n_item)
         self.device = device or _device()
-        u_off, u_ord, u_pos, u_cnt = _csr(uid, n_user)
-        i_off, i_ord, i_pos, i_cnt = _csr(iid, n_item)
-        nnz = np.concatenate([u_cnt, i_cnt])
-        sched = np.argsort(-nnz, kind='stable').astype(np.int32)
-        thr = HEAVY_NNZ if heavy_nnz is None else heavy_nnz
-        self.n_heavy = int((nnz > thr).sum())
+        nnz = np.concatenate([np.bincount(uid, minlength=n_user), np.bincount(iid, minlength=n_item)]).astype(np.int64)
+        order = np.argsort(-nnz, kind='stable')
+        padded = (nnz + 7) // 8 * 8
+        beg_sched = np.zeros(len(order), dtype=np.int64)
+        np.cumsum(padded[order][:-1], out=beg_sched[1:])
+        row_beg = np.empty_like(beg_sched)
+        row_beg[order] = beg_sched
+        self.n_slots = int(max(padded.sum(), 8))
+        if self.n_slots >= 2 ** 31:
+            raise ValueError('shard too large for 32-bit slot indices')
+        u_pos = _segment_slots(uid.astype(np.int64), row_beg[:n_user])
+        i_pos = _segment_slots(iid.astype(np.int64), row_beg[n_user:])
+        ent_oid = np.zeros(self.n_slots, dtype=np.int32)
+        ent_r = np.zeros(self.n_slots, dtype=np.float32)
+        ent_oid[u_pos], ent_r[u_pos] = iid, rating
+        ent_oid[i_pos], ent_r[i_pos] = uid, rating
+        sched = np.stack([order, row_beg[order], row_beg[order] + padded[order], nnz[order]], axis=1).astype(np.int32)
+        b_thr = BLOCK_NNZ if block_nnz is None else block_nnz
+        g_thr = GROUP_NNZ if group_nnz is None else group_nnz
+        self.n_active = int((nnz > 0).sum())
+        self.n_wave = int((nnz > g_thr).sum())
+        self.n_block = min(int((nnz > max(b_thr, g_thr)).sum()), self.n_wave)
         self.max_row = int(nnz.max())
         dev = self.device
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        self.u_off, self.u_oid, self.u_r, self.u_pos = to(u_off), to(iid[u_ord]), to(rating[u_ord]), to(u_pos)
-        self.i_off, self.i_oid, self.i_r, self.i_pos = to(i_off), to(uid[i_ord]), to(rating[i_ord]), to(i_pos)
-        self.u_b = torch.zeros(n, dtype=torch.int16, device=dev)
-        self.i_b = torch.zeros(n, dtype=torch.int16, device=dev)
-        self.row_sched = to(sched)
+        self.ent_oid, self.ent_r = to(ent_oid), to(ent_r)
+        self.u_pos, self.i_pos = to(u_pos.astype(np.int32)), to(i_pos.astype(np.int32))
+        self.ent_tag = torch.full((self.n_slots,), -1, dtype=torch.int16, device=dev)      # 0xFFFF: matches no batch
+        self.sched = to(sched)
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in
-                   (self.u_off, self.u_oid, self.u_r, self.u_pos, self.u_b, self.i_off, self.i_oid, self.i_r,
-                    self.i_pos, self.i_b, self.row_sched))
+                   (self.ent_oid, self.ent_r, self.ent_tag, self.u_pos, self.i_pos, self.sched))
 
 
 class TrainJob:
@@ -119,12 +140,12 @@ class TrainJob:
             perm = torch.as_tensor(perm)
             assert perm.shape == (self.epochs, sh.N), f'perm of shard {s} must be [epochs, N]'
             perm = perm.to(device=dev, dtype=torch.int32).contiguous()
-            sse = torch.zeros(self.epochs, dtype=torch.float64, device=dev)
+            sse = torch.zeros(self.epochs, sh.n_user, dtype=torch.float32, device=dev)
             self.state.append({'U': U, 'V': V, 'mU': mU, 'mV': mV, 'perm': perm, 'sse': sse})
             D = descs[s]
-            for name in ('u_off', 'u_oid', 'u_r', 'u_b', 'u_pos', 'i_off', 'i_oid', 'i_r', 'i_b', 'i_pos', 'row_sched'):
+            for name in ('ent_oid', 'ent_r', 'ent_tag', 'u_pos', 'i_pos', 'sched'):
                 setattr(D, name, nv.ptr(getattr(sh, name)))
-            D.n_heavy = sh.n_heavy
+            D.n_block, D.n_wave, D.n_active, D.n_slots = sh.n_block, sh.n_wave, sh.n_active, sh.n_slots
             D.U[0], D.U[1] = nv.ptr(U[0]), nv.ptr(U[1])
             D.V[0], D.V[1] = nv.ptr(V[0]), nv.ptr(V[1])
             D.mU, D.mV = nv.ptr(mU), nv.ptr(mV)
@@ -180,7 +201,7 @@ class TrainJob:
 
     def epoch_sse(self, s):
         """Per-epoch sum of squared training errors (host float64 array; synchronises)."""
-        return self.state[s]['sse'].cpu().numpy()
+        return self.state[s]['sse'].double().sum(dim=1).cpu().numpy()
 
     def close(self):
         if self._job:
