@@ -147,14 +147,15 @@ __global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__res
     ndcg[user] = dcg / idcg;
 }
 
-__global__ __launch_bounds__(kBlock) void merge_rows_kernel(float *__restrict__ dst, const float *__restrict__ src,
-                                                            const int64_t *__restrict__ rows, int64_t n_rows, int d4)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void merge_rows_kernel(T *__restrict__ dst, const T *__restrict__ src,
+                                                            const int64_t *__restrict__ rows, int64_t n_rows, int width)
 {
-    const int64_t total = n_rows * d4;
+    const int64_t total = n_rows * width;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
-        const int64_t r = rows[t / d4];
-        const int c = (int)(t % d4);
-        reinterpret_cast<float4 *>(dst)[r * d4 + c] = reinterpret_cast<const float4 *>(src)[r * d4 + c];
+        const int64_t r = rows[t / width];
+        const int c = (int)(t % width);
+        dst[r * width + c] = src[r * width + c];
     }
 }
 
@@ -217,12 +218,18 @@ int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const
 
 int ure_merge_rows(float *dst, const float *src, const int64_t *rows, int64_t n_rows, int d, void *stream)
 {
-    URE_ARG(dst && src && rows && n_rows >= 0 && d >= 4 && d % 4 == 0);
+    URE_ARG(dst && src && rows && n_rows >= 0 && d >= 1);
     if (n_rows == 0) return 0;
-    const int64_t total = n_rows * (d / 4);
+    const bool wide = d % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0;
+    const int width = wide ? d / 4 : d;
+    const int64_t total = n_rows * width;
     const unsigned blocks = (unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 2048);
-    hipLaunchKernelGGL(merge_rows_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), dst, src, rows,
-                       n_rows, d / 4);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (wide)
+        hipLaunchKernelGGL(merge_rows_kernel<float4>, dim3(blocks), dim3(kBlock), 0, st, reinterpret_cast<float4 *>(dst),
+                           reinterpret_cast<const float4 *>(src), rows, n_rows, width);
+    else
+        hipLaunchKernelGGL(merge_rows_kernel<float>, dim3(blocks), dim3(kBlock), 0, st, dst, src, rows, n_rows, width);
     URE_HIP(hipGetLastError());
     return 0;
 }

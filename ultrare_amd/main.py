@@ -1,0 +1,66 @@
+"""Command line of the reference (main.py:5-72) on the MI355X engine.
+
+Same flags, defaults and assertions; additions are optional:
+  --k N          embedding width (the reference hard-codes 16, config.py:19)
+  --parallel 1   train the shards of a SISA call side by side (and across ranks when
+                 launched with torch.distributed.run, one process per GPU)
+  --dataset toy  the small rating set shipped with the reference (data/toy)
+  --data-dir / --save-dir   roots of data/ and result/ (default: ./data, ./result)
+"""
+import argparse
+import os
+
+parser = argparse.ArgumentParser()
+parser.add_argument('--dataset', type=str, default='ml1m', help='dataset name')
+parser.add_argument('--epoch', type=int, default=50, help='number of epochs')
+parser.add_argument('--worker', type=int, default=24, help='number of CPU workers (accepted, unused: no DataLoader workers)')
+parser.add_argument('--verbose', type=int, default=1, help='verbose type')
+parser.add_argument('--group', type=int, default=2, help='number of groups')
+parser.add_argument('--layer', nargs='+', default=[64, 32], help='setting of layers')
+parser.add_argument('--learn', type=str, default='sisa', help='type of learning and unlearning')
+parser.add_argument('--delper', type=int, default=2, help='deleted user proportion')
+parser.add_argument('--deltype', type=str, default='rand', help='deletion type')
+parser.add_argument('--k', type=int, default=16, help='embedding width')
+parser.add_argument('--parallel', type=int, default=0, help='1: shards side by side / across GPUs')
+parser.add_argument('--group-type', type=str, default='emb-ot', help="'emb-ot' (reference) or 'uniform'")
+parser.add_argument('--data-dir', type=str, default=None)
+parser.add_argument('--save-dir', type=str, default=None)
+
+
+def main(argv=None):
+    args = parser.parse_args(argv)
+
+    assert args.dataset in ['ml1m', 'toy']
+    assert args.epoch > 0
+    assert args.worker > 0
+    assert args.verbose in [0, 1, 2]
+    assert args.group >= 0
+    for i in args.layer:
+        assert type(i) == int
+    assert args.learn in ['sisa']
+    assert args.delper in [2, 5]
+    assert args.deltype in ['rand']
+    assert args.group_type in ['emb-ot', 'uniform']
+
+    import torch
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        dist.init_process_group('nccl')
+
+    from .config import InsParam, Instance
+
+    torch.manual_seed(42)   # the reference never seeds the CPU generator; a fixed run needs it
+    param = InsParam(args.dataset, args.epoch, args.worker, args.layer, args.group, args.delper, args.deltype,
+                     k=args.k, parallel=bool(args.parallel), data_dir=args.data_dir)
+    ins = Instance(param, save_dir=args.save_dir)
+
+    if args.group == 0:
+        ins.runFull(is_save=True, verbose=args.verbose)
+    else:
+        ins.runGroup(is_save=True, learn_type=args.learn, group_type=args.group_type, n_group=args.group,
+                     verbose=args.verbose)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,148 @@
+"""Scratch.train with the reference's signature (method/scratch.py:11-148), driving
+the HBM-resident engine: the shard is uploaded once, every epoch is `steps` fused
+kernel launches, and the two per-epoch tests run on the device.
+
+RNG: the reference draws, per Scratch.train call, four normal fills (model init) and
+per epoch three or four int64 seeds from torch's global CPU generator.
+The draws are data independent, so they are all taken up front in the same order;
+the epoch permutations are then expanded from their own generators.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import engine, rng
+from ..read import as_loader
+from .utils import MF, padded_tables, seed_all
+
+PERM_THREADS = int(os.environ.get('URE_PERM_THREADS', str(min(16, os.cpu_count() or 1))))
+
+
+def _is_empty(x):
+    return isinstance(x, (list, tuple)) and len(x) == 0
+
+
+def prepare_shard(train_loader, n_user, n_item, k, epochs, has_total, given_model=''):
+    """Host part of one Scratch.train call: consume the RNG stream exactly like the
+    reference (model init, then per-epoch seeds) and expand the permutations."""
+    loader = as_loader(train_loader)
+    if _is_empty(given_model) or given_model == '':
+        init = MF(n_user, n_item, k)                       # 4 normal fills on the CPU generator
+        U0, V0 = init.user_mat.weight.detach(), init.item_mat.weight.detach()
+    else:
+        U0 = given_model.user_mat.weight.detach().float().cpu()
+        V0 = given_model.item_mat.weight.detach().float().cpu()
+    seeds = rng.epoch_seeds(epochs, has_total)
+    n = len(loader.dataset)
+    if loader.shuffle:
+        perms = rng.epoch_perms(seeds, n, threads=PERM_THREADS)
+    else:
+        perms = torch.arange(n, dtype=torch.int32).repeat(epochs, 1)
+    return loader.shard_data(n_user, n_item), (U0, V0), perms
+
+
+class Scratch(object):
+    def __init__(self, param, model_type):
+        # model param
+        self.n_user = param.n_user
+        self.n_item = param.n_item
+        self.k = param.k
+        self.lam = param.lam
+        self.model_type = model_type
+
+        # training param
+        self.seed = param.seed
+        self.lr = param.lr
+        self.lr_decay = param.lr_decay
+        self.momentum = param.momentum
+        self.epochs = param.epochs
+        self.batch = getattr(param, 'batch', 30000)
+        self.device = 'cuda'
+        # InsParam never sets dis_type / attr; 'nor' is the only branch that
+        # works with MF (utils.py:64-65)
+        self.dis_type = getattr(param, 'dis_type', 'nor')
+        if self.dis_type != 'nor':
+            raise NotImplementedError("only dis_type='nor' exists for the MF model (utils.py:66-81 needs a non-MF model)")
+        self.attr = []
+
+        # log (one dict per object, appended by every shard it trains)
+        self.log = {'train_loss': [],
+                    'test_rmse': [],
+                    'test_ndcg': [],
+                    'test_hr': [],
+                    'total_rmse': [],
+                    'total_ndcg': [],
+                    'total_hr': [],
+                    'time': []}
+
+        if self.model_type != 'mf':
+            raise NotImplementedError("model_type is always 'mf' on the published path (config.py:185-199)")
+        self.loss_fn = nn.MSELoss(reduction='sum')
+        self.is_rmse = True
+
+    def _models_before(self):
+        return list(getattr(self, 'model_list', [])) if self.__class__.__name__ == 'Sisa' else []
+
+    def train(self, train_data, test_data, test_total=[], verbose=1, save_dir='', id=0, given_model=''):
+        print('Using device:', self.device)
+        seed_all(self.seed)                                 # scratch.py:54
+        has_total = not _is_empty(test_total)
+        shard, init, perms = prepare_shard(train_data, self.n_user, self.n_item, self.k, self.epochs, has_total, given_model)
+        batch = as_loader(train_data).batch_size
+        job = engine.TrainJob([shard], [init], [perms], self.k, batch, self.epochs, self.lr, self.lam, self.momentum,
+                              self.lr_decay)
+        test_ev = as_loader(test_data).eval_set()
+        total_ev = as_loader(test_total).eval_set() if has_total else None
+        before = [padded_tables(m)[:2] for m in self._models_before()]
+        n_train = shard.N
+
+        for t in range(self.epochs):
+            if verbose == 2:
+                print(f'Epoch: [{t+1:>3d}/{self.epochs:>3d}] --------------------')
+            epoch_start = time.time()
+            job.run_epochs(1)                               # baseTrain (utils.py:46-111) + scheduler.step()
+            models = before + [job.padded_tables(0)]        # scratch.py:83-86
+            test_rmse, test_ndcg, test_hr = test_ev.evaluate(models, job.d)
+            if has_total:
+                total_rmse, total_ndcg, total_hr = total_ev.evaluate(models, job.d)
+            else:
+                total_rmse, total_ndcg, total_hr = test_rmse, test_ndcg, test_hr
+            train_loss = float(np.sqrt(job.epoch_sse(0)[t] / n_train))
+            train_rmse = train_loss
+            epoch_time = time.strftime('%H:%M:%S', time.gmtime(time.time() - epoch_start))
+            if verbose == 2:
+                print(f'Test - RMSE: {test_rmse:>.4f}, NDCG: {test_ndcg:>.3f}, HR: {test_hr:>.3f}')
+                print('Time:', epoch_time)
+            elif verbose == 1:
+                msg = (f'Epoch: [{t+1:>2d}/{self.epochs:>2d}]' + f' train loss: {train_loss:>.9f},' +
+                       f' train RMSE: {train_rmse:>.4f},' + f' test RMSE: {test_rmse:>.4f},')
+                if has_total:
+                    msg += f' total RMSE: {total_rmse:>.4f},'
+                print(msg + ' time:', epoch_time)
+
+            self.log['train_loss'].append(train_loss)
+            self.log['test_rmse'].append(test_rmse)
+            self.log['test_ndcg'].append(test_ndcg)
+            self.log['test_hr'].append(test_hr)
+            self.log['time'].append(epoch_time)
+            if has_total:
+                self.log['total_rmse'].append(total_rmse)
+                self.log['total_ndcg'].append(total_ndcg)
+                self.log['total_hr'].append(total_hr)
+
+        U, V = job.tables(0)
+        model = MF.from_tables(U.clone().contiguous(), V.clone().contiguous())
+        job.close()
+        self.save(model, save_dir, id)
+        return model
+
+    def save(self, model, save_dir, id):
+        """scratch.py:131-144: model{id}.pth, user_mat{id}.npy, item_mat{id}.npy, log{id}.npy."""
+        if len(save_dir) > 0:
+            torch.save(model.state_dict(), save_dir + '/model' + str(id) + '.pth')
+            np.save(save_dir + '/user_mat' + str(id), model.user_mat.weight.detach().cpu().numpy())
+            np.save(save_dir + '/item_mat' + str(id), model.item_mat.weight.detach().cpu().numpy())
+            np.save(save_dir + '/log' + str(id), self.log)

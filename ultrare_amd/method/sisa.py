@@ -1,0 +1,208 @@
+"""Sisa.learn / unlearn / test with the reference's signatures (method/sisa.py:7-118).
+
+Two execution modes, same final models and log0 (training of a shard is deterministic
+and isolated, and the RNG stream is consumed in the reference's order in both):
+
+  sequential (default)  shard after shard, with the reference's per-epoch group / total
+                        tests that average the models trained so far (scratch.py:83-97).
+  parallel              `param.parallel = True` (CLI --parallel 1): all shards of the
+                        call share every launch (engine.TrainJob) and, when
+                        torch.distributed is initialised, are spread over the ranks
+                        (one process per GPU, no collective while training; trained
+                        tables are exchanged once over RCCL).  Per-epoch logs then hold
+                        the training loss of every epoch and the tests of the final
+                        epoch only -- the in-loop tests depend on the sequential order.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import engine
+from ..read import as_loader
+from .scratch import Scratch, prepare_shard
+from .utils import MF, baseTest, padded_tables, seed_all
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def assign_shards(sizes, world):
+    """Longest-processing-time-first placement of shards on ranks."""
+    load = [0] * world
+    owner = [0] * len(sizes)
+    for s in sorted(range(len(sizes)), key=lambda i: (-sizes[i], i)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[s] = r
+        load[r] += sizes[s]
+    return owner
+
+
+def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_device=True):
+    """Host part of a parallel call.  Every rank replays the WHOLE RNG stream in shard
+    order (the draws are data independent: 4 fills + 4 seeds per epoch per shard,
+    SURVEY.md 3.4) and keeps the init / permutations of its own shards only, so shard
+    i starts from exactly the state it would have in a sequential single-process run."""
+    from .. import rng
+    prepared = {}
+    for pos, i in enumerate(ids):
+        if owner[pos] == rank:
+            if on_device:
+                prepared[i] = prepare_shard(train_dlist[i], n_user, n_item, k, epochs, True)
+            else:   # host-only (tests): same draws, no HBM layout
+                init = MF(n_user, n_item, k)
+                seeds = rng.epoch_seeds(epochs, True)
+                n = len(as_loader(train_dlist[i]).dataset)
+                prepared[i] = (None, (init.user_mat.weight.detach(), init.item_mat.weight.detach()),
+                               rng.epoch_perms(seeds, n))
+        else:
+            rng.mf_init(n_user, n_item, k)
+            rng.epoch_seeds(epochs, True)
+    return prepared
+
+
+def exchange_tables(models, ids, owner, rank, n_user, n_item, k, device, dist):
+    """After isolated training every rank receives every shard's (U, V) from its
+    owner: one broadcast per table over RCCL/xGMI (payloads of a few MB, latency
+    bound).  This is the path's only communication (sisa.py:52-58 needs all U_i,
+    utils.py:140-145 all V_i)."""
+    out = {}
+    for pos, i in enumerate(ids):
+        if owner[pos] == rank:
+            U, V = models[i]
+        else:
+            U = torch.empty(n_user, k, dtype=torch.float32, device=device)
+            V = torch.empty(n_item, k, dtype=torch.float32, device=device)
+        dist.broadcast(U, src=owner[pos])
+        dist.broadcast(V, src=owner[pos])
+        out[i] = (U, V)
+    return out
+
+
+class Sisa(Scratch):
+    def __init__(self, param={}, model_type='mf', n_group=5, group_index=[]):
+        super(Sisa, self).__init__(param, model_type)
+        self.n_group = n_group
+        self.group_index = group_index
+        self.parallel = bool(getattr(param, 'parallel', False))
+        self.model_list = []
+
+    def test(self, test_data, verbose, save_dir):
+        rmse, ndcg, hr = baseTest(test_data, self.model_list, nn.MSELoss(reduction='sum'), self.device, verbose)
+        log = {'total_rmse': rmse,
+               'total_ndcg': ndcg,
+               'total_hr': hr}
+        if len(save_dir) > 0:
+            np.save(save_dir + '/log0', log)
+        self.log0 = log
+
+    # ------------------------------------------------------------------ helpers
+    def _rows(self, i):
+        return torch.as_tensor(np.asarray(self.group_index[i], dtype=np.int64))
+
+    def _merge(self, merged, ids):
+        """sisa.py:52-58 / 107-113: merged[group_index[i]] = U_i[group_index[i]]."""
+        for i in ids:
+            src = self.model_list[i].user_mat.weight.detach().contiguous()
+            engine.merge_rows(merged, src, self.group_index[i])
+        for m in self.model_list:
+            m.user_mat.weight = nn.Parameter(merged, requires_grad=False)
+
+    def _train_parallel(self, ids, train_dlist, test_dlist, test_data, verbose, save_dir):
+        """Train the shards `ids` side by side (and across ranks)."""
+        seed_all(self.seed)
+        dist = _dist()
+        world = dist.get_world_size() if dist else 1
+        rank = dist.get_rank() if dist else 0
+        sizes = [len(as_loader(train_dlist[i]).dataset) for i in ids]
+        owner = assign_shards(sizes, world)
+        prepared = prepare_owned(ids, owner, rank, train_dlist, self.n_user, self.n_item, self.k, self.epochs)
+        mine = [i for pos, i in enumerate(ids) if owner[pos] == rank]
+        models = {}
+        if mine:
+            batch = as_loader(train_dlist[mine[0]]).batch_size
+            job = engine.TrainJob([prepared[i][0] for i in mine], [prepared[i][1] for i in mine],
+                                  [prepared[i][2] for i in mine], self.k, batch, self.epochs, self.lr, self.lam,
+                                  self.momentum, self.lr_decay)
+            job.run()
+            for pos, i in enumerate(mine):
+                U, V = job.tables(pos)
+                models[i] = (U.clone().contiguous(), V.clone().contiguous())
+                n = prepared[i][0].N
+                self.log['train_loss'] += [float(x) for x in np.sqrt(job.epoch_sse(pos) / n)]
+            job.close()
+        if dist:   # the only exchange of the path: every rank ends up with every shard's tables
+            models = exchange_tables(models, ids, owner, rank, self.n_user, self.n_item, self.k, engine._device(), dist)
+        out = {}
+        for i in ids:
+            out[i] = MF.from_tables(*models[i])
+            if rank == 0:
+                self.save(out[i], save_dir, i + 1)
+        return out
+
+    # ------------------------------------------------------------------ learn
+    def learn(self, train_dlist, test_dlist, test_data, verbose, save_dir):
+        '''
+        train_dlist:   list of dataloader[n_group]
+        '''
+        assert len(train_dlist) == self.n_group
+        assert len(test_dlist) == self.n_group
+
+        if self.parallel:
+            trained = self._train_parallel(list(range(self.n_group)), train_dlist, test_dlist, test_data, verbose, save_dir)
+            self.model_list = [trained[i] for i in range(self.n_group)]
+        else:
+            for i in range(self.n_group):
+                given_model = ''
+                model = super(Sisa, self).train(train_dlist[i], test_dlist[i], test_data, verbose, save_dir, i + 1, given_model)
+                self.model_list.append(model)
+
+        # merge user mat (sisa.py:52-58)
+        merged = torch.zeros_like(self.model_list[0].user_mat.weight.detach()).contiguous()
+        self._merge(merged, range(self.n_group))
+
+        # total test
+        self.test(test_data, verbose, save_dir)
+        return self.model_list
+
+    # ------------------------------------------------------------------ unlearn
+    def unlearn(self, model_list, train_dlist, test_dlist, test_data, del_user, verbose, save_dir):
+        '''
+        train_dlist:   list of dataloader[n_group]
+        '''
+        self.model_list = model_list
+
+        assert len(train_dlist) == self.n_group
+        assert len(test_dlist) == self.n_group
+
+        # find deletion (sisa.py:76-81)
+        member = [set(int(u) for u in g) for g in self.group_index]
+        retrain_gid = set()
+        for user in del_user:
+            for i in range(self.n_group):
+                if int(user) in member[i]:
+                    retrain_gid.add(i)
+                    break
+
+        model_before_unlearn = model_list[0]
+        merged = model_before_unlearn.user_mat.weight.detach().clone().contiguous()
+
+        if self.parallel:
+            ids = list(retrain_gid)
+            trained = self._train_parallel(ids, train_dlist, test_dlist, test_data, verbose, save_dir) if ids else {}
+            for i in ids:
+                self.model_list[i] = trained[i]
+        else:
+            for i in retrain_gid:
+                given_model = ''
+                model = super(Sisa, self).train(train_dlist[i], test_dlist[i], test_data, verbose, save_dir, i + 1, given_model)
+                self.model_list[i] = model
+
+        # merge user mat (sisa.py:107-113): only the retrained shards' rows change
+        self._merge(merged, list(retrain_gid))
+
+        # total test
+        self.test(test_data, verbose, save_dir)
+        self.retrained = sorted(retrain_gid)
+        return self.model_list
