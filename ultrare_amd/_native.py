@@ -68,6 +68,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise NativeError(f'{LIB_PATH} is missing: run `python -m ultrare_amd.build` '
                               '(there is no CPU fallback for the SISA hot path)')
+        # torch first: it bundles its own libamdhip64 / libhsa-runtime64, and the process must
+        # end up with ONE HIP runtime -- the one that owns the device pointers torch hands us.
+        # Loading this library first would pull /opt/rocm's copy and split the process in two.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOTYPES.items():
             fn = getattr(L, name)
