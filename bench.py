@@ -138,8 +138,20 @@ def main():
     alg_bytes = float((per_tick * b_sparse + active * 20 * P).sum()) / max(n_step, 1)   # per launch
     avg_ms = step_ms / max(n_step, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    # HBM-side bytes per launch come from rocprofv3 PMC passes of this same command (they cannot
+    # be collected from inside the process); the committed summary is quoted with its source
+    traffic, traffic_src = None, None
+    import glob
+    pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', '*pmc_hbm_traffic.json')))
+    if pmc and a.d == 32 and a.shards == 5 and a.batch == 30000:
+        try:
+            with open(pmc[-1]) as f:
+                k = [v for n, v in json.load(f)['kernels'].items() if 'mf_step_kernel' in n][0]
+            traffic, traffic_src = k['traffic_bytes_per_launch'], os.path.relpath(pmc[-1], ROOT)
+        except Exception:
+            pass
     roofline = {'bound': 'hbm', 'kernel': 'mf_step_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                 'alg_bytes_per_launch': round(alg_bytes), 'avg_launch_us': round(avg_ms * 1e3, 2),
                 'launches_timed': n_step, 'assign_avg_us': round(assign_ms / max(n_assign, 1) * 1e3, 2)}
 

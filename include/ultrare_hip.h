@@ -107,6 +107,11 @@ int ure_job_train(ure_job_t *job, int64_t tick0, int64_t tick1, void *stream);
 int ure_job_train_profiled(ure_job_t *job, int64_t tick0, int64_t tick1, void *stream, double *step_ms,
                            int64_t *n_step, double *assign_ms, int64_t *n_assign);
 
+/* read.py:133 / torch RandomSampler: out[t] = torch.randperm(n, generator seeded with
+ * seeds[t]) for t < n_perms, as int32, computed on `n_threads` host threads (0 = all).
+ * HOST memory; bit-identical to torch's CPU randperm for n < 2^32/20. */
+int ure_host_randperm(const int64_t *seeds, int n_perms, int64_t n, int32_t *out, int n_threads);
+
 /* ---------------------------------------------------------------------------
  * Evaluation (baseTest, utils.py:115-187)
  * ------------------------------------------------------------------------- */

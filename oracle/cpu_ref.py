@@ -232,7 +232,7 @@ def eval_metrics(data, models, batch, top_k=10):
 # ----------------------------------------------------------------------------
 # drivers
 # ----------------------------------------------------------------------------
-def scratch_train(h, n_user, n_item, train, test, test_total=None, prev_models=(), on_epoch=None):
+def scratch_train(h, n_user, n_item, train, test, test_total=None, prev_models=(), on_epoch=None, with_eval=True):
     """scratch.py:51-148.  Consumes the global torch CPU stream exactly as SURVEY 3.4
     lists.  Returns (U, V, log)."""
     U0, V0 = mf_init(n_user, n_item, h.k)
@@ -245,12 +245,13 @@ def scratch_train(h, n_user, n_item, train, test, test_total=None, prev_models=(
         tl, _ = train_epoch(st, train, perm, h.batch, lr, h.lam, h.momentum)
         models = list(prev_models) + [(st.U, st.V)]
         draw_seed()                                                  # 5c group-test loader base seed
-        g = eval_metrics(test, models, h.batch)
+        nan = (float('nan'),) * 3                                    # with_eval=False: draws only (tests at scale)
+        g = eval_metrics(test, models, h.batch) if with_eval else nan
         if test_total is None:
             tot = g
         else:
             draw_seed()                                              # 5d total-test loader base seed
-            tot = eval_metrics(test_total, models, h.batch)
+            tot = eval_metrics(test_total, models, h.batch) if with_eval else nan
         log['train_loss'].append(tl)
         for name, val in zip(('test_rmse', 'test_ndcg', 'test_hr'), g):
             log[name].append(val)
@@ -262,11 +263,12 @@ def scratch_train(h, n_user, n_item, train, test, test_total=None, prev_models=(
     return st.U, st.V, log
 
 
-def sisa_learn(h, n_user, n_item, group_index, train_list, test_list, test_total):
+def sisa_learn(h, n_user, n_item, group_index, train_list, test_list, test_total, with_eval=True):
     """sisa.py:25-63."""
     models, logs = [], []
     for i in range(len(group_index)):
-        U, V, log = scratch_train(h, n_user, n_item, train_list[i], test_list[i], test_total, prev_models=models)
+        U, V, log = scratch_train(h, n_user, n_item, train_list[i], test_list[i], test_total, prev_models=models,
+                                  with_eval=with_eval)
         models.append((U, V))
         logs.append(log)
     pre = [m[0].copy() for m in models]
@@ -279,7 +281,7 @@ def sisa_learn(h, n_user, n_item, group_index, train_list, test_list, test_total
     return {'models': models, 'U_pre': pre, 'merged': merged, 'log0': log0, 'logs': logs}
 
 
-def sisa_unlearn(h, n_user, n_item, group_index, models, train_list, test_list, test_total, del_user):
+def sisa_unlearn(h, n_user, n_item, group_index, models, train_list, test_list, test_total, del_user, with_eval=True):
     """sisa.py:66-118.  `models` = list of (merged U, V_i) from sisa_learn."""
     retrain = set()
     for u in del_user:
@@ -291,7 +293,8 @@ def sisa_unlearn(h, n_user, n_item, group_index, models, train_list, test_list, 
     before = models[0][0]
     logs = {}
     for i in retrain:                                                # python set iteration order
-        U, V, log = scratch_train(h, n_user, n_item, train_list[i], test_list[i], test_total, prev_models=models)
+        U, V, log = scratch_train(h, n_user, n_item, train_list[i], test_list[i], test_total, prev_models=models,
+                                  with_eval=with_eval)
         models[i] = (U, V)
         logs[i] = log
     merged = before.copy()

@@ -142,6 +142,17 @@ def test_product_rng_stream_equals_reference_stream():
     assert torch.equal(m.user_mat.weight.detach(), U0) and torch.equal(m.item_mat.weight.detach(), V0)
 
 
+@pytest.mark.parametrize('n', [0, 1, 2, 17, 3000, 28360])
+def test_host_randperm_equals_torch(n):
+    """ure_host_randperm (threaded C++) == torch.randperm, seed for seed (read.py:133)."""
+    from ultrare_amd import rng
+    seeds = [0, 1, 42, 2 ** 31, 2 ** 40 + 12345, 2 ** 63 - 1, 6364136223846793005]
+    got = rng.epoch_perms(seeds, n, threads=3)
+    assert got.dtype == torch.int32 and got.shape == (len(seeds), n)
+    for s, row in zip(seeds, got):
+        assert torch.equal(row, rng.epoch_perm(s, n))
+
+
 def test_shard_layout_invariants():
     """The slot array the kernels walk: every interaction appears once in its user's
     segment and once in its item's, segments are 8-aligned, padded slots never match."""

@@ -1,0 +1,155 @@
+"""GPU parity at BASELINE.json's sizes (the configs other than the bench workload are
+parity cases): the HIP path against the CPU oracle on the same seeded inputs where the
+oracle finishes in seconds, plus size-independent properties of the SISA path."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+@pytest.fixture(scope='module')
+def ml1m():
+    from ultrare_amd import synth
+    return synth.make_dataset(**synth.ML1M)
+
+
+def _job(parts, n_user, n_item, k, batch, epochs, seed=42):
+    from ultrare_amd import engine, rng
+    torch.manual_seed(seed)
+    inits, perms = [], []
+    for p in parts:
+        inits.append(rng.mf_init(n_user, n_item, k))
+        perms.append(rng.epoch_perms(rng.epoch_seeds(epochs, True), len(p[0])))
+    shards = [engine.ShardData(*p, n_user, n_item) for p in parts]
+    job = engine.TrainJob(shards, inits, perms, k, batch, epochs, 1e-3, 0.1, 0.9, 0.95)
+    job.run()
+    torch.cuda.synchronize()
+    return job, inits, perms
+
+
+def _oracle(part, init, perms, batch, epochs):
+    st = O.MFState(init[0].numpy().copy(), init[1].numpy().copy())
+    losses = [O.train_epoch(st, part, perms[t].numpy(), batch, 1e-3, 0.1, 0.9)[0] for t in range(epochs)]
+    return st, losses
+
+
+@pytest.mark.parametrize('S,k', [(5, 32), (8, 64)])
+def test_ml1m_sisa_shards_vs_oracle(ml1m, S, k):
+    """configs[1] (5 shards, d=32) and configs[2] (8 shards, d=64) at full ml-1m size:
+    all shards side by side, 2 epochs, every shard against the C oracle; then the
+    mean-ensemble metrics on the full test set against the oracle's baseTest."""
+    from ultrare_amd import engine, synth
+    n_user, n_item, B, E = ml1m['n_user'], ml1m['n_item'], 30000, 2
+    shard_of, groups = synth.uniform_shards(n_user, S)
+    parts = synth.split_shards(ml1m['train'], shard_of, S)
+    tests = synth.split_shards(ml1m['test'], shard_of, S)
+    assert sum(len(p[0]) for p in parts) == 896914
+    job, inits, perms = _job(parts, n_user, n_item, k, B, E)
+    models = []
+    for s in range(S):
+        st, losses = _oracle(parts[s], inits[s], perms[s], B, E)
+        U, V = job.tables(s)
+        assert rel(U, st.U) < 1e-5 and rel(V, st.V) < 1e-5, s
+        np.testing.assert_allclose(np.sqrt(job.epoch_sse(s) / len(parts[s][0])), losses, rtol=1e-5)
+        models.append((st.U, st.V))
+    # merge (sisa.py:52-58) on the device vs numpy, then baseTest on all 102,697 test rows
+    merged = torch.zeros(n_user, k, device='cuda')
+    want = np.zeros((n_user, k), dtype=np.float32)
+    for s, g in enumerate(groups):
+        engine.merge_rows(merged, job.tables(s)[0].contiguous(), g)
+        want[np.asarray(g)] = models[s][0][np.asarray(g)]
+    assert rel(merged, want) < 1e-5
+    total = O.hstack(tests)
+    ev = engine.EvalSet(*total)
+    got = ev.evaluate([(merged, job.padded_tables(s)[1]) for s in range(S)], job.d)
+    np.testing.assert_allclose(got, O.eval_metrics(total, [(want, m[1]) for m in models], B), rtol=1e-4)
+
+
+def test_ml25m_scale_shard_vs_oracle():
+    """configs[3] shape: one of the 32 shards of the synthetic 162k x 60k x 25M set at d=128
+    (5,063 users, ~781k ratings, 27 steps/epoch, 113.7 MB of tables): one epoch against the
+    oracle, including the 157k user rows the shard never touches (they only decay)."""
+    from ultrare_amd import synth
+    n_user, n_item, k, B = 162000, 60000, 128, 30000
+    d = synth.make_dataset(5063, n_item, 781250, 86800, seed=11)
+    ids = np.sort(np.random.RandomState(5).choice(n_user, 5063, replace=False))
+    u, i, r = d['train']
+    part = (ids[u].astype(np.int32), i.astype(np.int32), (r / 5).astype(np.float32))
+    job, inits, perms = _job([part], n_user, n_item, k, B, 1)
+    st, losses = _oracle(part, inits[0], perms[0], B, 1)
+    U, V = job.tables(0)
+    assert rel(U, st.U) < 1e-5 and rel(V, st.V) < 1e-5
+    np.testing.assert_allclose(np.sqrt(job.epoch_sse(0) / len(part[0])), losses, rtol=1e-5)
+    untouched = np.setdiff1d(np.arange(n_user), ids)[:1000]
+    assert np.array_equal(U[untouched].cpu().numpy() != inits[0][0].numpy()[untouched], np.ones((1000, k), bool))
+
+
+def test_unlearn_16_shards_properties(ml1m, tmp_path):
+    """configs[4]: ml-1m, 16 shards, 2 % random user deletion (config.py:46-49 with D1):
+    Sisa.unlearn retrains exactly the shards that hold a deleted user, leaves the other
+    shards' tables bit-identical, patches only the retrained shards' rows of the merged
+    user matrix, and the retrained tables equal the oracle's on the same stream."""
+    import copy
+    from ultrare_amd import synth
+    from ultrare_amd.method.sisa import Sisa
+    from ultrare_amd.read import RatingData, loadData
+
+    class P:
+        k, lam, seed, batch, lr, lr_decay, momentum, epochs = 16, 0.1, 42, 30000, 0.001, 0.95, 0.9, 1
+        n_user, n_item, parallel = ml1m['n_user'], ml1m['n_item'], True
+
+    S = 16
+    shard_of, groups = synth.uniform_shards(P.n_user, S)
+    np.random.seed(0)
+    del_user = np.random.choice(P.n_user, int(2 / 100 * P.n_user), replace=False)
+    # the reference's uniform grouping and its deletion set share seed(0): spread
+    # the deletion over shards the way OT groups would by using a second independent draw
+    del_user = np.random.RandomState(1).choice(P.n_user, 120, replace=False)
+
+    def loaders(triple, shuffle):
+        return [loadData(RatingData(np.vstack([p[0], p[1], p[2]])), P.batch, 24, shuffle)
+                for p in synth.split_shards(triple, shard_of, S)]
+
+    keep = ~np.isin(ml1m['train'][0], del_user)
+    train_del = tuple(a[keep] for a in ml1m['train'])
+    trd, trd_del, ted = loaders(ml1m['train'], True), loaders(train_del, True), loaders(ml1m['test'], False)
+    tot = loadData(RatingData(np.vstack(O.hstack(synth.split_shards(ml1m['test'], shard_of, S)))), P.batch, 24, False)
+    sisa = Sisa(P, 'mf', S, groups)
+    torch.manual_seed(42)
+    ml = sisa.learn(trd, ted, tot, 0, '')
+    before_V = [m.item_mat.weight.detach().clone() for m in ml]
+    before_U = ml[0].user_mat.weight.detach().clone()
+    s2 = Sisa(P, 'mf', S, groups)
+    torch.manual_seed(42)
+    ml2 = s2.unlearn([copy.deepcopy(m) for m in ml], trd_del, ted, tot, del_user.tolist(), 0, '')
+    affected = sorted({int(shard_of[u]) for u in del_user})
+    assert s2.retrained == affected and 0 < len(affected) <= S
+    after_U = ml2[0].user_mat.weight.detach()
+    for s in range(S):
+        rows = torch.as_tensor(np.asarray(groups[s]), device='cuda')
+        if s in affected:
+            assert not torch.equal(ml2[s].item_mat.weight.detach(), before_V[s])
+            assert not torch.equal(after_U[rows], before_U[rows])
+        else:
+            assert torch.equal(ml2[s].item_mat.weight.detach(), before_V[s])
+            assert torch.equal(after_U[rows], before_U[rows])
+    # oracle on the same stream (retrained shards in set order), evaluation skipped
+    h = O.Hyper(k=16, batch=P.batch, epochs=1)
+    parts_del = synth.split_shards(train_del, shard_of, S)
+    tests = synth.split_shards(ml1m['test'], shard_of, S)
+    torch.manual_seed(42)
+    models = [(before_U.cpu().numpy(), v.cpu().numpy()) for v in before_V]
+    ref = O.sisa_unlearn(h, P.n_user, P.n_item, groups, models, parts_del, tests, O.hstack(tests), del_user.tolist(),
+                         with_eval=False)
+    assert ref['retrained'] == affected
+    assert rel(after_U, ref['merged']) < 1e-5
+    for s in affected:
+        assert rel(ml2[s].item_mat.weight, ref['models'][s][1]) < 1e-5

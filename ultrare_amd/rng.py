@@ -10,8 +10,6 @@ be taken up front and the permutations expanded later (or on other threads).
   torch DataLoader        _base_seed per iterator                      -> draw_seed
   torch RandomSampler     seed -> Generator -> randperm(N)             -> epoch_perm
 """
-from concurrent.futures import ThreadPoolExecutor
-
 import numpy as np
 import torch
 
@@ -51,19 +49,20 @@ def epoch_perm(seed, n):
 
 
 def epoch_perms(seeds, n, threads=0):
-    """[len(seeds), n] int32 permutations; each has its own generator, so they are
-    independent and can be expanded concurrently (torch releases the GIL)."""
+    """[len(seeds), n] int32 permutations, perms[t] == torch.randperm(n, generator seeded with
+    seeds[t]).  Each epoch has its own generator, so the epochs are expanded concurrently by
+    the library's host threads (ure_host_randperm, a restatement of ATen's MT19937
+    Fisher-Yates loop checked against torch.randperm in tests/test_cpu_host.py)."""
+    from . import _native as nv
     out = torch.empty(len(seeds), n, dtype=torch.int32)
-
-    def fill(t):
-        out[t] = epoch_perm(seeds[t], n)
-
-    if threads and threads > 1 and len(seeds) > 1:
-        with ThreadPoolExecutor(threads) as ex:
-            list(ex.map(fill, range(len(seeds))))
-    else:
-        for t in range(len(seeds)):
-            fill(t)
+    if len(seeds) == 0 or n == 0:
+        return out
+    if n >= (2 ** 32 - 1) // 20:          # ATen switches algorithm for huge n: use torch itself
+        for t, s in enumerate(seeds):
+            out[t] = epoch_perm(s, n)
+        return out
+    sd = np.asarray(seeds, dtype=np.uint64).astype(np.int64)
+    nv.check(nv.lib().ure_host_randperm(sd.ctypes.data, len(sd), n, out.data_ptr(), int(threads or 0)), 'ure_host_randperm')
     return out
 
 
