@@ -43,9 +43,9 @@ int ure_device_info(int dev, int *n_cu, int *wave_size, char *arch, int arch_len
  * (built once by the host, stable in file order), so that whoever owns a
  * destination row can sum that row's gradient in registers and apply the
  * optimizer to it immediately -- no atomics, no gradient tables.
- * `*_pos` map an interaction's file-order index to its two slots; `ent_tag`
- * receives, once per epoch, the batch number every interaction falls in under that
- * epoch's permutation (read.py:133: batch s = perm[s*B : (s+1)*B]).
+ * `ent_src` maps a slot back to its interaction's file-order index; once per epoch the
+ * engine inverts the epoch's permutation into `file_tag` (read.py:133: batch s =
+ * perm[s*B : (s+1)*B]) and gathers the slot-ordered `ent_tag` from it.
  * ------------------------------------------------------------------------- */
 typedef struct ure_shard {
     /* Interactions.  Every destination row (user u -> row id u, item i -> row id
@@ -54,10 +54,15 @@ typedef struct ure_shard {
      * slots and padded to a multiple of 8 with slots that never match a batch.      */
     const int32_t *ent_oid;  /* [n_slots] opposite id: item id in a user row, user id in an item row */
     const float   *ent_r;    /* [n_slots] rating / max_rating (read.py:66)                */
-    uint16_t      *ent_tag;  /* [n_slots] batch number this epoch (written by the engine;
-                              * the caller initialises every slot to 0xFFFF)              */
-    const int32_t *u_pos;    /* [N] file-order index -> its slot in the user's segment    */
-    const int32_t *i_pos;    /* [N] file-order index -> its slot in the item's segment    */
+    uint16_t      *ent_tag;  /* [2][n_slots] batch number of the slot, double-buffered by epoch
+                              * parity (written by the engine one epoch ahead; the caller
+                              * initialises both halves to 0xFFFF)                         */
+    const int32_t *ent_src;  /* [n_slots] file-order index of the slot's interaction; -1 in
+                              * padding slots                                             */
+    uint16_t      *file_tag; /* [N] scratch: batch number of interaction j = inverse of the
+                              * permutation of the epoch being prepared                    */
+    uint32_t      *inv_stage;/* [N] scratch of the inverse's radix partition               */
+    int32_t       *inv_off;  /* [R][R+1] scratch, R = ceil(N / 2048) (unused when R > 1024) */
     /* Row schedule, heaviest first: {row id, first slot, end slot (padded), nnz}.
      * [0, n_block) one workgroup per row | [n_block, n_wave) one wavefront per row |
      * [n_wave, n_active) one lane group (d/4 lanes) per row | [n_active, rows) rows with

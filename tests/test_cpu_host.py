@@ -168,7 +168,9 @@ def test_shard_layout_invariants():
     assert sh.n_block == (sched[:, 3] > 200).sum() and sh.n_wave == (sched[:, 3] > 40).sum()
     assert sh.n_active == (sched[:, 3] > 0).sum() and sched[-1, 2] == sh.n_slots
     oid, r = sh.ent_oid.numpy(), sh.ent_r.numpy()
-    up, ip = sh.u_pos.numpy(), sh.i_pos.numpy()
+    up, ip = sh.u_pos, sh.i_pos
+    src = sh.ent_src.numpy()
+    assert np.array_equal(src[up], np.arange(n)) and np.array_equal(src[ip], np.arange(n)) and (src < 0).sum() == sh.n_slots - 2 * n
     assert len(set(up.tolist()) | set(ip.tolist())) == 2 * n                   # all slots distinct
     assert np.array_equal(oid[up], tr[1]) and np.array_equal(oid[ip], tr[0])
     assert np.array_equal(r[up], tr[2]) and np.array_equal(r[ip], tr[2])

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""End-to-end wall time of the SISA path on synthetic ml-1m: Sisa.learn then Sisa.unlearn
+after a 2 % random user deletion (BASELINE.json metric, second half), through the
+reference's operator surface.  Prints one JSON object.
+
+    python tools/e2e_sisa.py [--shards 5] [--k 32] [--epochs 50] [--parallel 1]
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--shards', type=int, default=5)
+    ap.add_argument('--k', type=int, default=32)
+    ap.add_argument('--epochs', type=int, default=50)
+    ap.add_argument('--parallel', type=int, default=1)
+    ap.add_argument('--delper', type=float, default=2.0)
+    a = ap.parse_args()
+    from ultrare_amd import synth
+    from ultrare_amd.method.sisa import Sisa
+    from ultrare_amd.read import RatingData, loadData
+
+    data = synth.make_dataset(**synth.ML1M)
+    n_user, n_item = data['n_user'], data['n_item']
+    shard_of, groups = synth.uniform_shards(n_user, a.shards)
+    del_user = np.random.RandomState(1).choice(n_user, int(a.delper / 100 * n_user), replace=False)
+
+    class P:
+        k, lam, seed, batch, lr, lr_decay, momentum, epochs = a.k, 0.1, 42, 30000, 0.001, 0.95, 0.9, a.epochs
+        parallel = bool(a.parallel)
+    P.n_user, P.n_item = n_user, n_item
+
+    def loaders(triple, shuffle):
+        return [loadData(RatingData(np.vstack(p)), P.batch, 24, shuffle) for p in synth.split_shards(triple, shard_of, a.shards)]
+
+    keep = ~np.isin(data['train'][0], del_user)
+    trd, ted = loaders(data['train'], True), loaders(data['test'], False)
+    trd_del = loaders(tuple(x[keep] for x in data['train']), True)
+    tot_arr = [np.concatenate([p[c] for p in synth.split_shards(data['test'], shard_of, a.shards)]) for c in range(3)]
+    tot = loadData(RatingData(np.vstack(tot_arr)), P.batch, 24, False)
+    torch.cuda.synchronize()
+
+    out = {'shards': a.shards, 'k': a.k, 'epochs': a.epochs, 'parallel': bool(a.parallel),
+           'train_rows': int(len(data['train'][0])), 'deleted_users': int(len(del_user))}
+    for rep in range(2):          # rep 0 warms allocator / caches / layout caches
+        sisa = Sisa(P, 'mf', a.shards, groups)
+        torch.manual_seed(42)
+        t0 = time.perf_counter()
+        ml = sisa.learn(trd, ted, tot, 0, '')
+        torch.cuda.synchronize()
+        t_learn = time.perf_counter() - t0
+        s2 = Sisa(P, 'mf', a.shards, groups)
+        snap = [copy.deepcopy(m) for m in ml]
+        torch.manual_seed(42)
+        t0 = time.perf_counter()
+        s2.unlearn(snap, trd_del, ted, tot, del_user.tolist(), 0, '')
+        torch.cuda.synchronize()
+        t_unlearn = time.perf_counter() - t0
+    n_learn = len(data['train'][0]) * a.epochs
+    n_un = int(keep.sum()) * a.epochs if len(s2.retrained) == a.shards else None
+    out.update(learn_s=round(t_learn, 4), unlearn_s=round(t_unlearn, 4), retrained_shards=len(s2.retrained),
+               learn_interactions_per_s=round(n_learn / t_learn, 1), log0=sisa.log0, unlearn_log0=s2.log0,
+               unlearn_interactions=n_un)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

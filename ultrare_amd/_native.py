@@ -22,7 +22,7 @@ _i64 = ctypes.c_int64
 class UreShard(ctypes.Structure):
     """struct ure_shard (include/ultrare_hip.h)."""
     _fields_ = [
-        ('ent_oid', _vp), ('ent_r', _vp), ('ent_tag', _vp), ('u_pos', _vp), ('i_pos', _vp),
+        ('ent_oid', _vp), ('ent_r', _vp), ('ent_tag', _vp), ('ent_src', _vp), ('file_tag', _vp), ('inv_stage', _vp), ('inv_off', _vp),
         ('sched', _vp), ('n_block', _i32), ('n_wave', _i32), ('n_active', _i32), ('n_slots', _i64),
         ('U', _vp * 2), ('V', _vp * 2), ('mU', _vp), ('mV', _vp),
         ('perm', _vp), ('lr', _vp), ('sse', _vp),

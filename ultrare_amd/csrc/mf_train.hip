@@ -25,14 +25,15 @@
 //     independent loads (tags, ids, ratings; four row gathers) together.
 //   * Row segments live in one slot array in schedule order, 8-aligned and padded, so
 //     a lane scans 8 slots with one 16-byte load per array.
-//   * Batch membership is a 2-byte tag per slot, refreshed once per epoch by
-//     assign_batches_kernel from the epoch's permutation.
+//   * Batch membership is a 2-byte tag per slot, double-buffered by epoch parity; the
+//     first three steps of an epoch carry the preparation of the next epoch's tags as
+//     extra workgroups (tag_prep.h).
 //   * Shards are independent (sisa.py:33-36), so a job's shards share each launch
 //     (blockIdx.y = shard): one tick advances every shard by one optimizer step.
 //
 // Algorithmic bytes per interaction and step: 16 + 16 d sparse,
 // 20 P dense; this kernel moves 16 P dense (no gradient read) + the tag scan.
-#include "ure_internal.h"
+#include "tag_prep.h"
 
 #include <algorithm>
 #include <vector>
@@ -44,47 +45,7 @@ constexpr int kQueue = 512;     // per-wave match queue: ring of 512 on the wave
                                 // 64/LPR private queues of 8*LPR on the group path
 constexpr int kSegPerLane = 8;  // slots one lane scans per segment on the group path
 
-struct ure_job {
-    std::vector<ure_shard_t> host;
-    ure_shard_t *dev = nullptr;
-    int64_t ticks = 0;
-    int max_blocks = 0;
-    int max_n = 0;
-    int d = 0;
-};
-
 __device__ __forceinline__ int shard_steps(const ure_shard_t &S) { return (S.N + S.batch - 1) / S.batch; }
-
-// Once per epoch and shard: tag every slot with the batch its interaction is drawn
-// into.  perm[b] = file-order index of the b-th sample of the epoch (read.py:133).
-// Four samples per thread so that the eight dependent position look-ups overlap.
-__global__ __launch_bounds__(kBlock) void assign_batches_kernel(const ure_shard_t *__restrict__ shards, int64_t tick)
-{
-    const ure_shard_t &S = shards[blockIdx.y];
-    const int steps = shard_steps(S);
-    if (tick >= (int64_t)steps * S.epochs) return;
-    const int epoch = (int)(tick / steps);
-    if (tick - (int64_t)epoch * steps != 0) return;
-    const int32_t *__restrict__ perm = S.perm + (size_t)epoch * S.N;
-    const int n = S.N;
-    for (int b0 = (blockIdx.x * kBlock + threadIdx.x) * 4; b0 < n; b0 += gridDim.x * kBlock * 4) {
-        int j[4], pu[4], pi[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) j[k] = b0 + k < n ? perm[b0 + k] : -1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool ok = (unsigned)j[k] < (unsigned)n;   // malformed permutation: never index outside the shard
-            pu[k] = ok ? S.u_pos[j[k]] : -1;
-            pi[k] = ok ? S.i_pos[j[k]] : -1;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint16_t s = (uint16_t)((b0 + k) / S.batch);
-            if (pu[k] >= 0) S.ent_tag[pu[k]] = s;
-            if (pi[k] >= 0) S.ent_tag[pi[k]] = s;
-        }
-    }
-}
 
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__restrict__ shards, int64_t tick)
@@ -93,10 +54,15 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     constexpr int G = kWave / LPR;           // table rows one wave instruction gathers
     constexpr int R4 = 4 * G;
     constexpr int CAP = kSegPerLane * LPR;   // group path: slots per segment = queue capacity per group
-    __shared__ int q_oid[kWavesPerBlock][kQueue];
-    __shared__ float q_r[kWavesPerBlock][kQueue];
+    // one raw LDS block: the row paths use it as match queues, the tag riders overlay their own
+    // arrays on it (tag_prep.h)
+    constexpr int kQueueBytes = kWavesPerBlock * kQueue * 8;
+    static_assert(kTagLds <= kQueueBytes, "tag phases must fit in the queue space");
+    __shared__ __attribute__((aligned(16))) char lds_raw[kQueueBytes];
     __shared__ float4 part_acc[kWavesPerBlock][LPR];
     __shared__ float part_sse[kWavesPerBlock];
+    int (*q_oid)[kQueue] = reinterpret_cast<int (*)[kQueue]>(lds_raw);
+    float (*q_r)[kQueue] = reinterpret_cast<float (*)[kQueue]>(lds_raw + kWavesPerBlock * kQueue * 4);
 
     const ure_shard_t &S = shards[blockIdx.y];
     const int steps = shard_steps(S);
@@ -112,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     const int4 *__restrict__ sched = reinterpret_cast<const int4 *>(S.sched);
     const int32_t *__restrict__ ent_oid = S.ent_oid;
     const float *__restrict__ ent_r = S.ent_r;
-    const uint16_t *__restrict__ ent_tag = S.ent_tag;
+    const uint16_t *__restrict__ ent_tag = S.ent_tag + (size_t)(epoch & 1) * S.n_slots;
     int *qo = q_oid[wave];
     float *qr = q_r[wave];
 
@@ -140,7 +106,17 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     const int nbB = S.n_block;
     const int nbW = (S.n_wave - S.n_block + kWavesPerBlock - 1) / kWavesPerBlock;
     const int nbG = (S.n_active - S.n_wave + kWavesPerBlock * G - 1) / (kWavesPerBlock * G);
-    const int blk = (int)blockIdx.x;
+    // While epoch e trains, its steps 0, 1, 2 carry the three phases of epoch e+1's batch tags as
+    // extra workgroups at the front of the grid (tag_prep.h); the launch boundary between steps
+    // orders the phases.
+    const int nbR = tag_rider_blocks(S.N, S.n_slots, steps, s, epoch + 1 < S.epochs);
+    if ((int)blockIdx.x < nbR) {
+        if (s == 0) tag_partition(S, epoch + 1, (int)blockIdx.x, lds_raw);
+        else if (s == 1) tag_collect(S, (int)blockIdx.x, lds_raw);
+        else tag_derive(S, epoch + 1, (int)blockIdx.x, nbR);
+        return;
+    }
+    const int blk = (int)blockIdx.x - nbR;
 
     if (blk >= nbB + nbW) {
         // ------------------------------------------------ group path and decay-only path
@@ -399,8 +375,8 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         const int n_rows = S.n_user + S.n_item;
         const bool ok = S.N > 0 && S.n_user > 0 && S.n_item > 0 && S.batch > 0 && S.epochs > 0 && pow2(S.d) && S.d >= 4 &&
                         S.d <= 256 && S.n_block >= 0 && S.n_block <= S.n_wave && S.n_wave <= S.n_active &&
-                        S.n_active <= n_rows && S.n_slots >= S.N && S.ent_oid && S.ent_r && S.ent_tag && S.u_pos &&
-                        S.i_pos && S.sched && S.U[0] && S.U[1] && S.V[0] && S.V[1] && S.mU && S.mV && S.perm && S.lr && S.sse;
+                        S.n_active <= n_rows && S.n_slots >= S.N && S.ent_oid && S.ent_r && S.ent_tag && S.ent_src &&
+                        S.file_tag && S.sched && S.U[0] && S.U[1] && S.V[0] && S.V[1] && S.mU && S.mV && S.perm && S.lr && S.sse;
         if (!ok) { delete job; return fail(-1, "ure_job_create: shard %d has an invalid descriptor", k); }
         if (S.d != shards[0].d) { delete job; return fail(-1, "ure_job_create: all shards of a job share d"); }
         const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
@@ -410,13 +386,19 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         const int per_block = per_wave * kWavesPerBlock;
         const int blocks = S.n_block + (S.n_wave - S.n_block + kWavesPerBlock - 1) / kWavesPerBlock +
                            (S.n_active - S.n_wave + per_block - 1) / per_block + (n_rows - S.n_active + per_block - 1) / per_block;
-        job->max_blocks = std::max(job->max_blocks, blocks);
+        const int riders = (steps >= 3 && tag_partitioned(S.N)) ? std::max(tag_ranges(S.N), tag_derive_blocks(S.n_slots)) : 0;
+        job->max_blocks = std::max(job->max_blocks, blocks + riders);
         job->max_n = std::max(job->max_n, S.N);
+        job->max_slots = std::max(job->max_slots, S.n_slots);
+        const bool small = tag_partitioned(S.N);
+        if (small && !(S.inv_stage && S.inv_off)) { delete job; return fail(-1, "ure_job_create: shard %d lacks inv_stage / inv_off", k); }
+        (small ? job->small_shards : job->large_shards) = true;
+        if (small) job->max_small_n = std::max(job->max_small_n, S.N);
     }
     job->d = shards[0].d;
     hipError_t e = hipMalloc(&job->dev, sizeof(ure_shard_t) * n_shards);
     if (e == hipSuccess) e = hipMemcpy(job->dev, shards, sizeof(ure_shard_t) * n_shards, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { if (job->dev) (void)hipFree(job->dev); delete job; return fail((int)e, "ure_job_create: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { const int rc = fail((int)e, "ure_job_create: %s", hipGetErrorString(e)); ure_job_destroy(reinterpret_cast<ure_job_t *>(job)); return rc; }
     *out = reinterpret_cast<ure_job_t *>(job);
     return 0;
 }
@@ -447,8 +429,6 @@ int64_t ure_job_ticks(const ure_job_t *j)
 static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStream_t st, std::vector<hipEvent_t> *step_ev,
                        std::vector<hipEvent_t> *assign_ev)
 {
-    const unsigned n_shards = (unsigned)job->host.size();
-    const unsigned assign_blocks = (unsigned)std::min((job->max_n + kBlock * 4 - 1) / (kBlock * 4), 2048);
     auto mark = [&](std::vector<hipEvent_t> *v) -> int {
         if (!v) return 0;
         hipEvent_t e;
@@ -458,14 +438,11 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
         return 0;
     };
     for (int64_t t = tick0; t < tick1; ++t) {
-        bool epoch_start = false;
-        for (const ure_shard_t &S : job->host) {
-            const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
-            if (t < steps * S.epochs && t % steps == 0) { epoch_start = true; break; }
-        }
-        if (epoch_start) {
+        // batch tags: the step kernel prepares the next epoch's itself (riders); epoch 0, shards with
+        // fewer than 3 steps per epoch and very large shards get standalone launches here
+        if (tag_prep_needed(job, t)) {
             if (int rc = mark(assign_ev)) return rc;
-            hipLaunchKernelGGL(assign_batches_kernel, dim3(assign_blocks, n_shards), dim3(kBlock), 0, st, job->dev, t);
+            launch_tag_prep(job, t, st);
             if (int rc = mark(assign_ev)) return rc;
         }
         if (int rc = mark(step_ev)) return rc;

@@ -1,0 +1,182 @@
+// tag_prep.h -- per-epoch batch tags for gfx950: which optimizer step of the epoch trains
+// each interaction.  Device code shared by the step kernel (mf_train.hip), which carries
+// these phases as extra workgroups, and by the standalone launches (tag_prep.hip).
+//
+// Replaces the batching of the reference's DataLoader (read.py:127-133): with the epoch's
+// permutation perm (torch RandomSampler), batch s is perm[s*B : (s+1)*B], so interaction j
+// trains in step inv[j] / B where inv is the inverse permutation.  The step kernel wants that
+// number per slot of its row segments (ent_tag), in slot order.
+//
+// A direct scatter (tag[pos[perm[b]]] = b / B) costs one 64-byte memory-side write per 2-byte
+// store on gfx950 -- stores leave the L2 as they are issued, partial lines are not merged
+// (profiles/r01/NOTES.md, tools/microbench/scatter.hip: ~50 G stores/s whatever the element
+// size) -- and that fabric traffic does not hide beside the step kernel (measured).  So the
+// inverse is built as a radix partition whose global traffic is all full-line:
+//   phase A  partition   workgroup c takes perm[c*2K : (c+1)*2K], bins the entries by the
+//                        2K-range their target j falls in (LDS counting sort) and writes the
+//                        reordered chunk, packed (j mod 2K | tag << 11), plus the bin offsets;
+//   phase B  collect     workgroup r gathers bin r of every chunk (~2K entries in all), drops
+//                        them into an LDS image of file_tag[r*2K : (r+1)*2K] and writes the
+//                        image with full-line stores;
+//   phase C  derive      ent_tag[p] = file_tag[ent_src[p]]: coalesced reads, L2-resident 2-byte
+//                        gathers, full-line stores.
+// While epoch e trains, steps 0, 1 and 2 of e carry phases A, B and C for epoch e+1 (ent_tag is
+// double-buffered by epoch parity); the kernel boundary between steps is the barrier between
+// phases.  Epoch 0, shards with fewer than 3 steps per epoch, and shards beyond kMaxRanges
+// ranges (2 M interactions; plain scatter) use standalone launches instead.
+#pragma once
+#include "ure_internal.h"
+
+namespace ure {
+
+constexpr int kRange = 2048;           // file indices per range = permutation entries per chunk
+constexpr int kMaxRanges = 1024;
+constexpr int kRangeBits = 11;
+static_assert((1 << kRangeBits) == kRange, "range size");
+
+__host__ __device__ inline int tag_ranges(int n) { return (n + kRange - 1) / kRange; }
+__host__ __device__ inline bool tag_partitioned(int n) { return tag_ranges(n) <= kMaxRanges; }
+
+// LDS needs of the phases, in bytes (the step kernel overlays them on its own arrays)
+constexpr int kTagLdsA = (kMaxRanges + 1) * 4 + kRange * 4 + kBlock * 4;
+constexpr int kTagLdsB = kRange * 2 + 2 * kMaxRanges * 4;
+constexpr int kTagLds = kTagLdsA > kTagLdsB ? kTagLdsA : kTagLdsB;
+
+// b / batch without an integer division per entry: M = ceil(2^62 / batch); (b * M) >> 62 is
+// exact while b * batch < 2^62.
+struct BatchOf {
+    unsigned long long M;
+    __device__ explicit BatchOf(int batch) : M((0x4000000000000000ull + (unsigned long long)batch - 1) / (unsigned long long)batch) {}
+    __device__ __forceinline__ int operator()(int b) const { return (int)__umul64hi((unsigned long long)b << 2, M); }
+};
+
+// Phase A, workgroup `c` of tag_ranges(N) (256 threads).
+__device__ inline void tag_partition(const ure_shard_t &S, int epoch, int c, char *lds)
+{
+    int *cnt = reinterpret_cast<int *>(lds);                            // [kMaxRanges + 1]
+    uint32_t *buf = reinterpret_cast<uint32_t *>(cnt + kMaxRanges + 1);  // [kRange]
+    int *scan = reinterpret_cast<int *>(buf + kRange);                  // [kBlock]
+    const int n = S.N;
+    const int n_ranges = tag_ranges(n);
+    const int32_t *__restrict__ perm = S.perm + (size_t)epoch * n;
+    uint32_t *__restrict__ stage = S.inv_stage;
+    int32_t *__restrict__ off = S.inv_off + (size_t)c * (n_ranges + 1);
+    const BatchOf batch_of(S.batch);
+    const int tid = threadIdx.x;
+    const int b_lo = c * kRange, b_hi = min(b_lo + kRange, n);
+
+    for (int t = tid; t <= n_ranges; t += kBlock) cnt[t] = 0;
+    __syncthreads();
+    constexpr int PER = kRange / kBlock;               // 8 entries per thread
+    int jv[PER], rank[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int b = b_lo + k * kBlock + tid;
+        jv[k] = b < b_hi ? perm[b] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        rank[k] = 0;
+        if ((unsigned)jv[k] < (unsigned)n) rank[k] = atomicAdd(&cnt[jv[k] >> kRangeBits], 1);   // malformed entries are dropped
+        else jv[k] = -1;
+    }
+    __syncthreads();
+    // exclusive prefix of cnt[0..n_ranges): four consecutive counters per thread + a block scan
+    int loc[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = tid * 4 + k;
+        loc[k] = t < n_ranges ? cnt[t] : 0;
+        sum += loc[k];
+    }
+    scan[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < kBlock; o <<= 1) {
+        const int v = tid >= o ? scan[tid - o] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    int run = scan[tid] - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = tid * 4 + k;
+        if (t < n_ranges) cnt[t] = run;
+        run += loc[k];
+    }
+    if (tid == kBlock - 1) cnt[n_ranges] = scan[tid];
+    __syncthreads();
+    for (int t = tid; t <= n_ranges; t += kBlock) off[t] = cnt[t];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (jv[k] >= 0) {
+            const int b = b_lo + k * kBlock + tid;
+            buf[cnt[jv[k] >> kRangeBits] + rank[k]] = (uint32_t)(jv[k] & (kRange - 1)) | ((uint32_t)batch_of(b) << kRangeBits);
+        }
+    }
+    __syncthreads();
+    const int total = cnt[n_ranges];
+    for (int t = tid; t < total; t += kBlock) stage[(size_t)b_lo + t] = buf[t];
+}
+
+// Phase B, workgroup `r` of tag_ranges(N) (256 threads).
+__device__ inline void tag_collect(const ure_shard_t &S, int r, char *lds)
+{
+    uint16_t *img = reinterpret_cast<uint16_t *>(lds);                  // [kRange]
+    int *lo = reinterpret_cast<int *>(img + kRange);                    // [kMaxRanges]
+    int *hi = lo + kMaxRanges;                                          // [kMaxRanges]
+    const int n = S.N;
+    const int n_ranges = tag_ranges(n);
+    const uint32_t *__restrict__ stage = S.inv_stage;
+    const int32_t *__restrict__ off = S.inv_off;
+    uint16_t *__restrict__ file_tag = S.file_tag;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < kRange; t += kBlock) img[t] = 0xFFFFu;        // an index the permutation misses never trains
+    for (int c = tid; c < n_ranges; c += kBlock) {
+        lo[c] = off[(size_t)c * (n_ranges + 1) + r];
+        hi[c] = off[(size_t)c * (n_ranges + 1) + r + 1];
+    }
+    __syncthreads();
+    // bins are ~2K / n_ranges entries: a quarter wave per chunk keeps most lanes busy
+    const int sub = tid & 15, part = tid >> 4;
+    for (int c = part; c < n_ranges; c += kBlock / 16) {
+        const uint32_t *__restrict__ src = stage + (size_t)c * kRange;
+        for (int t = lo[c] + sub; t < hi[c]; t += 16) {
+            const uint32_t e = src[t];
+            img[e & (kRange - 1)] = (uint16_t)(e >> kRangeBits);
+        }
+    }
+    __syncthreads();
+    const int j0 = r * kRange;
+    for (int t = tid; t < kRange && j0 + t < n; t += kBlock) file_tag[j0 + t] = img[t];
+}
+
+// Phase C, workgroup `blk` of `n_blk` (256 threads, eight slots per thread).
+__device__ inline void tag_derive(const ure_shard_t &S, int epoch, int blk, int n_blk)
+{
+    const int32_t *__restrict__ ent_src = S.ent_src;
+    const uint16_t *__restrict__ file_tag = S.file_tag;
+    uint16_t *__restrict__ ent_tag = S.ent_tag + (size_t)(epoch & 1) * S.n_slots;
+    const int64_t n8 = S.n_slots / 8;
+    for (int64_t q = (int64_t)blk * kBlock + threadIdx.x; q < n8; q += (int64_t)n_blk * kBlock) {
+        const int4 s0 = *reinterpret_cast<const int4 *>(ent_src + q * 8);
+        const int4 s1 = *reinterpret_cast<const int4 *>(ent_src + q * 8 + 4);
+        const int sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        unsigned tg[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tg[k] = sv[k] >= 0 ? (unsigned)file_tag[sv[k]] : 0xFFFFu;
+        *reinterpret_cast<uint4 *>(ent_tag + q * 8) =
+            make_uint4(tg[0] | (tg[1] << 16), tg[2] | (tg[3] << 16), tg[4] | (tg[5] << 16), tg[6] | (tg[7] << 16));
+    }
+}
+
+__host__ __device__ inline int tag_derive_blocks(int64_t n_slots) { return (int)((n_slots / 8 + kBlock - 1) / kBlock); }
+
+// Number of extra workgroups step `s` of an epoch carries for the NEXT epoch's tags.
+__host__ __device__ inline int tag_rider_blocks(int n, int64_t n_slots, int steps, int s, bool has_next)
+{
+    if (!has_next || steps < 3 || !tag_partitioned(n)) return 0;
+    return s == 0 || s == 1 ? tag_ranges(n) : s == 2 ? tag_derive_blocks(n_slots) : 0;
+}
+
+}  // namespace ure

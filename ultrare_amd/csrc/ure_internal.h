@@ -2,8 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
+#include <vector>
 
 #include "ultrare_hip.h"
 
@@ -29,6 +32,22 @@ int fail(int code, const char *fmt, ...);
         if (!(cond)) return ::ure::fail(-1, "%s:%d argument check failed: %s", __FILE__,      \
                                         __LINE__, #cond);                                     \
     } while (0)
+
+// A set of shards trained side by side (ure_job_t of the C ABI).
+struct ure_job {
+    std::vector<ure_shard_t> host;
+    ure_shard_t *dev = nullptr;
+    int64_t ticks = 0;
+    int max_blocks = 0;
+    int max_n = 0, max_small_n = 0;
+    int64_t max_slots = 0;
+    int d = 0;
+    bool small_shards = false, large_shards = false;   // which tag-preparation paths the job needs
+};
+
+// tag_prep.hip: standalone per-epoch tag preparation (the step kernel carries the common case)
+bool tag_prep_needed(const ure_job *job, int64_t tick);
+void launch_tag_prep(const ure_job *job, int64_t tick, hipStream_t st);
 
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 

@@ -5,9 +5,10 @@ include/ultrare_hip.h -- only layout building (numpy, once per shard), device me
 (torch tensors) and launches.
 
 HBM layout of one shard:
-  slot arrays  ent_oid[n_slots] i32 | ent_r[n_slots] f32 | ent_tag[n_slots] u16 -- one 8-aligned,
+  slot arrays  ent_oid[n_slots] i32 | ent_r[n_slots] f32 | ent_tag[2][n_slots] u16 -- one 8-aligned,
                padded segment per destination row (users and items), in schedule order
-  u_pos[N], i_pos[N] i32   file-order index -> slot in the user's / the item's segment
+  ent_src[n_slots] i32     slot -> file-order index of its interaction (-1 in padding)
+  file_tag[N] u16          scratch: batch of interaction j in the epoch being prepared
   sched[n_user+n_item][4] i32   {row id, first slot, end slot, nnz}, heaviest row first
   U[2][n_user][d] V[2][n_item][d] f32 ping-pong weights ; mU, mV momentum
   perm[epochs][N] i32 ; lr[epochs] f32 ; sse[epochs][n_user] f32 (per-user squared error)
@@ -89,6 +90,8 @@ class ShardData:
         ent_r = np.zeros(self.n_slots, dtype=np.float32)
         ent_oid[u_pos], ent_r[u_pos] = iid, rating
         ent_oid[i_pos], ent_r[i_pos] = uid, rating
+        ent_src = np.full(self.n_slots, -1, dtype=np.int32)
+        ent_src[u_pos] = ent_src[i_pos] = np.arange(n, dtype=np.int32)
         sched = np.stack([order, row_beg[order], row_beg[order] + padded[order], nnz[order]], axis=1).astype(np.int32)
         b_thr = BLOCK_NNZ if block_nnz is None else block_nnz
         g_thr = GROUP_NNZ if group_nnz is None else group_nnz
@@ -99,13 +102,18 @@ class ShardData:
         dev = self.device
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.ent_oid, self.ent_r = to(ent_oid), to(ent_r)
-        self.u_pos, self.i_pos = to(u_pos.astype(np.int32)), to(i_pos.astype(np.int32))
-        self.ent_tag = torch.full((self.n_slots,), -1, dtype=torch.int16, device=dev)      # 0xFFFF: matches no batch
+        self.ent_src = to(ent_src)
+        self.u_pos, self.i_pos = u_pos, i_pos                                              # host copies (tests, tools)
+        self.ent_tag = torch.full((2, self.n_slots), -1, dtype=torch.int16, device=dev)   # 0xFFFF: matches no batch
+        self.file_tag = torch.full((n,), -1, dtype=torch.int16, device=dev)
+        ranges = (n + 2047) // 2048
+        self.inv_stage = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.inv_off = torch.zeros(max(ranges * (ranges + 1), 1) if ranges <= 1024 else 1, dtype=torch.int32, device=dev)
         self.sched = to(sched)
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in
-                   (self.ent_oid, self.ent_r, self.ent_tag, self.u_pos, self.i_pos, self.sched))
+                   (self.ent_oid, self.ent_r, self.ent_tag, self.ent_src, self.file_tag, self.sched))
 
 
 class TrainJob:
@@ -143,7 +151,7 @@ class TrainJob:
             sse = torch.zeros(self.epochs, sh.n_user, dtype=torch.float32, device=dev)
             self.state.append({'U': U, 'V': V, 'mU': mU, 'mV': mV, 'perm': perm, 'sse': sse})
             D = descs[s]
-            for name in ('ent_oid', 'ent_r', 'ent_tag', 'u_pos', 'i_pos', 'sched'):
+            for name in ('ent_oid', 'ent_r', 'ent_tag', 'ent_src', 'file_tag', 'inv_stage', 'inv_off', 'sched'):
                 setattr(D, name, nv.ptr(getattr(sh, name)))
             D.n_block, D.n_wave, D.n_active, D.n_slots = sh.n_block, sh.n_wave, sh.n_active, sh.n_slots
             D.U[0], D.U[1] = nv.ptr(U[0]), nv.ptr(U[1])
