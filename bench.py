@@ -44,20 +44,22 @@ def parse():
     return ap.parse_args()
 
 
-def interactions_in_ticks(sizes, batch, t0, t1, epochs):
-    """Exact number of interactions the ticks [t0, t1) process over all shards."""
+def interactions_in_ticks(sizes, batch, t0, t1, epochs, dense_bytes=None):
+    """Exact number of interactions the ticks [t0, t1) process over all shards, and the
+    algorithmic bytes of every tick ((16 + 16 d) per interaction + 20 P per dense
+    optimizer step, P counted over the rows actually streamed)."""
     total = 0
     per_tick = np.zeros(max(t1 - t0, 0), dtype=np.int64)
-    active = np.zeros(max(t1 - t0, 0), dtype=np.int64)
-    for n in sizes:
+    dense = np.zeros(max(t1 - t0, 0), dtype=np.int64)
+    for k, n in enumerate(sizes):
         steps = (n + batch - 1) // batch
         last = n - (steps - 1) * batch
         for t in range(t0, min(t1, steps * epochs)):
             bs = last if (t % steps) == steps - 1 else batch
             per_tick[t - t0] += bs
-            active[t - t0] += 1
+            dense[t - t0] += dense_bytes[k] if dense_bytes is not None else 0
             total += bs
-    return total, per_tick, active
+    return total, per_tick, dense
 
 
 def main():
@@ -133,11 +135,13 @@ def main():
     # batch tags ride inside them), so the kernel's average duration is the HIP-event time of the
     # region / launches, on the stream the launches went to.  A second pass with one event pair
     # per launch (ure_job_train_profiled) is reported beside it.
-    _, per_tick, active = interactions_in_ticks(sizes, a.batch, t0_tick, t0_tick + a.steps * tps, epochs)
+    dp = engine.pad_dim(a.d)
+    rows_streamed = [sh.n_active if job.lazy_rows else spec['n_user'] + spec['n_item'] for sh in shards]
+    _, per_tick, dense = interactions_in_ticks(sizes, a.batch, t0_tick, t0_tick + a.steps * tps, epochs,
+                                               dense_bytes=[20 * r * dp for r in rows_streamed])
     n_launch = a.steps * tps
-    P = (spec['n_user'] + spec['n_item']) * engine.pad_dim(a.d)
-    b_sparse = 16 + 16 * engine.pad_dim(a.d)
-    alg_bytes = float((per_tick * b_sparse + active * 20 * P).sum()) / n_launch              # per launch
+    b_sparse = 16 + 16 * dp
+    alg_bytes = float((per_tick * b_sparse + dense).sum()) / n_launch                          # per launch
     avg_ms = dev_ms / n_launch
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     step_ms, n_step, assign_ms, n_assign = job.run_profiled(a.roofline_steps * tps)
@@ -156,7 +160,8 @@ def main():
     roofline = {'bound': 'hbm', 'kernel': 'mf_step_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                 'alg_bytes_per_launch': round(alg_bytes), 'avg_launch_us': round(avg_ms * 1e3, 2),
-                'launches_timed': n_launch, 'per_launch_event_us': round(step_ms / max(n_step, 1) * 1e3, 2)}
+                'launches_timed': n_launch, 'per_launch_event_us': round(step_ms / max(n_step, 1) * 1e3, 2),
+                'dense_rows_streamed_per_shard': rows_streamed, 'lazy_rows': bool(job.lazy_rows)}
 
     # ---- CPU baseline (rank 0, N = 1): the torch DataLoader port of the reference ---
     cpu = None

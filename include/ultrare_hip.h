@@ -75,6 +75,15 @@ typedef struct ure_shard {
     float *V[2];            /* [n_item][d]                                          */
     float *mU;              /* [n_user][d] SGD momentum buffer                      */
     float *mV;              /* [n_item][d]                                          */
+    /* Rows [n_active, rows) of the schedule have no interaction in this shard: nobody gathers
+     * them and they evolve linearly (weight decay + momentum only, scratch.py:65-68).  With
+     * lazy_rows != 0 the step kernel skips them and ure_job_materialize() writes their closed
+     * form a_T * w0, b_T * w0 when the tables are read; with 0 they are streamed every step
+     * exactly like the reference does.                                              */
+    const float *U0;        /* [n_user][d] initial tables (kept for the closed form)   */
+    const float *V0;        /* [n_item][d]                                          */
+    const float *lr_host;   /* [epochs] HOST copy of lr (read by ure_job_create only) */
+    int32_t lazy_rows;
     /* per-epoch inputs / outputs */
     const int32_t *perm;    /* [epochs][N] the epoch permutations (RandomSampler)   */
     const float   *lr;      /* [epochs] learning rate of each epoch (StepLR)        */
@@ -105,6 +114,10 @@ int64_t ure_job_ticks(const ure_job_t *job);
  * tables are U[ticks_done & 1] / V[ticks_done & 1] of each shard, where
  * ticks_done = min(tick1, shard steps). */
 int ure_job_train(ure_job_t *job, int64_t tick0, int64_t tick1, void *stream);
+/* Brings the rows that lazy_rows skips up to date in the current tables (and momentum) of
+ * every shard, for `ticks_done` = the number of ticks trained so far.  Call before reading
+ * the tables; training may continue afterwards.  No-op for shards with lazy_rows == 0. */
+int ure_job_materialize(ure_job_t *job, int64_t ticks_done, void *stream);
 /* Measurement aid (bench.py's roofline leg): the same ticks, each kernel launch
  * bracketed by a pair of HIP events on `stream`; synchronises the stream and returns
  * the summed durations and launch counts of the step kernel and of the per-epoch

@@ -25,6 +25,7 @@ class UreShard(ctypes.Structure):
         ('ent_oid', _vp), ('ent_r', _vp), ('ent_tag', _vp), ('ent_src', _vp), ('file_tag', _vp), ('inv_stage', _vp), ('inv_off', _vp),
         ('sched', _vp), ('n_block', _i32), ('n_wave', _i32), ('n_active', _i32), ('n_slots', _i64),
         ('U', _vp * 2), ('V', _vp * 2), ('mU', _vp), ('mV', _vp),
+        ('U0', _vp), ('V0', _vp), ('lr_host', _vp), ('lazy_rows', _i32),
         ('perm', _vp), ('lr', _vp), ('sse', _vp),
         ('N', _i32), ('n_user', _i32), ('n_item', _i32), ('d', _i32),
         ('batch', _i32), ('epochs', _i32),
@@ -46,6 +47,7 @@ _PROTOTYPES = {
     'ure_job_shard_steps': (_i64, [_vp, ctypes.c_int]),
     'ure_job_ticks': (_i64, [_vp]),
     'ure_job_train': (ctypes.c_int, [_vp, _i64, _i64, _vp]),
+    'ure_job_materialize': (ctypes.c_int, [_vp, _i64, _vp]),
     'ure_job_train_profiled': (ctypes.c_int, [_vp, _i64, _i64, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
                                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64)]),
     'ure_host_randperm': (ctypes.c_int, [_vp, ctypes.c_int, _i64, _vp, ctypes.c_int]),

@@ -106,6 +106,10 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     const int nbB = S.n_block;
     const int nbW = (S.n_wave - S.n_block + kWavesPerBlock - 1) / kWavesPerBlock;
     const int nbG = (S.n_active - S.n_wave + kWavesPerBlock * G - 1) / (kWavesPerBlock * G);
+    // lazy_rows: rows [n_active, n_rows) are never gathered by anyone and evolve linearly
+    // (w, m)_t = A_t (w, m)_{t-1}; they are then advanced in closed form only when the tables are
+    // read (materialize_rows_kernel) instead of being streamed through HBM every step
+    const int nbD = S.lazy_rows ? 0 : (n_rows - S.n_active + kWavesPerBlock * G - 1) / (kWavesPerBlock * G);
     // While epoch e trains, its steps 0, 1, 2 carry the three phases of epoch e+1's batch tags as
     // extra workgroups at the front of the grid (tag_prep.h); the launch boundary between steps
     // orders the phases.
@@ -118,6 +122,7 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     }
     const int blk = (int)blockIdx.x - nbR;
 
+    if (blk >= nbB + nbW + nbG + nbD) return;
     if (blk >= nbB + nbW) {
         // ------------------------------------------------ group path and decay-only path
         const bool dense_only = blk >= nbB + nbW + nbG;
@@ -352,6 +357,34 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     if (is_user && lane == 0 && sse != 0.f) S.sse[(size_t)epoch * S.n_user + row] += sse;
 }
 
+// Rows without interactions in their shard, advanced in closed form: after T optimizer steps
+// w_T = a_T * w_0 and m_T = b_T * w_0 with scalars (a, b) from the same recurrence the optimizer
+// applies to every element (g = lam*w; m = mu*m + g (m = g first); w -= lr*m), evaluated in
+// double on the host.  Differs from T fp32 steps by their accumulated rounding only (~1e-6).
+__global__ __launch_bounds__(kBlock) void materialize_rows_kernel(const ure_shard_t *__restrict__ shards, const double *__restrict__ ab,
+                                                                 int64_t ticks_done)
+{
+    const ure_shard_t &S = shards[blockIdx.y];
+    if (!S.lazy_rows) return;
+    const int steps = shard_steps(S);
+    const int64_t T = min(ticks_done, (int64_t)steps * S.epochs);
+    if (T <= 0) return;
+    const int cur = (int)(T & 1);
+    const float a = (float)ab[2 * blockIdx.y], b = (float)ab[2 * blockIdx.y + 1];
+    const int d4 = S.d / 4;
+    const int n_rows = S.n_user + S.n_item;
+    const int64_t total = (int64_t)(n_rows - S.n_active) * d4;
+    const int4 *__restrict__ sched = reinterpret_cast<const int4 *>(S.sched);
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+        const int row_id = sched[S.n_active + t / d4].x;
+        const bool is_user = row_id < S.n_user;
+        const size_t o = (size_t)(is_user ? row_id : row_id - S.n_user) * S.d + (size_t)(t % d4) * 4;
+        const float4 w0 = *reinterpret_cast<const float4 *>((is_user ? S.U0 : S.V0) + o);
+        *reinterpret_cast<float4 *>((is_user ? S.U[cur] : S.V[cur]) + o) = make_float4(a * w0.x, a * w0.y, a * w0.z, a * w0.w);
+        *reinterpret_cast<float4 *>((is_user ? S.mU : S.mV) + o) = make_float4(b * w0.x, b * w0.y, b * w0.z, b * w0.w);
+    }
+}
+
 template <int LPR>
 static void launch_step(const ure_job *job, int64_t tick, hipStream_t st)
 {
@@ -376,7 +409,8 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         const bool ok = S.N > 0 && S.n_user > 0 && S.n_item > 0 && S.batch > 0 && S.epochs > 0 && pow2(S.d) && S.d >= 4 &&
                         S.d <= 256 && S.n_block >= 0 && S.n_block <= S.n_wave && S.n_wave <= S.n_active &&
                         S.n_active <= n_rows && S.n_slots >= S.N && S.ent_oid && S.ent_r && S.ent_tag && S.ent_src &&
-                        S.file_tag && S.sched && S.U[0] && S.U[1] && S.V[0] && S.V[1] && S.mU && S.mV && S.perm && S.lr && S.sse;
+                        S.file_tag && S.sched && S.U[0] && S.U[1] && S.V[0] && S.V[1] && S.mU && S.mV && S.perm && S.lr && S.sse &&
+                        (!S.lazy_rows || (S.U0 && S.V0 && S.lr_host));
         if (!ok) { delete job; return fail(-1, "ure_job_create: shard %d has an invalid descriptor", k); }
         if (S.d != shards[0].d) { delete job; return fail(-1, "ure_job_create: all shards of a job share d"); }
         const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
@@ -385,7 +419,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         const int per_wave = kWave / (S.d / 4);
         const int per_block = per_wave * kWavesPerBlock;
         const int blocks = S.n_block + (S.n_wave - S.n_block + kWavesPerBlock - 1) / kWavesPerBlock +
-                           (S.n_active - S.n_wave + per_block - 1) / per_block + (n_rows - S.n_active + per_block - 1) / per_block;
+                           (S.n_active - S.n_wave + per_block - 1) / per_block + (S.lazy_rows ? 0 : (n_rows - S.n_active + per_block - 1) / per_block);
         const int riders = (steps >= 3 && tag_partitioned(S.N)) ? std::max(tag_ranges(S.N), tag_derive_blocks(S.n_slots)) : 0;
         job->max_blocks = std::max(job->max_blocks, blocks + riders);
         job->max_n = std::max(job->max_n, S.N);
@@ -396,8 +430,15 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         if (small) job->max_small_n = std::max(job->max_small_n, S.N);
     }
     job->d = shards[0].d;
+    for (int k = 0; k < n_shards; ++k) {
+        const ure_shard_t &S = shards[k];
+        job->lr_host.emplace_back(S.lr_host ? std::vector<float>(S.lr_host, S.lr_host + S.epochs) : std::vector<float>());
+        job->host[k].lr_host = nullptr;                       // the caller's array need not outlive this call
+        job->max_lazy = std::max<int64_t>(job->max_lazy, S.lazy_rows ? (int64_t)(S.n_user + S.n_item - S.n_active) * (S.d / 4) : 0);
+    }
     hipError_t e = hipMalloc(&job->dev, sizeof(ure_shard_t) * n_shards);
-    if (e == hipSuccess) e = hipMemcpy(job->dev, shards, sizeof(ure_shard_t) * n_shards, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(job->dev, job->host.data(), sizeof(ure_shard_t) * n_shards, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&job->dev_ab, sizeof(double) * 2 * n_shards);
     if (e != hipSuccess) { const int rc = fail((int)e, "ure_job_create: %s", hipGetErrorString(e)); ure_job_destroy(reinterpret_cast<ure_job_t *>(job)); return rc; }
     *out = reinterpret_cast<ure_job_t *>(job);
     return 0;
@@ -408,6 +449,7 @@ int ure_job_destroy(ure_job_t *j)
     auto *job = reinterpret_cast<ure::ure_job *>(j);
     if (!job) return 0;
     if (job->dev) (void)hipFree(job->dev);
+    if (job->dev_ab) (void)hipFree(job->dev_ab);
     delete job;
     return 0;
 }
@@ -458,6 +500,36 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
         }
         if (int rc = mark(step_ev)) return rc;
     }
+    URE_HIP(hipGetLastError());
+    return 0;
+}
+
+int ure_job_materialize(ure_job_t *j, int64_t ticks_done, void *stream)
+{
+    auto *job = reinterpret_cast<ure::ure_job *>(j);
+    URE_ARG(job && ticks_done >= 0);
+    if (job->max_lazy == 0 || ticks_done == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t n = job->host.size();
+    job->ab_host.assign(2 * n, 0.0);
+    for (size_t k = 0; k < n; ++k) {
+        const ure_shard_t &S = job->host[k];
+        if (!S.lazy_rows) continue;
+        const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
+        const int64_t T = std::min(ticks_done, steps * S.epochs);
+        double a = 1.0, b = 0.0;
+        const double lam = (double)S.lam, mu = (double)S.mu;
+        for (int64_t t = 0; t < T; ++t) {
+            b = t == 0 ? lam * a : mu * b + lam * a;
+            a -= (double)job->lr_host[k][(size_t)(t / steps)] * b;
+        }
+        job->ab_host[2 * k] = a;
+        job->ab_host[2 * k + 1] = b;
+    }
+    // pageable source: the runtime stages the copy, so ab_host may be reused right after
+    URE_HIP(hipMemcpyAsync(job->dev_ab, job->ab_host.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
+    const unsigned blocks = (unsigned)std::min<int64_t>((job->max_lazy + kBlock - 1) / kBlock, 2048);
+    hipLaunchKernelGGL(materialize_rows_kernel, dim3(blocks, (unsigned)n), dim3(kBlock), 0, st, job->dev, job->dev_ab, ticks_done);
     URE_HIP(hipGetLastError());
     return 0;
 }

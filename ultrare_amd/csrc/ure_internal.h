@@ -43,6 +43,10 @@ struct ure_job {
     int64_t max_slots = 0;
     int d = 0;
     bool small_shards = false, large_shards = false;   // which tag-preparation paths the job needs
+    std::vector<std::vector<float>> lr_host;           // per shard: learning rate of each epoch (for the closed form)
+    std::vector<double> ab_host;                       // per shard (a, b) of the lazily advanced rows
+    double *dev_ab = nullptr;
+    int64_t max_lazy = 0;                              // float4 slices of lazily advanced rows, max over shards
 };
 
 // tag_prep.hip: standalone per-epoch tag preparation (the step kernel carries the common case)

@@ -25,6 +25,7 @@ from . import _native as nv
 # the rest one lane group (d/4 lanes) each
 BLOCK_NNZ = int(os.environ.get('URE_BLOCK_NNZ', '1024'))
 GROUP_NNZ = int(os.environ.get('URE_GROUP_NNZ', '128'))
+LAZY_ROWS = os.environ.get('URE_LAZY_ROWS', '1') != '0'
 
 
 def pad_dim(d):
@@ -124,7 +125,7 @@ class TrainJob:
     perms  : list of int32 [epochs, N_s] arrays (numpy or torch; CPU or device)
     """
 
-    def __init__(self, shards, inits, perms, k, batch, epochs, lr, lam, momentum, lr_decay=1.0, lr_step=50):
+    def __init__(self, shards, inits, perms, k, batch, epochs, lr, lam, momentum, lr_decay=1.0, lr_step=50, lazy_rows=None):
         assert len(shards) == len(inits) == len(perms) and len(shards) > 0
         self.shards, self.k, self.d = shards, int(k), pad_dim(int(k))
         self.batch, self.epochs = int(batch), int(epochs)
@@ -132,6 +133,11 @@ class TrainJob:
         self.device = dev
         # StepLR(step_size=50, gamma): lr of epoch t (scratch.py:69,79-80)
         lr_host = np.array([lr * (lr_decay ** (t // lr_step)) for t in range(self.epochs)], dtype=np.float32)
+        self._lr_host = lr_host
+        # rows a shard never touches only decay: advance them in closed form when the tables are read
+        # (URE_LAZY_ROWS=0 streams them every step, exactly as the reference's dense optimizer does)
+        self.lazy_rows = LAZY_ROWS if lazy_rows is None else bool(lazy_rows)
+        self._fresh = 0          # ticks for which the lazily advanced rows are up to date
         self.lr = torch.from_numpy(lr_host).to(dev)
         self.state = []
         descs = (nv.UreShard * len(shards))()
@@ -142,6 +148,7 @@ class TrainJob:
             U = torch.zeros(2, sh.n_user, self.d, dtype=torch.float32, device=dev)
             V = torch.zeros(2, sh.n_item, self.d, dtype=torch.float32, device=dev)
             U[0, :, :self.k] = U0.to(dev)
+            U0d, V0d = None, None
             V[0, :, :self.k] = V0.to(dev)
             mU = torch.zeros(sh.n_user, self.d, dtype=torch.float32, device=dev)
             mV = torch.zeros(sh.n_item, self.d, dtype=torch.float32, device=dev)
@@ -161,6 +168,10 @@ class TrainJob:
             D.N, D.n_user, D.n_item, D.d = sh.N, sh.n_user, sh.n_item, self.d
             D.batch, D.epochs = self.batch, self.epochs
             D.lam, D.mu = float(lam), float(momentum)
+            if self.lazy_rows:
+                U0d, V0d = U[0].clone(), V[0].clone()
+                self.state[-1].update(U0=U0d, V0=V0d)
+                D.U0, D.V0, D.lr_host, D.lazy_rows = nv.ptr(U0d), nv.ptr(V0d), lr_host.ctypes.data, 1
         self._descs = descs
         self._job = ctypes.c_void_p()
         nv.check(nv.lib().ure_job_create(descs, len(shards), ctypes.byref(self._job)), 'ure_job_create')
@@ -196,13 +207,21 @@ class TrainJob:
         assert len(self.shards) == 1
         return self.run(n_epochs * self.steps_per_epoch(0), stream)
 
+    def materialize(self, stream=None):
+        """Bring the lazily advanced rows (lazy_rows) up to date in the current tables."""
+        if self.lazy_rows and self._fresh != self.done:
+            nv.check(nv.lib().ure_job_materialize(self._job, self.done, nv.stream_handle(stream)), 'ure_job_materialize')
+            self._fresh = self.done
+
     def tables(self, s):
         """Current (U, V) of shard s as device views [rows, k]."""
+        self.materialize()
         cur = min(self.done, self.shard_steps[s]) & 1
         st = self.state[s]
         return st['U'][cur, :, :self.k], st['V'][cur, :, :self.k]
 
     def padded_tables(self, s):
+        self.materialize()
         cur = min(self.done, self.shard_steps[s]) & 1
         st = self.state[s]
         return st['U'][cur], st['V'][cur]
