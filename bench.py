@@ -35,8 +35,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--shards', type=int, default=5)
-    ap.add_argument('--d', type=int, default=32)
+    ap.add_argument('--workload', choices=['ml1m', 'ml25m'], default='ml1m',
+                    help="ml1m: BASELINE configs[1] (default); ml25m: configs[3] shape (32 shards, d=128) on one GPU")
+    ap.add_argument('--shards', type=int, default=None)
+    ap.add_argument('--d', type=int, default=None)
     ap.add_argument('--batch', type=int, default=30000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU baseline work')
@@ -79,7 +81,9 @@ def main():
     from ultrare_amd import _native as nv
 
     # ---- inputs: generated and made resident before anything is timed ----------
-    spec = synth.ML1M
+    spec = synth.ML1M if a.workload == 'ml1m' else synth.ML25M
+    a.shards = a.shards or (5 if a.workload == 'ml1m' else 32)
+    a.d = a.d or (32 if a.workload == 'ml1m' else 128)
     data = synth.make_dataset(**spec, seed=synth.SEED + rank)
     shard_of, _ = synth.uniform_shards(spec['n_user'], a.shards)
     parts = synth.split_shards(data['train'], shard_of, a.shards)
@@ -150,7 +154,7 @@ def main():
     traffic, traffic_src = None, None
     import glob
     pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', '*pmc_hbm_traffic.json')))
-    if pmc and a.d == 32 and a.shards == 5 and a.batch == 30000:
+    if pmc and a.workload == 'ml1m' and a.d == 32 and a.shards == 5 and a.batch == 30000:
         try:
             with open(pmc[-1]) as f:
                 k = [v for n, v in json.load(f)['kernels'].items() if 'mf_step_kernel' in n][0]
@@ -188,12 +192,12 @@ def main():
         except Exception:
             pass
         out = {
-            'metric': 'training interactions/sec, ml-1m 5-shard SISA',
+            'metric': 'training interactions/sec, ml-1m 5-shard SISA' if a.workload == 'ml1m' else f'training interactions/sec, synthetic ml-25m-scale {a.shards}-shard SISA',
             'value': round(n_total / wall, 1), 'unit': 'interactions/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(wall * 1e3 / a.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'ml-1m-shaped synthetic {spec["n_user"]}x{spec["n_item"]}, {spec["n_train"]} train rows, '
+            'config': {'workload': f'{a.workload}-shaped synthetic {spec["n_user"]}x{spec["n_item"]}, {spec["n_train"]} train rows, '
                                    f'{a.shards}-shard SISA (uniform grouping), d={a.d}, batch={a.batch}, SGD-momentum-L2, '
                                    f'all shards of a rank side by side',
                        'shards_per_gpu': a.shards, 'shard_rows': sizes, 'ticks_per_step': tps, 'parallelism': f'shards x{world}',
