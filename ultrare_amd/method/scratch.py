@@ -38,7 +38,7 @@ def prepare_shard(train_loader, n_user, n_item, k, epochs, has_total, given_mode
     seeds = rng.epoch_seeds(epochs, has_total)
     n = len(loader.dataset)
     if loader.shuffle:
-        perms = rng.epoch_perms(seeds, n, threads=PERM_THREADS)
+        perms = rng.epoch_perms(seeds, n, threads=PERM_THREADS, pooled=True)
     else:
         perms = torch.arange(n, dtype=torch.int32).repeat(epochs, 1)
     return loader.shard_data(n_user, n_item), (U0, V0), perms
@@ -94,6 +94,7 @@ class Scratch(object):
         batch = as_loader(train_data).batch_size
         job = engine.TrainJob([shard], [init], [perms], self.k, batch, self.epochs, self.lr, self.lam, self.momentum,
                               self.lr_decay)
+        rng.release(perms)                                  # uploaded: the host buffer goes back to the pool
         test_ev = as_loader(test_data).eval_set()
         total_ev = as_loader(test_total).eval_set() if has_total else None
         before = [padded_tables(m)[:2] for m in self._models_before()]

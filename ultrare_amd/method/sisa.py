@@ -125,6 +125,9 @@ class Sisa(Scratch):
             job = engine.TrainJob([prepared[i][0] for i in mine], [prepared[i][1] for i in mine],
                                   [prepared[i][2] for i in mine], self.k, batch, self.epochs, self.lr, self.lam,
                                   self.momentum, self.lr_decay)
+            from .. import rng
+            for i in mine:
+                rng.release(prepared[i][2])                 # uploaded: host buffers go back to the pool
             job.run()
             for pos, i in enumerate(mine):
                 U, V = job.tables(pos)
