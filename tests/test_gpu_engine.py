@@ -53,11 +53,13 @@ def test_full_mf_vs_reference_golden(toy, E):
 
 @pytest.mark.parametrize('k,batch,thr', [(4, 1000, (None, None)), (8, 3000, (64, 16)), (16, 3000, (0, 0)),
                                          (32, 5000, (10 ** 9, 10 ** 9)), (32, 3000, (10 ** 9, 0)), (64, 3000, (128, 8)),
-                                         (128, 30000, (256, 40)), (20, 3000, (None, None)), (256, 2000, (300, 100))])
+                                         (128, 30000, (256, 40)), (20, 3000, (None, None)), (256, 2000, (300, 100)),
+                                         (16, 15000, (None, None)), (16, 9454, (None, None))])
 def test_step_kernel_vs_oracle(toy, k, batch, thr):
     """Every table width (incl. a padded one), every row path alone (all rows by
-    workgroup / by wavefront / by lane group) and mixed, batch larger than the shard;
-    2 epochs against the C oracle on identical init/perms."""
+    workgroup / by wavefront / by lane group) and mixed, batch larger than the shard (1 step
+    per epoch), 2 and 3 steps per epoch (the boundary between standalone and riding batch-tag
+    preparation); 2 epochs against the C oracle on identical init/perms."""
     train, _ = toy
     E = 2
     lr = 1e-3 if k <= 128 else 1e-5          # N(0,1) tables of width 256 diverge at 1e-3 (in the oracle too)
@@ -144,3 +146,27 @@ def test_eval_on_reference_models(toy, E):
     np.testing.assert_allclose(got, g[f'E{E}_final_stable'], rtol=RTOL)
     pred = ev.predictions()
     assert rel(pred, O.score([(g[f'E{E}_U'], g[f'E{E}_V'])], test[0], test[1])) < 1e-5
+
+
+def test_large_shard_scatter_fallback_and_many_epochs():
+    """A shard beyond the LDS partition's reach (> 1024 ranges of 2048 = 2.1 M interactions)
+    takes the plain-scatter tag path; 3 epochs so that epoch parity of the tag buffers and
+    the per-epoch standalone launches are exercised.  d = 4 keeps the oracle quick."""
+    from ultrare_amd import engine, rng
+    rs = np.random.RandomState(3)
+    n_user, n_item, n = 4000, 3000, 2_200_000
+    key = rs.choice(n_user * n_item, n, replace=False)
+    part = ((key // n_item).astype(np.int32), (key % n_item).astype(np.int32), rs.choice([.2, .4, .6, .8, 1.], n).astype(np.float32))
+    k, B, E = 4, 300_000, 3
+    torch.manual_seed(1)
+    U0, V0 = rng.mf_init(n_user, n_item, k)
+    perms = rng.epoch_perms(rng.epoch_seeds(E, True), n)
+    job = engine.TrainJob([engine.ShardData(*part, n_user, n_item)], [(U0, V0)], [perms], k, B, E, 1e-4, 0.1, 0.9)
+    job.run()
+    torch.cuda.synchronize()
+    st = O.MFState(U0.numpy().copy(), V0.numpy().copy())
+    losses = [O.train_epoch(st, part, perms[t].numpy(), B, 1e-4, 0.1, 0.9)[0] for t in range(E)]
+    assert np.isfinite(st.U).all()
+    U, V = job.tables(0)
+    assert rel(U.cpu().numpy(), st.U) < 1e-4 and rel(V.cpu().numpy(), st.V) < 1e-4
+    np.testing.assert_allclose(np.sqrt(job.epoch_sse(0) / n), losses, rtol=1e-4)
