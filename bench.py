@@ -43,6 +43,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU baseline work')
     ap.add_argument('--roofline-steps', type=int, default=3)
+    ap.add_argument('--backend', default='nccl', help='process-group backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
+    ap.add_argument('--force-device', type=int, default=None, help='rehearsal only: put every rank on this device')
     return ap.parse_args()
 
 
@@ -71,11 +73,16 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    if a.force_device is not None:
+        local = a.force_device
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if a.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(a.backend)
 
     from ultrare_amd import engine, rng, synth
     from ultrare_amd import _native as nv
