@@ -348,7 +348,9 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
                 acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
             }
         }
-        sse = (part_sse[0] + part_sse[1]) + (part_sse[2] + part_sse[3]);
+        sse = 0.f;
+#pragma unroll
+        for (int k = 0; k < kWavesPerBlock; ++k) sse += part_sse[k];
     }
 
     if (lane < LPR) sgd_update(w, m4, acc, mom + row_off, w_next + row_off);
@@ -388,7 +390,17 @@ __global__ __launch_bounds__(kBlock) void materialize_rows_kernel(const ure_shar
 template <int LPR>
 static void launch_step(const ure_job *job, int64_t tick, hipStream_t st)
 {
-    dim3 grid(job->max_blocks, (unsigned)job->host.size());
+    // grid.x = the largest need of any shard AT THIS TICK (row workgroups + the tag riders its
+    // current step carries); finished shards need nothing
+    int blocks = 1;
+    for (size_t k = 0; k < job->host.size(); ++k) {
+        const ure_shard_t &S = job->host[k];
+        const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
+        if (tick >= steps * S.epochs) continue;
+        const int64_t epoch = tick / steps;
+        blocks = std::max(blocks, job->row_blocks[k] + tag_rider_blocks(S.N, S.n_slots, (int)steps, (int)(tick - epoch * steps), epoch + 1 < S.epochs));
+    }
+    dim3 grid((unsigned)blocks, (unsigned)job->host.size());
     hipLaunchKernelGGL(mf_step_kernel<LPR>, grid, dim3(kBlock), 0, st, job->dev, tick);
 }
 
@@ -420,8 +432,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         const int per_block = per_wave * kWavesPerBlock;
         const int blocks = S.n_block + (S.n_wave - S.n_block + kWavesPerBlock - 1) / kWavesPerBlock +
                            (S.n_active - S.n_wave + per_block - 1) / per_block + (S.lazy_rows ? 0 : (n_rows - S.n_active + per_block - 1) / per_block);
-        const int riders = (steps >= 3 && tag_partitioned(S.N)) ? std::max(tag_ranges(S.N), tag_derive_blocks(S.n_slots)) : 0;
-        job->max_blocks = std::max(job->max_blocks, blocks + riders);
+        job->row_blocks.push_back(blocks);
         job->max_n = std::max(job->max_n, S.N);
         job->max_slots = std::max(job->max_slots, S.n_slots);
         const bool small = tag_partitioned(S.N);
