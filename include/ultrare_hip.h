@@ -131,6 +131,28 @@ int ure_job_train_profiled(ure_job_t *job, int64_t tick0, int64_t tick1, void *s
 int ure_host_randperm(const int64_t *seeds, int n_perms, int64_t n, int32_t *out, int n_threads);
 
 /* ---------------------------------------------------------------------------
+ * Host-side ingest (HOST memory throughout; linear time, `n_threads` = 0 means all cores)
+ * ------------------------------------------------------------------------- */
+/* read.py:37 pd.read_csv(dir, header=None, sep=','): rows `uid,iid,rating[,...]`.  The three
+ * arrays are malloc'ed by the library; release each with ure_host_free(). */
+int ure_host_read_csv(const char *path, int32_t **uid, int32_t **iid, double **rating, int64_t *n_rows, int n_threads);
+void ure_host_free(void *p);
+/* read.py:52-70: shard s receives, in file order, the rows whose user u has
+ * shard_of_user[u] == s (-1: deleted user, dropped); rating / max_rating as float32.
+ * counts [n_shards] is always filled; with out_uid == NULL nothing else is written (size query),
+ * otherwise the shards are written back to back (shard s starts at sum(counts[:s])). */
+int ure_host_partition(const int32_t *uid, const int32_t *iid, const double *rating, int64_t n, const int32_t *shard_of_user,
+                       int32_t n_user, int32_t n_shards, double max_rating, int64_t *counts, int32_t *out_uid,
+                       int32_t *out_iid, float *out_rating);
+/* Builds the slot layout of struct ure_shard from a shard's triples: ent_oid / ent_r / ent_src
+ * (capacity 2 n + 8 (n_user + n_item) slots, *n_slots receives the used count), sched
+ * [n_user + n_item][4], the schedule prefixes, and optionally u_pos / i_pos [n] (slot of each
+ * interaction in its user's / item's segment). */
+int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *rating, int64_t n, int32_t n_user, int32_t n_item,
+                          int32_t block_nnz, int32_t group_nnz, int32_t *ent_oid, float *ent_r, int32_t *ent_src, int32_t *sched,
+                          int64_t *n_slots, int32_t *n_block, int32_t *n_wave, int32_t *n_active, int32_t *u_pos, int32_t *i_pos);
+
+/* ---------------------------------------------------------------------------
  * Evaluation (baseTest, utils.py:115-187)
  * ------------------------------------------------------------------------- */
 /* utils.py:140-145: pred[j] = (sum_m U_m[uid[j]] . V_m[iid[j]]) / n_models_total.

@@ -158,7 +158,7 @@ def test_shard_layout_invariants():
     segment and once in its item's, segments are 8-aligned, padded slots never match."""
     from ultrare_amd.engine import ShardData
     tr = O.partition(*O.load_csv(TRAIN), [list(range(N_USER))])[0]
-    sh = ShardData(*tr, N_USER, N_ITEM, device=torch.device('cpu'), block_nnz=200, group_nnz=40)
+    sh = ShardData(*tr, N_USER, N_ITEM, device=torch.device('cpu'), block_nnz=200, group_nnz=40, keep_positions=True)
     sched = sh.sched.numpy()
     n = len(tr[0])
     assert sorted(sched[:, 0].tolist()) == list(range(N_USER + N_ITEM))
@@ -183,6 +183,61 @@ def test_shard_layout_invariants():
     assert (sh.ent_tag.numpy() == -1).all()                                    # 0xFFFF everywhere before training
     with pytest.raises(ValueError):
         ShardData(tr[0], tr[1] + N_ITEM, tr[2], N_USER, N_ITEM, device=torch.device('cpu'))
+
+
+def test_native_ingest_matches_numpy(tmp_path):
+    """ure_host_read_csv / ure_host_partition / ure_host_build_layout against numpy."""
+    from ultrare_amd import _native as nv
+    u, i, r = nv.read_csv(TRAIN, threads=3)
+    ou, oi, orr = O.load_csv(TRAIN)
+    assert np.array_equal(u, ou) and np.array_equal(i, oi) and np.array_equal(r, orr)
+    odd = tmp_path / 'odd.csv'                                    # exponents, blanks, extra column, CRLF, no final newline
+    odd.write_text('1,2,3.5\r\n\n3,4,1e-1,999\n 5,6,4\n7,8,0.30000000000000004')
+    u2, i2, r2 = nv.read_csv(str(odd))
+    assert u2.tolist() == [1, 3, 5, 7] and i2.tolist() == [2, 4, 6, 8] and r2.tolist() == [3.5, 0.1, 4.0, 0.30000000000000004]
+    bad = tmp_path / 'bad.csv'
+    bad.write_text('1,2\n')
+    with pytest.raises(nv.NativeError):
+        nv.read_csv(str(bad))
+    # partition: same shards as the oracle's np.isin partition, deleted users dropped
+    import ctypes
+    idx = O.uniform_groups(N_USER, 4)
+    dels = [3, 77, 500]
+    shard_of = np.full(N_USER, -1, dtype=np.int32)
+    for s_, g_ in enumerate(idx):
+        shard_of[np.asarray(g_)] = s_
+    shard_of[dels] = -1
+    counts = np.zeros(4, dtype=np.int64)
+    L = nv.lib()
+    nv.check(L.ure_host_partition(u.ctypes.data, i.ctypes.data, r.ctypes.data, len(u), shard_of.ctypes.data, N_USER, 4, 5.0,
+                                  counts.ctypes.data, None, None, None), 'count')
+    ouid, oiid, orat = (np.empty(counts.sum(), np.int32), np.empty(counts.sum(), np.int32), np.empty(counts.sum(), np.float32))
+    nv.check(L.ure_host_partition(u.ctypes.data, i.ctypes.data, r.ctypes.data, len(u), shard_of.ctypes.data, N_USER, 4, 5.0,
+                                  counts.ctypes.data, ouid.ctypes.data, oiid.ctypes.data, orat.ctypes.data), 'partition')
+    want = O.partition(ou, oi, orr, idx, dels)
+    o = 0
+    for s_ in range(4):
+        c = int(counts[s_])
+        assert c == len(want[s_][0])
+        assert np.array_equal(ouid[o:o + c], want[s_][0]) and np.array_equal(oiid[o:o + c], want[s_][1])
+        assert np.array_equal(orat[o:o + c], want[s_][2])
+        o += c
+    # layout: identical to a stable-argsort construction
+    tr = want[0]
+    lay = nv.build_layout(tr[0], tr[1], tr[2], N_USER, N_ITEM, 200, 40, want_pos=True)
+    nnz = np.concatenate([np.bincount(tr[0], minlength=N_USER), np.bincount(tr[1], minlength=N_ITEM)])
+    order = np.argsort(-nnz, kind='stable')
+    assert np.array_equal(lay['sched'][:, 0], order) and np.array_equal(lay['sched'][:, 3], nnz[order])
+    for keys, pos, base in ((tr[0], lay['u_pos'], 0), (tr[1], lay['i_pos'], N_USER)):
+        beg = np.empty(N_USER + N_ITEM, dtype=np.int64)
+        beg[lay['sched'][:, 0]] = lay['sched'][:, 1]
+        srt = np.argsort(keys, kind='stable')
+        first = np.searchsorted(keys[srt], keys[srt], side='left')
+        want_pos = np.empty(len(keys), dtype=np.int64)
+        want_pos[srt] = beg[base + keys[srt]] + (np.arange(len(keys)) - first)
+        assert np.array_equal(pos, want_pos)
+    with pytest.raises(nv.NativeError):
+        nv.build_layout(tr[0], tr[1] + N_ITEM, tr[2], N_USER, N_ITEM, 200, 40)
 
 
 def test_shard_placement_is_lpt():

@@ -51,6 +51,12 @@ _PROTOTYPES = {
     'ure_job_train_profiled': (ctypes.c_int, [_vp, _i64, _i64, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
                                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64)]),
     'ure_host_randperm': (ctypes.c_int, [_vp, ctypes.c_int, _i64, _vp, ctypes.c_int]),
+    'ure_host_read_csv': (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                         ctypes.POINTER(_i64), ctypes.c_int]),
+    'ure_host_free': (None, [_vp]),
+    'ure_host_partition': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, ctypes.c_double, _vp, _vp, _vp, _vp]),
+    'ure_host_build_layout': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
+                                             ctypes.POINTER(_i64), ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(_i32), _vp, _vp]),
     'ure_score': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_int, _vp, _vp, _vp, _i64, ctypes.c_int, _vp, _vp, _vp]),
     'ure_eval_users': (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -121,3 +127,41 @@ def ot_assign(dist_kn):
     check(lib().ure_ot_assign(dist_kn.ctypes.data, n, k, label.ctypes.data, plan.ctypes.data, ctypes.byref(obj)),
           'ure_ot_assign')
     return label, plan, obj.value
+
+
+def read_csv(path, threads=0):
+    """ure_host_read_csv -> (uid int32, iid int32, rating float64) numpy arrays."""
+    pu, pi, pr, n = _vp(), _vp(), _vp(), _i64()
+    check(lib().ure_host_read_csv(os.fsencode(path), ctypes.byref(pu), ctypes.byref(pi), ctypes.byref(pr), ctypes.byref(n), threads),
+          'ure_host_read_csv')
+    try:
+        m = n.value
+        u = np.ctypeslib.as_array(ctypes.cast(pu, ctypes.POINTER(ctypes.c_int32)), (max(m, 1),))[:m].copy()
+        i = np.ctypeslib.as_array(ctypes.cast(pi, ctypes.POINTER(ctypes.c_int32)), (max(m, 1),))[:m].copy()
+        r = np.ctypeslib.as_array(ctypes.cast(pr, ctypes.POINTER(ctypes.c_double)), (max(m, 1),))[:m].copy()
+    finally:
+        for p in (pu, pi, pr):
+            if p:
+                lib().ure_host_free(p)
+    return u, i, r
+
+
+def build_layout(uid, iid, rating, n_user, n_item, block_nnz, group_nnz, want_pos=False):
+    """ure_host_build_layout on numpy triples -> dict of numpy arrays + counts."""
+    n = len(uid)
+    cap = 2 * n + 8 * (n_user + n_item) + 8
+    ent_oid = np.empty(cap, dtype=np.int32)
+    ent_r = np.empty(cap, dtype=np.float32)
+    ent_src = np.empty(cap, dtype=np.int32)
+    sched = np.empty((n_user + n_item, 4), dtype=np.int32)
+    u_pos = np.empty(n, dtype=np.int32) if want_pos else None
+    i_pos = np.empty(n, dtype=np.int32) if want_pos else None
+    ns, nb, nw, na = _i64(), _i32(), _i32(), _i32()
+    check(lib().ure_host_build_layout(uid.ctypes.data, iid.ctypes.data, rating.ctypes.data, n, n_user, n_item, block_nnz, group_nnz,
+                                      ent_oid.ctypes.data, ent_r.ctypes.data, ent_src.ctypes.data, sched.ctypes.data,
+                                      ctypes.byref(ns), ctypes.byref(nb), ctypes.byref(nw), ctypes.byref(na),
+                                      u_pos.ctypes.data if want_pos else None, i_pos.ctypes.data if want_pos else None),
+          'ure_host_build_layout')
+    k = ns.value
+    return {'ent_oid': ent_oid[:k], 'ent_r': ent_r[:k], 'ent_src': ent_src[:k], 'sched': sched, 'n_slots': k,
+            'n_block': nb.value, 'n_wave': nw.value, 'n_active': na.value, 'u_pos': u_pos, 'i_pos': i_pos}

@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libultrare_hip.so')
-SOURCES = ['ure_common.hip', 'mf_train.hip', 'tag_prep.hip', 'mf_eval.hip', 'ot.hip', 'ot_solver.cpp', 'host_rng.cpp']
+SOURCES = ['ure_common.hip', 'mf_train.hip', 'tag_prep.hip', 'mf_eval.hip', 'ot.hip', 'ot_solver.cpp', 'host_rng.cpp', 'host_layout.cpp']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-munsafe-fp-atomics',
          '-ffp-contract=off', '-Wall', '-Wno-unused-result', '-pthread']
 

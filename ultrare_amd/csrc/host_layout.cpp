@@ -1,0 +1,238 @@
+// host_layout.cpp -- host-side ingest of the SISA path: CSV -> triples -> per-shard HBM layout.
+//
+//   ure_host_read_csv      read.py:37   pd.read_csv(dir, header=None): `uid,iid,rating` rows
+//   ure_host_partition     read.py:52-70 shard s = rows (file order) whose user is in group s and
+//                                        not deleted; rating / max_rating
+//   ure_host_build_layout  (no reference counterpart) the slot arrays, schedule and positions the
+//                          step kernel walks (include/ultrare_hip.h, struct ure_shard), built with
+//                          linear counting sorts instead of numpy argsorts
+//
+// The reference spends its time here in pandas / np.in1d / per-sample Dataset objects; with
+// training at tens of milliseconds this host work IS the end-to-end cost of an unlearning request
+// (new deletion set -> new shards -> new layouts), so it is native and linear.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+#include "ultrare_hip.h"
+
+namespace ure {
+int fail(int code, const char *fmt, ...);
+}
+
+namespace {
+
+// strtod-free number parsing for the plain decimals of rating files ("123", "3.5", "4.0");
+// anything else (exponents, inf, nan, hex) falls back to strtod for that field.
+inline const char *parse_field(const char *p, const char *end, double *out, bool *ok)
+{
+    const char *s = p;
+    bool neg = false;
+    if (p < end && (*p == '-' || *p == '+')) { neg = *p == '-'; ++p; }
+    uint64_t ip = 0;
+    int nd = 0;
+    while (p < end && *p >= '0' && *p <= '9') { ip = ip * 10 + (uint64_t)(*p - '0'); ++p; ++nd; }
+    double v = (double)ip;
+    if (p < end && *p == '.') {
+        ++p;
+        uint64_t fp = 0;
+        int fd = 0;
+        while (p < end && *p >= '0' && *p <= '9') { if (fd < 18) { fp = fp * 10 + (uint64_t)(*p - '0'); ++fd; } ++p; ++nd; }
+        static const double pw[19] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18};
+        // exact for the <= 15 significant digits of rating files: one correctly rounded division
+        if (nd <= 15) v = (double)(ip * (uint64_t)pw[fd] + fp) / pw[fd];
+        else v = (double)ip + (double)fp / pw[fd];
+    }
+    const bool plain = nd > 0 && nd <= 15 && (p == end || *p == ',' || *p == '\n' || *p == '\r' || *p == ' ');
+    if (!plain) {   // exponent or something unusual: let strtod decide
+        char buf[64];
+        size_t len = 0;
+        const char *q = s;
+        while (q < end && *q != ',' && *q != '\n' && *q != '\r' && len < sizeof(buf) - 1) buf[len++] = *q++;
+        buf[len] = 0;
+        char *e = nullptr;
+        v = std::strtod(buf, &e);
+        if (e == buf) *ok = false;
+        *out = v;
+        return q;
+    }
+    *out = neg ? -v : v;
+    return p;
+}
+
+struct Chunk {
+    std::vector<int32_t> u, i;
+    std::vector<double> r;
+    bool ok = true;
+};
+
+}  // namespace
+
+extern "C" {
+
+int ure_host_read_csv(const char *path, int32_t **uid, int32_t **iid, double **rating, int64_t *n_rows, int n_threads)
+{
+    if (!path || !uid || !iid || !rating || !n_rows) return ure::fail(-1, "ure_host_read_csv: bad arguments");
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return ure::fail(-1, "ure_host_read_csv: cannot open %s", path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); return ure::fail(-1, "ure_host_read_csv: cannot stat %s", path); }
+    const size_t size = (size_t)sb.st_size;
+    *uid = *iid = nullptr; *rating = nullptr; *n_rows = 0;
+    if (size == 0) { close(fd); return 0; }
+    const char *data = (const char *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (data == MAP_FAILED) return ure::fail(-1, "ure_host_read_csv: mmap failed for %s", path);
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    nt = std::max(1, std::min<int>(nt, (int)(size / (1 << 16)) + 1));
+    std::vector<size_t> cut(nt + 1, size);
+    cut[0] = 0;
+    for (int t = 1; t < nt; ++t) {
+        size_t p = size / nt * t;
+        while (p < size && data[p - 1] != '\n') ++p;
+        cut[t] = p;
+    }
+    std::vector<Chunk> chunks(nt);
+    auto work = [&](int t) {
+        Chunk &c = chunks[t];
+        const char *p = data + cut[t], *end = data + cut[t + 1];
+        const size_t guess = (cut[t + 1] - cut[t]) / 8 + 16;
+        c.u.reserve(guess); c.i.reserve(guess); c.r.reserve(guess);
+        while (p < end) {
+            while (p < end && (*p == '\n' || *p == '\r' || *p == ' ')) ++p;
+            if (p >= end) break;
+            double a, b, r;
+            p = parse_field(p, end, &a, &c.ok);
+            if (p >= end || *p != ',') { c.ok = false; break; }
+            p = parse_field(p + 1, end, &b, &c.ok);
+            if (p >= end || *p != ',') { c.ok = false; break; }
+            p = parse_field(p + 1, end, &r, &c.ok);
+            while (p < end && *p != '\n') ++p;          // further columns (timestamps) are ignored
+            c.u.push_back((int32_t)a); c.i.push_back((int32_t)b); c.r.push_back(r);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    munmap((void *)data, size);
+    int64_t total = 0;
+    for (auto &c : chunks) { if (!c.ok) return ure::fail(-1, "ure_host_read_csv: malformed row in %s", path); total += (int64_t)c.u.size(); }
+    *uid = (int32_t *)std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1));
+    *iid = (int32_t *)std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(total, 1));
+    *rating = (double *)std::malloc(sizeof(double) * (size_t)std::max<int64_t>(total, 1));
+    if (!*uid || !*iid || !*rating) return ure::fail(-1, "ure_host_read_csv: out of memory");
+    int64_t o = 0;
+    for (auto &c : chunks) {
+        std::memcpy(*uid + o, c.u.data(), c.u.size() * sizeof(int32_t));
+        std::memcpy(*iid + o, c.i.data(), c.i.size() * sizeof(int32_t));
+        std::memcpy(*rating + o, c.r.data(), c.r.size() * sizeof(double));
+        o += (int64_t)c.u.size();
+    }
+    *n_rows = total;
+    return 0;
+}
+
+void ure_host_free(void *p) { std::free(p); }
+
+int ure_host_partition(const int32_t *uid, const int32_t *iid, const double *rating, int64_t n, const int32_t *shard_of_user,
+                       int32_t n_user, int32_t n_shards, double max_rating, int64_t *counts, int32_t *out_uid, int32_t *out_iid,
+                       float *out_rating)
+{
+    if (!uid || !iid || !rating || !shard_of_user || !counts || n < 0 || n_user <= 0 || n_shards <= 0)
+        return ure::fail(-1, "ure_host_partition: bad arguments");
+    std::fill(counts, counts + n_shards, (int64_t)0);
+    for (int64_t j = 0; j < n; ++j) {
+        const int32_t u = uid[j];
+        if (u < 0 || u >= n_user) return ure::fail(-1, "ure_host_partition: user id %d outside [0, %d)", u, n_user);
+        const int32_t s = shard_of_user[u];
+        if (s >= n_shards) return ure::fail(-1, "ure_host_partition: shard %d outside [0, %d)", s, n_shards);
+        if (s >= 0) ++counts[s];
+    }
+    if (!out_uid) return 0;                       // counting pass only
+    std::vector<int64_t> cur(n_shards, 0);
+    for (int s = 1; s < n_shards; ++s) cur[s] = cur[s - 1] + counts[s - 1];
+    for (int64_t j = 0; j < n; ++j) {
+        const int32_t s = shard_of_user[uid[j]];
+        if (s < 0) continue;                      // deleted user / user of no group
+        const int64_t o = cur[s]++;
+        out_uid[o] = uid[j];
+        out_iid[o] = iid[j];
+        out_rating[o] = (float)(rating[j] / max_rating);      // read.py:66 then read.py:113,124 (float64 division, one cast)
+    }
+    return 0;
+}
+
+int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *rating, int64_t n, int32_t n_user, int32_t n_item,
+                          int32_t block_nnz, int32_t group_nnz, int32_t *ent_oid, float *ent_r, int32_t *ent_src, int32_t *sched,
+                          int64_t *n_slots, int32_t *n_block, int32_t *n_wave, int32_t *n_active, int32_t *u_pos, int32_t *i_pos)
+{
+    if (!uid || !iid || !rating || !ent_oid || !ent_r || !ent_src || !sched || !n_slots || !n_block || !n_wave || !n_active ||
+        n <= 0 || n_user <= 0 || n_item <= 0)
+        return ure::fail(-1, "ure_host_build_layout: bad arguments");
+    const int64_t n_rows = (int64_t)n_user + n_item;
+    std::vector<int64_t> nnz(n_rows, 0);
+    for (int64_t j = 0; j < n; ++j) {
+        if (uid[j] < 0 || uid[j] >= n_user || iid[j] < 0 || iid[j] >= n_item)
+            return ure::fail(-1, "ure_host_build_layout: interaction %lld has an id outside [0,%d) x [0,%d)", (long long)j, n_user, n_item);
+        ++nnz[uid[j]];
+        ++nnz[n_user + iid[j]];
+    }
+    // schedule: rows by nnz descending, ties by row id (= a stable sort on -nnz): counting sort on nnz
+    int64_t max_nnz = 0;
+    for (int64_t r = 0; r < n_rows; ++r) max_nnz = std::max(max_nnz, nnz[r]);
+    std::vector<int64_t> first(max_nnz + 2, 0);
+    for (int64_t r = 0; r < n_rows; ++r) ++first[max_nnz - nnz[r] + 1];
+    for (int64_t v = 1; v <= max_nnz + 1; ++v) first[v] += first[v - 1];
+    std::vector<int32_t> order(n_rows);
+    for (int64_t r = 0; r < n_rows; ++r) order[first[max_nnz - nnz[r]]++] = (int32_t)r;
+    std::vector<int64_t> row_beg(n_rows);
+    int64_t slots = 0;
+    int32_t nb = 0, nw = 0, na = 0;
+    const int64_t b_thr = std::max(block_nnz, group_nnz);
+    for (int64_t q = 0; q < n_rows; ++q) {
+        const int32_t r = order[q];
+        const int64_t padded = (nnz[r] + 7) / 8 * 8;
+        row_beg[r] = slots;
+        sched[4 * q + 0] = r;
+        sched[4 * q + 1] = (int32_t)slots;
+        sched[4 * q + 2] = (int32_t)(slots + padded);
+        sched[4 * q + 3] = (int32_t)nnz[r];
+        slots += padded;
+        nb += nnz[r] > b_thr;
+        nw += nnz[r] > group_nnz;
+        na += nnz[r] > 0;
+    }
+    slots = std::max<int64_t>(slots, 8);
+    if (slots >= ((int64_t)1 << 31)) return ure::fail(-1, "ure_host_build_layout: shard too large for 32-bit slot indices");
+    *n_slots = slots;
+    *n_block = std::min(nb, nw);
+    *n_wave = nw;
+    *n_active = na;
+    std::memset(ent_oid, 0, sizeof(int32_t) * (size_t)slots);
+    std::memset(ent_r, 0, sizeof(float) * (size_t)slots);
+    std::fill(ent_src, ent_src + slots, (int32_t)-1);
+    // file order inside every segment: one cursor per row
+    std::vector<int64_t> cur(row_beg);
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t pu = cur[uid[j]]++, pi = cur[n_user + iid[j]]++;
+        ent_oid[pu] = iid[j]; ent_r[pu] = rating[j]; ent_src[pu] = (int32_t)j;
+        ent_oid[pi] = uid[j]; ent_r[pi] = rating[j]; ent_src[pi] = (int32_t)j;
+        if (u_pos) u_pos[j] = (int32_t)pu;
+        if (i_pos) i_pos[j] = (int32_t)pi;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -45,24 +45,12 @@ def _device():
     return torch.device('cuda', torch.cuda.current_device())
 
 
-def _segment_slots(keys, row_beg):
-    """Slot of every file-order entry inside its row's segment (stable in file order)."""
-    order = np.argsort(keys, kind='stable')
-    counts = np.bincount(keys, minlength=len(row_beg))
-    first = np.zeros(len(row_beg), dtype=np.int64)
-    np.cumsum(counts[:-1], out=first[1:])
-    sk = keys[order]
-    pos = np.empty(len(keys), dtype=np.int64)
-    pos[order] = row_beg[sk] + (np.arange(len(keys), dtype=np.int64) - first[sk])
-    return pos
-
-
 class ShardData:
     """One shard's interactions laid out for the step kernel: every destination row
     (users, then items) owns an 8-aligned, padded segment of one slot array; segments
     follow the row schedule (heaviest first)."""
 
-    def __init__(self, uid, iid, rating, n_user, n_item, device=None, block_nnz=None, group_nnz=None):
+    def __init__(self, uid, iid, rating, n_user, n_item, device=None, block_nnz=None, group_nnz=None, keep_positions=False):
         uid = np.ascontiguousarray(uid, dtype=np.int32)
         iid = np.ascontiguousarray(iid, dtype=np.int32)
         rating = np.ascontiguousarray(rating, dtype=np.float32)
@@ -75,31 +63,14 @@ class ShardData:
             raise ValueError('user or item id outside [0, n_user) x [0, n_item)')
         self.N, self.n_user, self.n_item = n, int(n_user), int(n_item)
         self.device = device or _device()
-        nnz = np.concatenate([np.bincount(uid, minlength=n_user), np.bincount(iid, minlength=n_item)]).astype(np.int64)
-        order = np.argsort(-nnz, kind='stable')
-        padded = (nnz + 7) // 8 * 8
-        beg_sched = np.zeros(len(order), dtype=np.int64)
-        np.cumsum(padded[order][:-1], out=beg_sched[1:])
-        row_beg = np.empty_like(beg_sched)
-        row_beg[order] = beg_sched
-        self.n_slots = int(max(padded.sum(), 8))
-        if self.n_slots >= 2 ** 31:
-            raise ValueError('shard too large for 32-bit slot indices')
-        u_pos = _segment_slots(uid.astype(np.int64), row_beg[:n_user])
-        i_pos = _segment_slots(iid.astype(np.int64), row_beg[n_user:])
-        ent_oid = np.zeros(self.n_slots, dtype=np.int32)
-        ent_r = np.zeros(self.n_slots, dtype=np.float32)
-        ent_oid[u_pos], ent_r[u_pos] = iid, rating
-        ent_oid[i_pos], ent_r[i_pos] = uid, rating
-        ent_src = np.full(self.n_slots, -1, dtype=np.int32)
-        ent_src[u_pos] = ent_src[i_pos] = np.arange(n, dtype=np.int32)
-        sched = np.stack([order, row_beg[order], row_beg[order] + padded[order], nnz[order]], axis=1).astype(np.int32)
         b_thr = BLOCK_NNZ if block_nnz is None else block_nnz
         g_thr = GROUP_NNZ if group_nnz is None else group_nnz
-        self.n_active = int((nnz > 0).sum())
-        self.n_wave = int((nnz > g_thr).sum())
-        self.n_block = min(int((nnz > max(b_thr, g_thr)).sum()), self.n_wave)
-        self.max_row = int(nnz.max())
+        lay = nv.build_layout(uid, iid, rating, n_user, n_item, min(b_thr, 2 ** 31 - 1), min(g_thr, 2 ** 31 - 1),
+                              want_pos=keep_positions)
+        ent_oid, ent_r, ent_src, sched = lay['ent_oid'], lay['ent_r'], lay['ent_src'], lay['sched']
+        u_pos, i_pos = lay['u_pos'], lay['i_pos']
+        self.n_slots, self.n_block, self.n_wave, self.n_active = lay['n_slots'], lay['n_block'], lay['n_wave'], lay['n_active']
+        self.max_row = int(sched[0, 3])
         dev = self.device
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.ent_oid, self.ent_r = to(ent_oid), to(ent_r)

@@ -17,12 +17,11 @@ import torch
 
 
 def _read_csv(path):
-    """`uid,iid,rating` rows, no header -> float64 [n, 3]."""
-    try:
-        import pandas as pd
-        return pd.read_csv(path, header=None, sep=',').values.astype(np.float64)
-    except ImportError:
-        return np.loadtxt(path, delimiter=',', dtype=np.float64, ndmin=2)
+    """`uid,iid,rating` rows, no header (read.py:37) -> (uid int64, iid int64, rating float64),
+    parsed by the library's threaded reader (ure_host_read_csv)."""
+    from . import _native as nv
+    u, i, r = nv.read_csv(path)
+    return u.astype(np.int64), i.astype(np.int64), r
 
 
 def sort_group(order='a', group_index=(), var='count', ratings0=(), dataset=''):
@@ -53,8 +52,7 @@ def readRating(dir, n_user, max_rating=5, del_user=[], del_rating=[], n_group=1,
             group_index = [org_index[i * group_len:(i + 1) * group_len] for i in range(n_group)]
     group_index = list(group_index)
 
-    ratings = _read_csv(dir)
-    uid = ratings[:, 0].astype(np.int64)
+    uid, iid, raw = _read_csv(dir)
 
     if sort in ['d', 'a']:
         sorted_index = sort_group(order='a', group_index=group_index, var='count', ratings0=uid)   # read.py:45: always ascending
@@ -67,16 +65,14 @@ def readRating(dir, n_user, max_rating=5, del_user=[], del_rating=[], n_group=1,
     # path; rows listed there are dropped as well for completeness
     drop = np.zeros(len(uid), dtype=bool)
     for pair in np.asarray(del_rating).reshape(-1, 2) if len(del_rating) else ():
-        drop |= (uid == int(pair[0])) & (ratings[:, 1].astype(np.int64) == int(pair[1]))
+        drop |= (uid == int(pair[0])) & (iid == int(pair[1]))
 
     rating_lists = []
     for i in range(n_group):
         member = np.zeros(len(deleted), dtype=bool)
         member[np.asarray(group_index[i], dtype=np.int64)] = True
         loc = member[uid] & ~deleted[uid] & ~drop
-        ratings_group = ratings[loc].T.copy()
-        ratings_group[2] /= max_rating
-        rating_lists.append(ratings_group)
+        rating_lists.append(np.vstack([uid[loc].astype(np.float64), iid[loc].astype(np.float64), raw[loc] / max_rating]))
     return rating_lists, group_index
 
 
@@ -158,8 +154,6 @@ def loadData(data, batch=30000, n_worker=24, shuffle=True):
 def readSparseMat(dir, n_user, n_item, max_rating=5):
     """read.py:136-145 (float16 CSR of ratings; consumed only by 'rating-ot')."""
     from scipy.sparse import coo_matrix
-    ratings = _read_csv(dir)
-    row = ratings[:, 0].astype(int)
-    col = ratings[:, 1].astype(int)
-    val = ratings[:, 2].astype(float) / max_rating
+    row, col, raw = _read_csv(dir)
+    val = raw / max_rating
     return coo_matrix((val, (row, col)), shape=(n_user, n_item), dtype=np.float16).tocsr()
