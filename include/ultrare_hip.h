@@ -84,6 +84,13 @@ typedef struct ure_shard {
     const float *V0;        /* [n_item][d]                                          */
     const float *lr_host;   /* [epochs] HOST copy of lr (read by ure_job_create only) */
     int32_t lazy_rows;
+    /* Optional end-of-epoch snapshots (NULL = none): after the last step of epoch e the shard's
+     * complete tables are copied to snapU[e] / snapV[e]; snap_a[e] = the closed-form weight scalar
+     * of the lazy rows after epoch e (required with lazy_rows).  Lets a caller rebuild the
+     * reference's per-epoch test logs (scratch.py:83-97) after training shards side by side. */
+    float       *snapU;     /* [epochs][n_user][d]                                   */
+    float       *snapV;     /* [epochs][n_item][d]                                   */
+    const float *snap_a;    /* [epochs] device                                       */
     /* per-epoch inputs / outputs */
     const int32_t *perm;    /* [epochs][N] the epoch permutations (RandomSampler)   */
     const float   *lr;      /* [epochs] learning rate of each epoch (StepLR)        */
@@ -173,6 +180,12 @@ int ure_score(const float *const *U_tables, const float *const *V_tables, int n_
  * computed by the host with numpy so that the division matches bit for bit. */
 int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const float *rating,
                    const double *log2_tab, int32_t *hits, double *ndcg, void *stream);
+
+/* utils.py:163,183-184: out3 (device, 3 doubles) = { sqrt(*sse / n_rows), mean(ndcg), mean(hits / 10) }
+ * from the outputs of ure_score / ure_eval_users, reduced on the device in a fixed order: lets a
+ * caller queue many evaluations without synchronising and read all results at the end. */
+int ure_eval_reduce(const int32_t *hits, const double *ndcg, int32_t n_users, const double *sse, int64_t n_rows, double *out3,
+                    void *stream);
 
 /* sisa.py:55-56,110-111: dst[rows[t]][:] = src[rows[t]][:]. */
 int ure_merge_rows(float *dst, const float *src, const int64_t *rows, int64_t n_rows, int d, void *stream);

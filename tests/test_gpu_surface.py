@@ -93,10 +93,11 @@ def test_sisa_learn_unlearn_matches_reference(S, E, parallel, tmp_path):
     assert rel(ml[0].user_mat.weight, g[f'{tag}_learn_Umerged']) < RTOL
     log0 = np.load(tmp_path / 'log0.npy', allow_pickle=True).item()
     np.testing.assert_allclose([log0['total_rmse'], log0['total_ndcg'], log0['total_hr']], g[f'{tag}_learn_log0'], rtol=RTOL)
-    np.testing.assert_allclose(sisa.log['train_loss'], g[f'{tag}_learn_log_train_loss'], rtol=RTOL)
-    if not parallel:    # the in-loop tests exist only in the sequential order (scratch.py:83-97)
-        for key in ('test_rmse', 'test_ndcg', 'test_hr', 'total_rmse', 'total_ndcg', 'total_hr'):
-            np.testing.assert_allclose(sisa.log[key], g[f'{tag}_learn_log_{key}'], rtol=RTOL, err_msg=key)
+    # per-epoch series (scratch.py:83-128): in-loop in the sequential mode, rebuilt from snapshots
+    # in the parallel mode
+    for key in ('train_loss', 'test_rmse', 'test_ndcg', 'test_hr', 'total_rmse', 'total_ndcg', 'total_hr'):
+        np.testing.assert_allclose(sisa.log[key], g[f'{tag}_learn_log_{key}'], rtol=RTOL, err_msg=key)
+    assert len(np.load(tmp_path / f'log{S}.npy', allow_pickle=True).item()['total_hr']) == S * E      # D8
 
     for name in ('A', 'B'):
         t = f'{tag}_un{name}'
@@ -114,8 +115,8 @@ def test_sisa_learn_unlearn_matches_reference(S, E, parallel, tmp_path):
             assert rel(ml2[i].item_mat.weight, g[f'{t}_V{i}']) < RTOL
         l0 = np.load(out / 'log0.npy', allow_pickle=True).item()
         np.testing.assert_allclose([l0['total_rmse'], l0['total_ndcg'], l0['total_hr']], g[t + '_log0'], rtol=RTOL)
-        if not parallel:
-            np.testing.assert_allclose(s2.log['total_rmse'], g[t + '_log_total_rmse'], rtol=RTOL)
+        for key in ('train_loss', 'test_rmse', 'total_rmse', 'total_ndcg', 'total_hr'):
+            np.testing.assert_allclose(s2.log[key], g[f'{t}_log_{key}'], rtol=RTOL, err_msg=key)
 
 
 def test_parallel_equals_sequential_bitwise(tmp_path):

@@ -26,6 +26,7 @@ class UreShard(ctypes.Structure):
         ('sched', _vp), ('n_block', _i32), ('n_wave', _i32), ('n_active', _i32), ('n_slots', _i64),
         ('U', _vp * 2), ('V', _vp * 2), ('mU', _vp), ('mV', _vp),
         ('U0', _vp), ('V0', _vp), ('lr_host', _vp), ('lazy_rows', _i32),
+        ('snapU', _vp), ('snapV', _vp), ('snap_a', _vp),
         ('perm', _vp), ('lr', _vp), ('sse', _vp),
         ('N', _i32), ('n_user', _i32), ('n_item', _i32), ('d', _i32),
         ('batch', _i32), ('epochs', _i32),
@@ -60,6 +61,7 @@ _PROTOTYPES = {
     'ure_score': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_int, _vp, _vp, _vp, _i64, ctypes.c_int, _vp, _vp, _vp]),
     'ure_eval_users': (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'ure_eval_reduce': (ctypes.c_int, [_vp, _vp, _i32, _vp, _i64, _vp, _vp]),
     'ure_merge_rows': (ctypes.c_int, [_vp, _vp, _vp, _i64, ctypes.c_int, _vp]),
     'ure_ot_cost': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'ure_ot_centroids': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),

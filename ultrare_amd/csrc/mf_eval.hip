@@ -147,6 +147,38 @@ __global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__res
     ndcg[user] = dcg / idcg;
 }
 
+// utils.py:163-184 tail: rmse = sqrt(sse / n_rows), ndcg = mean(ndcg), hr = mean(hits / 10), reduced on
+// the device by ONE workgroup in a fixed order (reproducible) so that a caller can queue many
+// evaluations and read all results once.
+__global__ __launch_bounds__(1024) void eval_reduce_kernel(const int32_t *__restrict__ hits, const double *__restrict__ ndcg,
+                                                           int32_t n_users, const double *__restrict__ sse, int64_t n_rows,
+                                                           double *__restrict__ out3)
+{
+    __shared__ double sn[1024];
+    __shared__ long long sh[1024];
+    double an = 0.0;
+    long long ah = 0;
+    for (int t = threadIdx.x; t < n_users; t += 1024) {
+        an += ndcg[t];
+        ah += hits[t];
+    }
+    sn[threadIdx.x] = an;
+    sh[threadIdx.x] = ah;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sn[threadIdx.x] += sn[threadIdx.x + o];
+            sh[threadIdx.x] += sh[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out3[0] = sqrt(*sse / (double)n_rows);
+        out3[1] = n_users > 0 ? sn[0] / (double)n_users : 0.0;
+        out3[2] = n_users > 0 ? ((double)sh[0] / 10.0) / (double)n_users : 0.0;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void merge_rows_kernel(T *__restrict__ dst, const T *__restrict__ src,
                                                             const int64_t *__restrict__ rows, int64_t n_rows, int width)
@@ -212,6 +244,16 @@ int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const
     const unsigned blocks = (unsigned)((n_users + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(eval_users_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), off, n_users, pred,
                        rating, log2_tab, hits, ndcg);
+    URE_HIP(hipGetLastError());
+    return 0;
+}
+
+int ure_eval_reduce(const int32_t *hits, const double *ndcg, int32_t n_users, const double *sse, int64_t n_rows, double *out3,
+                    void *stream)
+{
+    URE_ARG(hits && ndcg && sse && out3 && n_users >= 0 && n_rows > 0);
+    hipLaunchKernelGGL(eval_reduce_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), hits, ndcg, n_users, sse, n_rows,
+                       out3);
     URE_HIP(hipGetLastError());
     return 0;
 }

@@ -359,6 +359,40 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     if (is_user && lane == 0 && sse != 0.f) S.sse[(size_t)epoch * S.n_user + row] += sse;
 }
 
+// End-of-epoch snapshot of a shard's tables into snapU/snapV[epoch] (optional; used to rebuild the
+// reference's per-epoch test logs after shards were trained side by side, scratch.py:83-97).
+// Rows the step kernel skips (lazy_rows) are written in closed form with the epoch's scalar.
+__global__ __launch_bounds__(kBlock) void snapshot_kernel(const ure_shard_t *__restrict__ shards, int64_t ticks_done)
+{
+    const ure_shard_t &S = shards[blockIdx.y];
+    if (!S.snapU || !S.snapV) return;
+    const int steps = shard_steps(S);
+    if (ticks_done > (int64_t)steps * S.epochs || ticks_done % steps != 0) return;   // only at an epoch end of this shard
+    const int epoch = (int)(ticks_done / steps) - 1;
+    const int cur = (int)(ticks_done & 1);
+    const float a = S.lazy_rows ? S.snap_a[epoch] : 0.f;
+    const int d4 = S.d / 4;
+    const int n_rows = S.n_user + S.n_item;
+    const int4 *__restrict__ sched = reinterpret_cast<const int4 *>(S.sched);
+    float *__restrict__ su = S.snapU + (size_t)epoch * S.n_user * S.d;
+    float *__restrict__ sv = S.snapV + (size_t)epoch * S.n_item * S.d;
+    const int64_t total = (int64_t)n_rows * d4;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+        const int idx = (int)(t / d4);
+        const int row_id = sched[idx].x;
+        const bool is_user = row_id < S.n_user;
+        const size_t o = (size_t)(is_user ? row_id : row_id - S.n_user) * S.d + (size_t)(t % d4) * 4;
+        float4 v;
+        if (S.lazy_rows && idx >= S.n_active) {
+            const float4 w0 = *reinterpret_cast<const float4 *>((is_user ? S.U0 : S.V0) + o);
+            v = make_float4(a * w0.x, a * w0.y, a * w0.z, a * w0.w);
+        } else {
+            v = *reinterpret_cast<const float4 *>((is_user ? S.U[cur] : S.V[cur]) + o);
+        }
+        *reinterpret_cast<float4 *>((is_user ? su : sv) + o) = v;
+    }
+}
+
 // Rows without interactions in their shard, advanced in closed form: after T optimizer steps
 // w_T = a_T * w_0 and m_T = b_T * w_0 with scalars (a, b) from the same recurrence the optimizer
 // applies to every element (g = lam*w; m = mu*m + g (m = g first); w -= lr*m), evaluated in
@@ -446,6 +480,11 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         job->lr_host.emplace_back(S.lr_host ? std::vector<float>(S.lr_host, S.lr_host + S.epochs) : std::vector<float>());
         job->host[k].lr_host = nullptr;                       // the caller's array need not outlive this call
         job->max_lazy = std::max<int64_t>(job->max_lazy, S.lazy_rows ? (int64_t)(S.n_user + S.n_item - S.n_active) * (S.d / 4) : 0);
+        if (S.snapU || S.snapV) {
+            if (!(S.snapU && S.snapV) || (S.lazy_rows && !S.snap_a)) { delete job; return fail(-1, "ure_job_create: shard %d has an incomplete snapshot set", k); }
+            job->snapshots = true;
+            job->snap_blocks = std::max<unsigned>(job->snap_blocks, (unsigned)std::min<int64_t>(((int64_t)(S.n_user + S.n_item) * (S.d / 4) + kBlock - 1) / kBlock, 2048));
+        }
     }
     hipError_t e = hipMalloc(&job->dev, sizeof(ure_shard_t) * n_shards);
     if (e == hipSuccess) e = hipMemcpy(job->dev, job->host.data(), sizeof(ure_shard_t) * n_shards, hipMemcpyHostToDevice);
@@ -510,6 +549,15 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
             default: return fail(-1, "ure_job_train: unsupported d=%d", job->d);
         }
         if (int rc = mark(step_ev)) return rc;
+        if (job->snapshots) {
+            bool epoch_end = false;
+            for (const ure_shard_t &S : job->host) {
+                const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
+                if (S.snapU && t + 1 <= steps * S.epochs && (t + 1) % steps == 0) { epoch_end = true; break; }
+            }
+            if (epoch_end)
+                hipLaunchKernelGGL(snapshot_kernel, dim3(job->snap_blocks, (unsigned)job->host.size()), dim3(kBlock), 0, st, job->dev, t + 1);
+        }
     }
     URE_HIP(hipGetLastError());
     return 0;

@@ -88,6 +88,20 @@ class ShardData:
                    (self.ent_oid, self.ent_r, self.ent_tag, self.ent_src, self.file_tag, self.sched))
 
 
+def closed_form_scalars(lr_host, steps, lam, mu):
+    """a_e with w = a_e * w0 after epoch e for a row that only decays: the optimizer's recurrence
+    g = lam*w; m = mu*m + g (m = g on the first step); w -= lr*m, in float64 (as ure_job_materialize)."""
+    a, b, out, t = 1.0, 0.0, [], 0
+    for e in range(len(lr_host)):
+        lr = float(lr_host[e])
+        for _ in range(steps):
+            b = lam * a if t == 0 else mu * b + lam * a
+            a -= lr * b
+            t += 1
+        out.append(a)
+    return np.asarray(out, dtype=np.float32)
+
+
 class TrainJob:
     """A set of shards trained side by side, one optimizer step of each per launch.
 
@@ -96,7 +110,7 @@ class TrainJob:
     perms  : list of int32 [epochs, N_s] arrays (numpy or torch; CPU or device)
     """
 
-    def __init__(self, shards, inits, perms, k, batch, epochs, lr, lam, momentum, lr_decay=1.0, lr_step=50, lazy_rows=None):
+    def __init__(self, shards, inits, perms, k, batch, epochs, lr, lam, momentum, lr_decay=1.0, lr_step=50, lazy_rows=None, snapshots=False):
         assert len(shards) == len(inits) == len(perms) and len(shards) > 0
         self.shards, self.k, self.d = shards, int(k), pad_dim(int(k))
         self.batch, self.epochs = int(batch), int(epochs)
@@ -109,6 +123,7 @@ class TrainJob:
         # (URE_LAZY_ROWS=0 streams them every step, exactly as the reference's dense optimizer does)
         self.lazy_rows = LAZY_ROWS if lazy_rows is None else bool(lazy_rows)
         self._fresh = 0          # ticks for which the lazily advanced rows are up to date
+        self.snapshots = bool(snapshots)
         self.lr = torch.from_numpy(lr_host).to(dev)
         self.state = []
         descs = (nv.UreShard * len(shards))()
@@ -139,6 +154,13 @@ class TrainJob:
             D.N, D.n_user, D.n_item, D.d = sh.N, sh.n_user, sh.n_item, self.d
             D.batch, D.epochs = self.batch, self.epochs
             D.lam, D.mu = float(lam), float(momentum)
+            if self.snapshots:
+                snapU = torch.empty(self.epochs, sh.n_user, self.d, dtype=torch.float32, device=dev)
+                snapV = torch.empty(self.epochs, sh.n_item, self.d, dtype=torch.float32, device=dev)
+                steps = (sh.N + self.batch - 1) // self.batch
+                snap_a = torch.from_numpy(closed_form_scalars(lr_host, steps, float(np.float32(lam)), float(np.float32(momentum)))).to(dev)
+                self.state[-1].update(snapU=snapU, snapV=snapV, snap_a=snap_a)
+                D.snapU, D.snapV, D.snap_a = nv.ptr(snapU), nv.ptr(snapV), nv.ptr(snap_a)
             if self.lazy_rows:
                 U0d, V0d = U[0].clone(), V[0].clone()
                 self.state[-1].update(U0=U0d, V0=V0d)
@@ -177,6 +199,11 @@ class TrainJob:
         """Single-shard convenience: advance by whole epochs."""
         assert len(self.shards) == 1
         return self.run(n_epochs * self.steps_per_epoch(0), stream)
+
+    def snapshot(self, s, epoch):
+        """(U, V) of shard s as they were at the end of `epoch` (padded width; needs snapshots=True)."""
+        st = self.state[s]
+        return st['snapU'][epoch], st['snapV'][epoch]
 
     def materialize(self, stream=None):
         """Bring the lazily advanced rows (lazy_rows) up to date in the current tables."""
@@ -248,11 +275,13 @@ class EvalSet:
         self.log2 = to(_LOG2_TAB)
         self.order = order
 
-    def evaluate(self, models, d, stream=None, top_k=10):
+    def evaluate(self, models, d, stream=None, top_k=10, out=None):
         """baseTest (utils.py:115-187) for an ensemble: `models` = list of (U, V) device
         tensors with row stride d (the padded width).  Returns (rmse, ndcg, hr)."""
         assert top_k == 10, 'the kernel implements the reference default top_k=10'
         if self.n == 0:
+            if out is not None:
+                return out.fill_(float('nan'))
             return float('nan'), float('nan'), float('nan')
         L, st = nv.lib(), nv.stream_handle(stream)
         self.sse.zero_()
@@ -268,6 +297,11 @@ class EvalSet:
                                  nv.ptr(self.pred), nv.ptr(self.sse), st), 'ure_score')
         nv.check(L.ure_eval_users(nv.ptr(self.off), self.n_users, nv.ptr(self.pred), nv.ptr(self.rating),
                                   nv.ptr(self.log2), nv.ptr(self.hits), nv.ptr(self.ndcg), st), 'ure_eval_users')
+        if out is not None:
+            # queued evaluation: (rmse, ndcg, hr) land in `out` (device, 3 float64); nothing synchronises
+            nv.check(L.ure_eval_reduce(nv.ptr(self.hits), nv.ptr(self.ndcg), self.n_users, nv.ptr(self.sse), self.n,
+                                       nv.ptr(out), st), 'ure_eval_reduce')
+            return out
         sse = float(self.sse.cpu().item())
         hits = self.hits[:self.n_users].cpu().numpy()
         ndcg = self.ndcg[:self.n_users].cpu().numpy()

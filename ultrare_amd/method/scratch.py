@@ -100,12 +100,22 @@ class Scratch(object):
         before = [padded_tables(m)[:2] for m in self._models_before()]
         n_train = shard.N
 
+        # verbose 0: nothing is printed per epoch, so the two tests of every epoch are queued on the
+        # stream and all results are read once at the end; otherwise each epoch synchronises to print
+        queued = verbose == 0
+        res = torch.zeros(self.epochs, 2, 3, dtype=torch.float64, device=shard.device) if queued else None
+        times = []
         for t in range(self.epochs):
             if verbose == 2:
                 print(f'Epoch: [{t+1:>3d}/{self.epochs:>3d}] --------------------')
             epoch_start = time.time()
             job.run_epochs(1)                               # baseTrain (utils.py:46-111) + scheduler.step()
             models = before + [job.padded_tables(0)]        # scratch.py:83-86
+            if queued:
+                test_ev.evaluate(models, job.d, out=res[t, 0])
+                (total_ev if has_total else test_ev).evaluate(models, job.d, out=res[t, 1])
+                times.append(time.strftime('%H:%M:%S', time.gmtime(time.time() - epoch_start)))
+                continue
             test_rmse, test_ndcg, test_hr = test_ev.evaluate(models, job.d)
             if has_total:
                 total_rmse, total_ndcg, total_hr = total_ev.evaluate(models, job.d)
@@ -133,6 +143,16 @@ class Scratch(object):
                 self.log['total_rmse'].append(total_rmse)
                 self.log['total_ndcg'].append(total_ndcg)
                 self.log['total_hr'].append(total_hr)
+
+        if queued:
+            res = res.cpu().numpy()
+            self.log['train_loss'] += [float(x) for x in np.sqrt(job.epoch_sse(0) / n_train)]
+            for c, key in enumerate(('test_rmse', 'test_ndcg', 'test_hr')):
+                self.log[key] += [float(x) for x in res[:, 0, c]]
+            self.log['time'] += times
+            if has_total:
+                for c, key in enumerate(('total_rmse', 'total_ndcg', 'total_hr')):
+                    self.log[key] += [float(x) for x in res[:, 1, c]]
 
         U, V = job.tables(0)
         model = MF.from_tables(U.clone().contiguous(), V.clone().contiguous())

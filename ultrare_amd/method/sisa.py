@@ -9,10 +9,14 @@ and isolated, and the RNG stream is consumed in the reference's order in both):
                         call share every launch (engine.TrainJob) and, when
                         torch.distributed is initialised, are spread over the ranks
                         (one process per GPU, no collective while training; trained
-                        tables are exchanged once over RCCL).  Per-epoch logs then hold
-                        the training loss of every epoch and the tests of the final
-                        epoch only -- the in-loop tests depend on the sequential order.
+                        tables are exchanged once over RCCL).  The reference's per-epoch
+                        test logs depend on the sequential order (they average the models
+                        trained before the shard); they are rebuilt afterwards from
+                        end-of-epoch snapshots (`param.epoch_logs`, default on while the
+                        snapshots fit URE_SNAPSHOT_LIMIT_GB).
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -21,6 +25,9 @@ from .. import engine
 from ..read import as_loader
 from .scratch import Scratch, prepare_shard
 from .utils import MF, baseTest, padded_tables, seed_all
+
+
+SNAPSHOT_LIMIT_BYTES = int(float(os.environ.get('URE_SNAPSHOT_LIMIT_GB', '8')) * 2 ** 30)
 
 
 def _dist():
@@ -86,6 +93,7 @@ class Sisa(Scratch):
         self.n_group = n_group
         self.group_index = group_index
         self.parallel = bool(getattr(param, 'parallel', False))
+        self.epoch_logs = bool(getattr(param, 'epoch_logs', True))   # parallel mode: rebuild the per-epoch test logs
         self.model_list = []
 
     def test(self, test_data, verbose, save_dir):
@@ -109,8 +117,12 @@ class Sisa(Scratch):
         for m in self.model_list:
             m.user_mat.weight = nn.Parameter(merged, requires_grad=False)
 
-    def _train_parallel(self, ids, train_dlist, test_dlist, test_data, verbose, save_dir):
-        """Train the shards `ids` side by side (and across ranks)."""
+    def _train_parallel(self, ids, train_dlist, test_dlist, test_data, verbose, save_dir, unlearning=False):
+        """Train the shards `ids` side by side (and across ranks).  With epoch_logs the tables of
+        every epoch end are kept on the device and the reference's per-epoch group / total tests
+        (scratch.py:83-97: mean of the models trained BEFORE this shard + this shard's model of
+        that epoch) are computed afterwards, so log{id}.npy carries the same series as a
+        sequential run."""
         seed_all(self.seed)
         dist = _dist()
         world = dist.get_world_size() if dist else 1
@@ -119,12 +131,16 @@ class Sisa(Scratch):
         owner = assign_shards(sizes, world)
         prepared = prepare_owned(ids, owner, rank, train_dlist, self.n_user, self.n_item, self.k, self.epochs)
         mine = [i for pos, i in enumerate(ids) if owner[pos] == rank]
-        models = {}
+        snap_bytes = len(mine) * self.epochs * (self.n_user + self.n_item) * engine.pad_dim(self.k) * 4
+        keep_logs = self.epoch_logs and snap_bytes <= SNAPSHOT_LIMIT_BYTES
+        if self.epoch_logs and not keep_logs and verbose:
+            print(f'per-epoch test logs skipped: {snap_bytes / 2**30:.1f} GiB of snapshots exceeds the limit')
+        models, job, losses = {}, None, {}
         if mine:
             batch = as_loader(train_dlist[mine[0]]).batch_size
             job = engine.TrainJob([prepared[i][0] for i in mine], [prepared[i][1] for i in mine],
                                   [prepared[i][2] for i in mine], self.k, batch, self.epochs, self.lr, self.lam,
-                                  self.momentum, self.lr_decay)
+                                  self.momentum, self.lr_decay, snapshots=keep_logs)
             from .. import rng
             for i in mine:
                 rng.release(prepared[i][2])                 # uploaded: host buffers go back to the pool
@@ -132,14 +148,49 @@ class Sisa(Scratch):
             for pos, i in enumerate(mine):
                 U, V = job.tables(pos)
                 models[i] = (U.clone().contiguous(), V.clone().contiguous())
-                n = prepared[i][0].N
-                self.log['train_loss'] += [float(x) for x in np.sqrt(job.epoch_sse(pos) / n)]
-            job.close()
+                losses[i] = [float(x) for x in np.sqrt(job.epoch_sse(pos) / prepared[i][0].N)]
         if dist:   # the only exchange of the path: every rank ends up with every shard's tables
             models = exchange_tables(models, ids, owner, rank, self.n_user, self.n_item, self.k, engine._device(), dist)
-        out = {}
+        out = {i: MF.from_tables(*models[i]) for i in ids}
+
+        # ---- logs, shard after shard in the reference's order (one dict for all shards)
+        logs = {}
+        for i in mine:
+            entry = {'train_loss': losses[i]}
+            if keep_logs:
+                total_ev = as_loader(test_data).eval_set()
+                test_ev = as_loader(test_dlist[i]).eval_set()
+                before = list(self.model_list) if unlearning else []
+                for j in ids:
+                    if j == i:
+                        break
+                    if unlearning:
+                        before[j] = out[j]                  # sisa.py:89: already replaced when shard i trains
+                    else:
+                        before.append(out[j])
+                before = [padded_tables(m)[:2] for m in before]
+                pos = mine.index(i)
+                res = torch.zeros(self.epochs, 2, 3, dtype=torch.float64, device=engine._device())
+                for e in range(self.epochs):                # queued on the stream: no synchronisation per call
+                    ms = before + [job.snapshot(pos, e)]
+                    test_ev.evaluate(ms, job.d, out=res[e, 0])
+                    total_ev.evaluate(ms, job.d, out=res[e, 1])
+                res = res.cpu().numpy()
+                for c, key in enumerate(('test_rmse', 'test_ndcg', 'test_hr')):
+                    entry[key] = [float(x) for x in res[:, 0, c]]
+                for c, key in enumerate(('total_rmse', 'total_ndcg', 'total_hr')):
+                    entry[key] = [float(x) for x in res[:, 1, c]]
+            logs[i] = entry
+        if job is not None:
+            job.close()
+        if dist:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, logs)
+            logs = {k: v for part in gathered for k, v in part.items()}
         for i in ids:
-            out[i] = MF.from_tables(*models[i])
+            for key, vals in logs[i].items():
+                self.log[key] += vals
+            self.log['time'] += ['00:00:00'] * self.epochs
             if rank == 0:
                 self.save(out[i], save_dir, i + 1)
         return out
@@ -193,7 +244,7 @@ class Sisa(Scratch):
 
         if self.parallel:
             ids = list(retrain_gid)
-            trained = self._train_parallel(ids, train_dlist, test_dlist, test_data, verbose, save_dir) if ids else {}
+            trained = self._train_parallel(ids, train_dlist, test_dlist, test_data, verbose, save_dir, unlearning=True) if ids else {}
             for i in ids:
                 self.model_list[i] = trained[i]
         else:
