@@ -30,6 +30,7 @@ extern "C" {
 
 #define URE_ABI_VERSION 1
 #define URE_MAX_MODELS_PER_CALL 32
+#define URE_SCORE_PARTIALS 2048       /* length of ure_score's sse buffer */
 
 int ure_abi_version(void);
 const char *ure_last_error(void);
@@ -165,8 +166,9 @@ int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *r
 /* utils.py:140-145: pred[j] = (sum_m U_m[uid[j]] . V_m[iid[j]]) / n_models_total.
  * Up to URE_MAX_MODELS_PER_CALL tables per call; for larger ensembles call
  * repeatedly with `first`/`last` marking the first and last chunk (pred holds the
- * running sum in between).  When `sse` is non-NULL the last chunk also adds
- * sum_j (pred[j] - rating[j])^2 to *sse (utils.py:148; double, device memory). */
+ * running sum in between).  When `sse` is non-NULL the last chunk also writes partial sums of
+ * (pred[j] - rating[j])^2 to sse[0 .. URE_SCORE_PARTIALS) (utils.py:148; double, device memory);
+ * their total is the loss (summed in a fixed order by ure_eval_reduce, or by the caller). */
 int ure_score(const float *const *U_tables, const float *const *V_tables, int n_models,
               int n_models_total, int first, int last,
               const int32_t *uid, const int32_t *iid, const float *rating, int64_t n, int d,
@@ -176,12 +178,12 @@ int ure_score(const float *const *U_tables, const float *const *V_tables, int n_
  * [off[t], off[t+1]).  For each user: top-10 by prediction and by rating (ties:
  * higher position first = stable argsort reversed), hits[t] = #(rating[top_pred]
  * >= 4/5), ndcg[t] = the reference's positional NDCG@10 (utils.py:190-210).
- * `inv_log2` = 1/log2(2..10) is NOT used; `log2_tab` [9] = log2(2..10) as float64
- * computed by the host with numpy so that the division matches bit for bit. */
+ * `log2_tab` [10] (device, float64) = log2(2..10) followed by the ideal DCG computeDCG(ones(10)),
+ * both computed by the host with numpy so that every division matches the reference bit for bit. */
 int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const float *rating,
                    const double *log2_tab, int32_t *hits, double *ndcg, void *stream);
 
-/* utils.py:163,183-184: out3 (device, 3 doubles) = { sqrt(*sse / n_rows), mean(ndcg), mean(hits / 10) }
+/* utils.py:163,183-184: out3 (device, 3 doubles) = { sqrt(sum(sse[0..URE_SCORE_PARTIALS)) / n_rows), mean(ndcg), mean(hits / 10) }
  * from the outputs of ure_score / ure_eval_users, reduced on the device in a fixed order: lets a
  * caller queue many evaluations without synchronising and read all results at the end. */
 int ure_eval_reduce(const int32_t *hits, const double *ndcg, int32_t n_users, const double *sse, int64_t n_rows, double *out3,

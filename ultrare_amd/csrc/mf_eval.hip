@@ -42,14 +42,28 @@ __global__ __launch_bounds__(kBlock) void score_kernel(TableList T, int n_models
         const bool act = j < n;
         const int u = act ? uid[j] : 0, i = act ? iid[j] : 0;
         float acc = (act && !first) ? pred[j] : 0.f;
-        for (int m = 0; m < n_models; ++m) {
-            const float4 a = *reinterpret_cast<const float4 *>(T.U[m] + (size_t)u * D + sub * 4);
-            const float4 b = *reinterpret_cast<const float4 *>(T.V[m] + (size_t)i * D + sub * 4);
-            float p = a.x * b.x;
-            p = fmaf(a.y, b.y, p);
-            p = fmaf(a.z, b.z, p);
-            p = fmaf(a.w, b.w, p);
-            acc += group_sum<LPR>(p);
+        // the rows of four models are fetched together (eight independent 16-byte gathers per lane);
+        // the sum over models stays in list order (utils.py:145 stack(...).mean(0))
+        for (int m0 = 0; m0 < n_models; m0 += 4) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                b[k] = a[k];
+                if (m0 + k < n_models) {
+                    a[k] = *reinterpret_cast<const float4 *>(T.U[m0 + k] + (size_t)u * D + sub * 4);
+                    b[k] = *reinterpret_cast<const float4 *>(T.V[m0 + k] + (size_t)i * D + sub * 4);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float p = a[k].x * b[k].x;
+                p = fmaf(a[k].y, b[k].y, p);
+                p = fmaf(a[k].z, b[k].z, p);
+                p = fmaf(a[k].w, b[k].w, p);
+                p = group_sum<LPR>(p);
+                if (m0 + k < n_models) acc += p;
+            }
         }
         if (last) {
             acc = acc / (float)n_total;
@@ -61,8 +75,20 @@ __global__ __launch_bounds__(kBlock) void score_kernel(TableList T, int n_models
         if (act && sub == 0) pred[j] = acc;
     }
     if (last && sse) {
+        // one partial per workgroup, no atomics: thousands of waves adding to ONE address serialise
+        // at ~12 ns each (measured: 69 us for this kernel); the partials are summed in a fixed
+        // order by ure_eval_reduce or by the host
+        __shared__ float part[kWavesPerBlock];
         sq = wave_sum(sq);
-        if (lane == 0 && sq != 0.f) atomicAdd(sse, (double)sq);
+        if (lane == 0) part[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < kWavesPerBlock; ++k) t += (double)part[k];
+            sse[blockIdx.x] = t;
+        }
+        for (int t = gridDim.x + threadIdx.x; blockIdx.x == 0 && t < URE_SCORE_PARTIALS; t += kBlock) sse[t] = 0.0;
     }
 }
 
@@ -103,6 +129,48 @@ __device__ __forceinline__ void top_k_positions(const float *__restrict__ val, i
     }
 }
 
+// The same selection when the segment has at most 64 entries: lane t holds entry t.
+// Every lane counts the entries that beat its own (val, position) key -- `cnt` independent
+// broadcasts instead of ten dependent arg-max rounds -- and the entry of rank k is top[k].
+template <int K>
+__device__ __forceinline__ void top_k_in_registers(float val, int cnt, int lane, int (&top)[K])
+{
+    int rank = 0;
+    for (int t = 0; t < cnt; ++t) {
+        const float ov = __shfl(val, t, kWave);
+        rank += key_gt(ov, t, val, lane) ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const unsigned long long m = __ballot(lane < cnt && rank == k);
+        top[k] = m ? (int)__builtin_ctzll(m) : -1;
+    }
+}
+
+// Segments of up to 64 * kRegItems entries: lane t holds entries t, t+64, ... in registers; every
+// round takes the best not-yet-taken key of the wave (no memory access per round).
+constexpr int kRegItems = 8;
+template <int K>
+__device__ __forceinline__ void top_k_multi(const float (&val)[kRegItems], int cnt, int lane, int (&top)[K])
+{
+    unsigned taken = 0;
+#pragma unroll
+    for (int r = 0; r < kRegItems; ++r) taken |= (lane + r * kWave >= cnt ? 1u : 0u) << r;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float bv = -FLT_MAX;
+        int bi = -1;
+#pragma unroll
+        for (int r = 0; r < kRegItems; ++r) {
+            const int t = lane + r * kWave;
+            if (!((taken >> r) & 1u) && (bi < 0 || key_gt(val[r], t, bv, bi))) { bv = val[r]; bi = t; }
+        }
+        wave_argmax(bv, bi);
+        top[k] = bi;
+        if (bi >= 0 && (bi & (kWave - 1)) == lane) taken |= 1u << (bi / kWave);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__restrict__ off, int32_t n_users,
                                                             const float *__restrict__ pred, const float *__restrict__ rating,
                                                             const double *__restrict__ log2_tab,
@@ -114,8 +182,28 @@ __global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__res
     if (user >= n_users) return;
     const int beg = off[user], cnt = off[user + 1] - beg;
     int tp[K], tr[K];
-    top_k_positions<K>(pred + beg, cnt, lane, tp);
-    top_k_positions<K>(rating + beg, cnt, lane, tr);
+    if (cnt <= kWave) {
+        // the common case (a user's test items fit one per lane): both rankings are extracted from
+        // registers, ten wave arg-max rounds each, no memory access per round
+        const float pv = lane < cnt ? pred[beg + lane] : 0.f;
+        const float rv = lane < cnt ? rating[beg + lane] : 0.f;
+        top_k_in_registers<K>(pv, cnt, lane, tp);
+        top_k_in_registers<K>(rv, cnt, lane, tr);
+    } else if (cnt <= kWave * kRegItems) {
+        // heavier users: up to 8 entries per lane, loaded once; ten arg-max rounds in registers
+        float pv[kRegItems], rv[kRegItems];
+#pragma unroll
+        for (int r = 0; r < kRegItems; ++r) {
+            const int t = lane + r * kWave;
+            pv[r] = t < cnt ? pred[beg + t] : 0.f;
+            rv[r] = t < cnt ? rating[beg + t] : 0.f;
+        }
+        top_k_multi<K>(pv, cnt, lane, tp);
+        top_k_multi<K>(rv, cnt, lane, tr);
+    } else {
+        top_k_positions<K>(pred + beg, cnt, lane, tp);
+        top_k_positions<K>(rating + beg, cnt, lane, tr);
+    }
     if (lane != 0) return;
     const int n_top = cnt < K ? cnt : K;
     double val[K];
@@ -135,16 +223,14 @@ __global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__res
     }
     // computeDCG (utils.py:209-210): r[0] + np.sum(r[1:] / log2(2..10)); np.sum of 9
     // float64 = numpy pairwise: 8 lanes combined as a tree, then the 9th added.
-    double a[K - 1], b[K - 1];
+    // The ideal DCG, computeDCG(np.ones(10)), is a constant: the host evaluates it with numpy
+    // itself and passes it as log2_tab[9].
+    double a[K - 1];
 #pragma unroll
-    for (int j = 0; j < K - 1; ++j) {
-        a[j] = val[j + 1] / log2_tab[j];
-        b[j] = 1.0 / log2_tab[j];
-    }
+    for (int j = 0; j < K - 1; ++j) a[j] = val[j + 1] / log2_tab[j];
     const double dcg = val[0] + ((((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + a[8]);
-    const double idcg = 1.0 + ((((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]))) + b[8]);
     hits[user] = n_hit;
-    ndcg[user] = dcg / idcg;
+    ndcg[user] = dcg / log2_tab[K - 1];
 }
 
 // utils.py:163-184 tail: rmse = sqrt(sse / n_rows), ndcg = mean(ndcg), hr = mean(hits / 10), reduced on
@@ -172,8 +258,17 @@ __global__ __launch_bounds__(1024) void eval_reduce_kernel(const int32_t *__rest
         }
         __syncthreads();
     }
+    __shared__ double ss[1024];
+    double as = 0.0;
+    for (int t = threadIdx.x; t < URE_SCORE_PARTIALS; t += 1024) as += sse[t];
+    ss[threadIdx.x] = as;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) ss[threadIdx.x] += ss[threadIdx.x + o];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        out3[0] = sqrt(*sse / (double)n_rows);
+        out3[0] = sqrt(ss[0] / (double)n_rows);
         out3[1] = n_users > 0 ? sn[0] / (double)n_users : 0.0;
         out3[2] = n_users > 0 ? ((double)sh[0] / 10.0) / (double)n_users : 0.0;
     }
@@ -197,7 +292,7 @@ static void launch_score(const TableList &T, int nm, int nt, int first, int last
 {
     constexpr int G = kWave / LPR;
     const int64_t waves = (n + G - 1) / G;
-    const unsigned blocks = (unsigned)std::min<int64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 8);
+    const unsigned blocks = (unsigned)std::min<int64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, URE_SCORE_PARTIALS);
     hipLaunchKernelGGL(score_kernel<LPR>, dim3(blocks ? blocks : 1), dim3(kBlock), 0, st, T, nm, nt, first, last, uid, iid,
                        rating, n, pred, sse);
 }

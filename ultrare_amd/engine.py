@@ -25,6 +25,7 @@ from . import _native as nv
 # the rest one lane group (d/4 lanes) each
 BLOCK_NNZ = int(os.environ.get('URE_BLOCK_NNZ', '1024'))
 GROUP_NNZ = int(os.environ.get('URE_GROUP_NNZ', '128'))
+SCORE_PARTIALS = 2048     # URE_SCORE_PARTIALS of the C ABI
 LAZY_ROWS = os.environ.get('URE_LAZY_ROWS', '1') != '0'
 
 
@@ -241,6 +242,8 @@ class TrainJob:
 
 
 _LOG2_TAB = np.log2(np.arange(2, 11)).astype(np.float64)      # utils.py:210
+_IDCG = 1.0 + np.sum(np.ones(9) / _LOG2_TAB)                   # computeDCG(np.ones(10)), utils.py:207
+_LOG2_TAB = np.concatenate([_LOG2_TAB, [_IDCG]])
 
 
 class EvalSet:
@@ -271,7 +274,7 @@ class EvalSet:
         self.pred = torch.zeros(max(self.n, 1), dtype=torch.float32, device=dev)
         self.hits = torch.zeros(max(self.n_users, 1), dtype=torch.int32, device=dev)
         self.ndcg = torch.zeros(max(self.n_users, 1), dtype=torch.float64, device=dev)
-        self.sse = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.sse = torch.zeros(SCORE_PARTIALS, dtype=torch.float64, device=dev)
         self.log2 = to(_LOG2_TAB)
         self.order = order
 
@@ -284,7 +287,6 @@ class EvalSet:
                 return out.fill_(float('nan'))
             return float('nan'), float('nan'), float('nan')
         L, st = nv.lib(), nv.stream_handle(stream)
-        self.sse.zero_()
         S = len(models)
         for c0 in range(0, S, nv.MAX_MODELS_PER_CALL):
             chunk = models[c0:c0 + nv.MAX_MODELS_PER_CALL]
@@ -302,7 +304,7 @@ class EvalSet:
             nv.check(L.ure_eval_reduce(nv.ptr(self.hits), nv.ptr(self.ndcg), self.n_users, nv.ptr(self.sse), self.n,
                                        nv.ptr(out), st), 'ure_eval_reduce')
             return out
-        sse = float(self.sse.cpu().item())
+        sse = float(self.sse.cpu().numpy().sum())
         hits = self.hits[:self.n_users].cpu().numpy()
         ndcg = self.ndcg[:self.n_users].cpu().numpy()
         rmse = float(np.sqrt(sse / self.n))
