@@ -29,13 +29,14 @@
 //     first three steps of an epoch carry the preparation of the next epoch's tags as
 //     extra workgroups (tag_prep.h).
 //   * Shards are independent (sisa.py:33-36), so a job's shards share each launch
-//     (blockIdx.y = shard): one tick advances every shard by one optimizer step.
+//     (blockIdx.x = shard): one tick advances every shard by one optimizer step.
 //
 // Algorithmic bytes per interaction and step: 16 + 16 d sparse,
 // 20 P dense; this kernel moves 16 P dense (no gradient read) + the tag scan.
 #include "tag_prep.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace ure {
@@ -48,7 +49,7 @@ constexpr int kSegPerLane = 8;  // slots one lane scans per segment on the group
 __device__ __forceinline__ int shard_steps(const ure_shard_t &S) { return (S.N + S.batch - 1) / S.batch; }
 
 template <int LPR>
-__global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__restrict__ shards, int64_t tick)
+__global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__restrict__ shards, int64_t tick, int shard_fast)
 {
     constexpr int D = LPR * 4;
     constexpr int G = kWave / LPR;           // table rows one wave instruction gathers
@@ -64,7 +65,12 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     int (*q_oid)[kQueue] = reinterpret_cast<int (*)[kQueue]>(lds_raw);
     float (*q_r)[kQueue] = reinterpret_cast<float (*)[kQueue]>(lds_raw + kWavesPerBlock * kQueue * 4);
 
-    const ure_shard_t &S = shards[blockIdx.y];
+    // grid = (shards, workgroups): the shard is the FAST index of the linear workgroup id, so with
+    // the dispatcher's round-robin placement all workgroups of shard k run on XCD (k mod 8) whenever
+    // the shard count is a multiple of 8 -- each XCD's L2 then holds only its own shards' tables.
+    // (A speed matter only; for other shard counts every shard simply spreads over all XCDs.)
+    const ure_shard_t &S = shards[shard_fast ? blockIdx.x : blockIdx.y];
+    const int wg = (int)(shard_fast ? blockIdx.y : blockIdx.x);
     const int steps = shard_steps(S);
     if (tick >= (int64_t)steps * S.epochs) return;
     const int epoch = (int)(tick / steps);
@@ -114,13 +120,13 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     // extra workgroups at the front of the grid (tag_prep.h); the launch boundary between steps
     // orders the phases.
     const int nbR = tag_rider_blocks(S.N, S.n_slots, steps, s, epoch + 1 < S.epochs);
-    if ((int)blockIdx.x < nbR) {
-        if (s == 0) tag_partition(S, epoch + 1, (int)blockIdx.x, lds_raw);
-        else if (s == 1) tag_collect(S, (int)blockIdx.x, lds_raw);
-        else tag_derive(S, epoch + 1, (int)blockIdx.x, nbR);
+    if (wg < nbR) {
+        if (s == 0) tag_partition(S, epoch + 1, wg, lds_raw);
+        else if (s == 1) tag_collect(S, wg, lds_raw);
+        else tag_derive(S, epoch + 1, wg, nbR);
         return;
     }
-    const int blk = (int)blockIdx.x - nbR;
+    const int blk = wg - nbR;
 
     if (blk >= nbB + nbW + nbG + nbD) return;
     if (blk >= nbB + nbW) {
@@ -434,8 +440,9 @@ static void launch_step(const ure_job *job, int64_t tick, hipStream_t st)
         const int64_t epoch = tick / steps;
         blocks = std::max(blocks, job->row_blocks[k] + tag_rider_blocks(S.N, S.n_slots, (int)steps, (int)(tick - epoch * steps), epoch + 1 < S.epochs));
     }
-    dim3 grid((unsigned)blocks, (unsigned)job->host.size());
-    hipLaunchKernelGGL(mf_step_kernel<LPR>, grid, dim3(kBlock), 0, st, job->dev, tick);
+    const int shard_fast = job->shard_fast && blocks <= 65535;
+    dim3 grid = shard_fast ? dim3((unsigned)job->host.size(), (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)job->host.size());
+    hipLaunchKernelGGL(mf_step_kernel<LPR>, grid, dim3(kBlock), 0, st, job->dev, tick, shard_fast);
 }
 
 }  // namespace ure
@@ -475,6 +482,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         if (small) job->max_small_n = std::max(job->max_small_n, S.N);
     }
     job->d = shards[0].d;
+    if (const char *e = std::getenv("URE_SHARD_FAST")) job->shard_fast = e[0] != '0';
     for (int k = 0; k < n_shards; ++k) {
         const ure_shard_t &S = shards[k];
         job->lr_host.emplace_back(S.lr_host ? std::vector<float>(S.lr_host, S.lr_host + S.epochs) : std::vector<float>());

@@ -46,6 +46,7 @@ struct ure_job {
     std::vector<std::vector<float>> lr_host;           // per shard: learning rate of each epoch (for the closed form)
     std::vector<double> ab_host;                       // per shard (a, b) of the lazily advanced rows
     double *dev_ab = nullptr;
+    bool shard_fast = true;              // shard = fast index of the workgroup id (XCD affinity for 8k shards)
     bool snapshots = false;
     unsigned snap_blocks = 1;
     int64_t max_lazy = 0;                              // float4 slices of lazily advanced rows, max over shards
