@@ -170,3 +170,41 @@ def test_large_shard_scatter_fallback_and_many_epochs():
     U, V = job.tables(0)
     assert rel(U.cpu().numpy(), st.U) < 1e-4 and rel(V.cpu().numpy(), st.V) < 1e-4
     np.testing.assert_allclose(np.sqrt(job.epoch_sse(0) / n), losses, rtol=1e-4)
+
+
+def test_edge_cases_tiny_shards_ragged_eval_and_large_ensembles():
+    """Ragged / degenerate inputs: shards of 1 and 7 interactions, width 1 (padded to 4), a test
+    user with more than 512 items (the global-memory top-10 path), an ensemble of 33 models
+    (more than one ure_score call), an empty test set."""
+    from ultrare_amd import engine, rng
+    rs = np.random.RandomState(0)
+    for n, k in ((1, 1), (7, 3)):
+        part = (rs.randint(0, 5, n).astype(np.int32), rs.randint(0, 6, n).astype(np.int32), rs.rand(n).astype(np.float32))
+        torch.manual_seed(n)
+        U0, V0 = rng.mf_init(5, 6, k)
+        perms = rng.epoch_perms(rng.epoch_seeds(4, True), n)
+        job = engine.TrainJob([engine.ShardData(*part, 5, 6)], [(U0, V0)], [perms], k, 4, 4, 1e-2, 0.1, 0.9)
+        job.run()
+        st = O.MFState(U0.numpy().copy(), V0.numpy().copy())
+        for t in range(4):
+            O.train_epoch(st, part, perms[t].numpy(), 4, 1e-2, 0.1, 0.9)
+        U, V = job.tables(0)
+        assert rel(U.cpu().numpy(), st.U) < 1e-5 and rel(V.cpu().numpy(), st.V) < 1e-5
+    # evaluation: one user with 700 items, one with 65, many small ones; 33 models
+    cnts = [700, 65, 64, 1, 10, 11] + [3] * 40
+    uid = np.repeat(np.arange(len(cnts)), cnts).astype(np.int32)
+    n = len(uid)
+    iid = rs.randint(0, 50, n).astype(np.int32)
+    r = rs.choice([0.2, 0.4, 0.6, 0.8, 1.0], n).astype(np.float32)
+    models = [(rs.standard_normal((len(cnts), 8)).astype(np.float32) * 0.4, rs.standard_normal((50, 8)).astype(np.float32) * 0.4)
+              for _ in range(33)]
+    ev = engine.EvalSet(uid, iid, r)
+    dev = [(torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()) for U, V in models]
+    got = ev.evaluate(dev, 8)
+    want = O.eval_metrics((uid, iid, r), models, 3000)
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+    out = torch.zeros(3, dtype=torch.float64, device='cuda')
+    ev.evaluate(dev, 8, out=out)                                     # queued form: same numbers
+    np.testing.assert_allclose(out.cpu().numpy(), got, rtol=1e-12)
+    empty = engine.EvalSet(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+    assert all(np.isnan(x) for x in empty.evaluate(dev[:1], 8))
