@@ -16,7 +16,7 @@ Harness conventions:
     default kind is host-specific, SURVEY section 7 "NDCG tie-breaking"); the as-is
     value is stored beside it as information.
 
-usage: python tests/golden/make_golden.py [full] [sisa] [eval] [ot]
+usage: python tests/golden/make_golden.py [full] [sisa] [eval] [ot] [ml1m]
 """
 import contextlib
 import io
@@ -402,8 +402,77 @@ def gen_ot():
     np.savez_compressed(os.path.join(HERE, 'ot_toy.npz'), **out)
 
 
+def gen_ml1m():
+    """BASELINE.json configs[0]/[1] shape: ml-1m-sized synthetic ratings (the build's own seeded
+    generator, ultrare_amd/synth.py -- the real ratings.dat is not shipped), d = 32, batch 30,000,
+    ONE epoch through the real reference: full MF (Scratch.train) and 5-shard SISA (Sisa.learn).
+    Only sampled rows, sums and metrics are stored."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from ultrare_amd import synth
+    data = synth.make_dataset(**synth.ML1M)
+    n_user, n_item = data['n_user'], data['n_item']
+
+    def arr(t):
+        return np.vstack([t[0].astype(np.float64), t[1].astype(np.float64), t[2] / 5.0])
+
+    class P(Param):
+        pass
+    p = P(1, k=32, batch=30000)
+    p.n_user, p.n_item = n_user, n_item
+    rows_u = np.linspace(0, n_user - 1, 256).astype(np.int64)
+    rows_i = np.linspace(0, n_item - 1, 256).astype(np.int64)
+    out = {'rows_u': rows_u, 'rows_i': rows_i, 'n_train': len(data['train'][0]), 'n_test': len(data['test'][0]),
+           'train_check': np.int64((data['train'][0] * 7 + data['train'][1]).sum()), 'seed': synth.SEED}
+
+    def pack(tag, U, V):
+        out[tag + '_U_rows'] = U[rows_u].copy()
+        out[tag + '_V_rows'] = V[rows_i].copy()
+        out[tag + '_U_sum'] = np.float64(U.astype(np.float64).sum())
+        out[tag + '_V_sum'] = np.float64(V.astype(np.float64).sum())
+        out[tag + '_U_abs'] = np.float64(np.abs(U.astype(np.float64)).sum())
+        out[tag + '_V_abs'] = np.float64(np.abs(V.astype(np.float64)).sum())
+
+    # ---- full MF, one epoch
+    tr, te = loaders(arr(data['train']), arr(data['test']), p.batch)
+    sc = RS.Scratch(p, 'mf')
+    t0 = time.time()
+    torch.manual_seed(p.seed)
+    with quiet(), stable_sort():
+        model = sc.train(tr, te, [], 0, '')
+    out['full_seconds'] = time.time() - t0
+    pack('full', model.user_mat.weight.detach().numpy(), model.item_mat.weight.detach().numpy())
+    out['full_train_loss'] = np.array(sc.log['train_loss'])
+    out['full_test'] = np.array([sc.log['test_rmse'][0], sc.log['test_ndcg'][0], sc.log['test_hr'][0]])
+    print('ml1m full MF 1 epoch:', round(out['full_seconds'], 1), 's', out['full_test'], flush=True)
+
+    # ---- 5-shard SISA (uniform grouping), one epoch
+    S = 5
+    shard_of, groups = synth.uniform_shards(n_user, S)
+    tr_l = [arr(tuple(x[shard_of[data['train'][0]] == g] for x in data['train'])) for g in range(S)]
+    te_l = [arr(tuple(x[shard_of[data['test'][0]] == g] for x in data['test'])) for g in range(S)]
+    trd = [RR.loadData(RR.RatingData(a), p.batch, 0) for a in tr_l]
+    ted = [RR.loadData(RR.RatingData(a), p.batch, 0, False) for a in te_l]
+    tot = RR.loadData(RR.RatingData(np.hstack(te_l)), p.batch, 0, False)
+    sisa = RSI.Sisa(p, 'mf', S, groups)
+    save = tempfile.mkdtemp()
+    t0 = time.time()
+    torch.manual_seed(p.seed)
+    with quiet(), stable_sort():
+        ml = sisa.learn(trd, ted, tot, 0, save)
+    out['sisa_seconds'] = time.time() - t0
+    for i in range(S):
+        pack(f'sisa{i}', np.load(f'{save}/user_mat{i + 1}.npy'), ml[i].item_mat.weight.detach().numpy())
+    out['sisa_merged_rows'] = ml[0].user_mat.weight.detach().numpy()[rows_u].copy()
+    log0 = np.load(f'{save}/log0.npy', allow_pickle=True).item()
+    out['sisa_log0'] = np.array([log0['total_rmse'], log0['total_ndcg'], log0['total_hr']])
+    for key in ('train_loss', 'test_rmse', 'test_ndcg', 'test_hr', 'total_rmse', 'total_ndcg', 'total_hr'):
+        out['sisa_log_' + key] = np.array(sisa.log[key])
+    print('ml1m 5-shard SISA 1 epoch:', round(out['sisa_seconds'], 1), 's', out['sisa_log0'], flush=True)
+    np.savez_compressed(os.path.join(HERE, 'ml1m_synth.npz'), **out)
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['full', 'sisa', 'eval', 'ot']
     torch.set_num_threads(1)
     for w in what:
-        {'full': gen_full, 'sisa': gen_sisa, 'eval': gen_eval, 'ot': gen_ot}[w]()
+        {'full': gen_full, 'sisa': gen_sisa, 'eval': gen_eval, 'ot': gen_ot, 'ml1m': gen_ml1m}[w]()

@@ -153,3 +153,57 @@ def test_unlearn_16_shards_properties(ml1m, tmp_path):
     assert rel(after_U, ref['merged']) < 1e-5
     for s in affected:
         assert rel(ml2[s].item_mat.weight, ref['models'][s][1]) < 1e-5
+
+
+def test_ml1m_size_vs_reference_golden(ml1m, tmp_path):
+    """BASELINE configs[0] and [1] at full ml-1m size against the REAL reference (one epoch,
+    tests/golden/ml1m_synth.npz): Scratch.train (full MF) and Sisa.learn (5 shards, d=32),
+    sequential and shard-parallel, including the per-epoch group / total test series."""
+    import os
+    from ultrare_amd import synth
+    from ultrare_amd.method.scratch import Scratch
+    from ultrare_amd.method.sisa import Sisa
+    from ultrare_amd.read import RatingData, loadData
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ml1m_synth.npz'))
+    assert int((ml1m['train'][0] * 7 + ml1m['train'][1]).sum()) == int(g['train_check'])
+
+    class P:
+        k, lam, seed, batch, lr, lr_decay, momentum, epochs, parallel = 32, 0.1, 42, 30000, 0.001, 0.95, 0.9, 1, False
+        n_user, n_item = ml1m['n_user'], ml1m['n_item']
+
+    def check(tag, U, V):
+        U = U.detach().cpu().numpy() if torch.is_tensor(U) else U
+        V = V.detach().cpu().numpy() if torch.is_tensor(V) else V
+        assert rel(U[g['rows_u']], g[tag + '_U_rows']) < 1e-4 and rel(V[g['rows_i']], g[tag + '_V_rows']) < 1e-4
+        assert abs(np.abs(U.astype(np.float64)).sum() / float(g[tag + '_U_abs']) - 1) < 1e-5
+
+    def arr(t):
+        return np.vstack([t[0].astype(np.float64), t[1].astype(np.float64), t[2] / 5.0])
+
+    tr, te = loadData(RatingData(arr(ml1m['train'])), P.batch, 24), loadData(RatingData(arr(ml1m['test'])), P.batch, 24, False)
+    sc = Scratch(P, 'mf')
+    torch.manual_seed(42)
+    m = sc.train(tr, te, [], 0, '')
+    check('full', m.user_mat.weight, m.item_mat.weight)
+    np.testing.assert_allclose(sc.log['train_loss'], g['full_train_loss'], rtol=1e-4)
+    np.testing.assert_allclose([sc.log['test_rmse'][0], sc.log['test_ndcg'][0], sc.log['test_hr'][0]], g['full_test'], rtol=1e-4)
+
+    S = 5
+    shard_of, groups = synth.uniform_shards(P.n_user, S)
+    trd = [loadData(RatingData(np.vstack(p)), P.batch, 24) for p in synth.split_shards(ml1m['train'], shard_of, S)]
+    parts_te = synth.split_shards(ml1m['test'], shard_of, S)
+    ted = [loadData(RatingData(np.vstack(p)), P.batch, 24, False) for p in parts_te]
+    tot = loadData(RatingData(np.vstack(O.hstack(parts_te))), P.batch, 24, False)
+    for par in (False, True):
+        P.parallel = par
+        out = tmp_path / f'par{int(par)}'
+        out.mkdir()
+        sisa = Sisa(P, 'mf', S, groups)
+        torch.manual_seed(42)
+        ml = sisa.learn(trd, ted, tot, 0, str(out))
+        for i in range(S):
+            check(f'sisa{i}', np.load(out / f'user_mat{i + 1}.npy'), ml[i].item_mat.weight)
+        assert rel(ml[0].user_mat.weight.detach().cpu().numpy()[g['rows_u']], g['sisa_merged_rows']) < 1e-4
+        np.testing.assert_allclose([sisa.log0['total_rmse'], sisa.log0['total_ndcg'], sisa.log0['total_hr']], g['sisa_log0'], rtol=1e-4)
+        for key in ('train_loss', 'test_rmse', 'test_ndcg', 'test_hr', 'total_rmse', 'total_ndcg', 'total_hr'):
+            np.testing.assert_allclose(sisa.log[key], g['sisa_log_' + key], rtol=1e-4, err_msg=key)

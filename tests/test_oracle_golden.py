@@ -138,3 +138,34 @@ def test_ot_cluster_matches_reference(k):
     assert np.array_equal(trace[-1]['dist'].T, g[tag + '_last_dist'])
     assert np.array_equal(label, g[tag + '_label'])
     assert np.float64(inertia) == g[tag + '_inertia']
+
+
+def _ml1m_inputs():
+    from ultrare_amd import synth
+    g = np.load(os.path.join(G, 'ml1m_synth.npz'))
+    data = synth.make_dataset(**synth.ML1M, seed=int(g['seed']))
+    assert len(data['train'][0]) == int(g['n_train']) and len(data['test'][0]) == int(g['n_test'])
+    assert int((data['train'][0] * 7 + data['train'][1]).sum()) == int(g['train_check'])      # same generator output
+    return g, data
+
+
+def _check_rows(g, tag, U, V, tol):
+    assert rel(U[g['rows_u']], g[tag + '_U_rows']) < tol and rel(V[g['rows_i']], g[tag + '_V_rows']) < tol
+    assert abs(float(np.abs(U.astype(np.float64)).sum()) / float(g[tag + '_U_abs']) - 1) < tol
+    assert abs(float(np.abs(V.astype(np.float64)).sum()) / float(g[tag + '_V_abs']) - 1) < tol
+
+
+def test_ml1m_size_full_mf_matches_reference():
+    """BASELINE configs[0] shape (6040 x 3416, 896,914 rows, d=32, B=30,000), one epoch through the
+    real reference (tests/golden/ml1m_synth.npz) vs the oracle."""
+    from ultrare_amd import synth
+    g, data = _ml1m_inputs()
+    full = np.zeros(data['n_user'], dtype=np.int64)
+    train = synth.split_shards(data['train'], full, 1)[0]
+    test = synth.split_shards(data['test'], full, 1)[0]
+    h = O.Hyper(k=32, batch=30000, epochs=1)
+    torch.manual_seed(h.seed)
+    U, V, log = O.scratch_train(h, data['n_user'], data['n_item'], train, test)
+    _check_rows(g, 'full', U, V, 5e-6)
+    np.testing.assert_allclose(log['train_loss'], g['full_train_loss'], rtol=1e-5)
+    np.testing.assert_allclose([log['test_rmse'][0], log['test_ndcg'][0], log['test_hr'][0]], g['full_test'], rtol=1e-4)
