@@ -45,6 +45,10 @@ constexpr int kSuper = 4;       // 64-slot chunks scanned together on the wave /
 constexpr int kQueue = 512;     // per-wave match queue: ring of 512 on the wave path,
                                 // 64/LPR private queues of 8*LPR on the group path
 constexpr int kSegPerLane = 8;  // slots one lane scans per segment on the group path
+#ifndef URE_GROUP_BATCH
+#define URE_GROUP_BATCH 6
+#endif
+constexpr int kGB = URE_GROUP_BATCH; // table rows a lane group gathers together on the group path
 
 __device__ __forceinline__ int shard_steps(const ure_shard_t &S) { return (S.N + S.batch - 1) / S.batch; }
 
@@ -194,24 +198,24 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
                 }
                 __builtin_amdgcn_wave_barrier();
                 // every group walks its own queue in order, four gathers in flight
-                for (int t0 = 0; __any(t0 < qn); t0 += 4) {
-                    int o[4];
-                    float r[4];
-                    bool act[4];
-                    float4 v[4];
+                for (int t0 = 0; __any(t0 < qn); t0 += kGB) {
+                    int o[kGB];
+                    float r[kGB];
+                    bool act[kGB];
+                    float4 v[kGB];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < kGB; ++k) {
                         act[k] = t0 + k < qn;
                         o[k] = act[k] ? gq[t0 + k] : 0;
                         r[k] = act[k] ? gr[t0 + k] : 0.f;
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < kGB; ++k) {
                         v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (act[k]) v[k] = *reinterpret_cast<const float4 *>(other + (size_t)o[k] * D + sub * 4);
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < kGB; ++k) {
                         float p = w.x * v[k].x;
                         p = fmaf(w.y, v[k].y, p);
                         p = fmaf(w.z, v[k].z, p);
