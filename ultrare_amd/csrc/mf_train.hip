@@ -45,10 +45,6 @@ constexpr int kSuper = 4;       // 64-slot chunks scanned together on the wave /
 constexpr int kQueue = 512;     // per-wave match queue: ring of 512 on the wave path,
                                 // 64/LPR private queues of 8*LPR on the group path
 constexpr int kSegPerLane = 8;  // slots one lane scans per segment on the group path
-#ifndef URE_GROUP_BATCH
-#define URE_GROUP_BATCH 6
-#endif
-constexpr int kGB = URE_GROUP_BATCH; // table rows a lane group gathers together on the group path
 
 __device__ __forceinline__ int shard_steps(const ure_shard_t &S) { return (S.N + S.batch - 1) / S.batch; }
 
@@ -59,6 +55,10 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     constexpr int G = kWave / LPR;           // table rows one wave instruction gathers
     constexpr int R4 = 4 * G;
     constexpr int CAP = kSegPerLane * LPR;   // group path: slots per segment = queue capacity per group
+    // table rows a lane group gathers together on the group path: six while rows are narrow (swept on
+    // hardware: 18.5 us vs 18.9 at four, 19.7 at eight for d = 32); four for wide rows, where the
+    // extra registers cost occupancy (d = 128: 1.55 ms vs 1.34 ms per launch of the 25 M workload)
+    constexpr int kGB = LPR <= 8 ? 6 : 4;
     // one raw LDS block: the row paths use it as match queues, the tag riders overlay their own
     // arrays on it (tag_prep.h)
     constexpr int kQueueBytes = kWavesPerBlock * kQueue * 8;
