@@ -45,13 +45,18 @@ constexpr int kSuper = 4;       // 64-slot chunks scanned together on the wave /
 constexpr int kQueue = 512;     // per-wave match queue: ring of 512 on the wave path,
                                 // 64/LPR private queues of 8*LPR on the group path
 constexpr int kSegPerLane = 8;  // slots one lane scans per segment on the group path
+#ifndef URE_WIDE_V4
+#define URE_WIDE_V4 2
+#endif
+constexpr int kWideV4 = URE_WIDE_V4;  // float4 pieces per lane for rows wider than 64 floats
 
 __device__ __forceinline__ int shard_steps(const ure_shard_t &S) { return (S.N + S.batch - 1) / S.batch; }
 
-template <int LPR>
+template <int LPR, int V4>
 __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__restrict__ shards, int64_t tick, int shard_fast)
 {
-    constexpr int D = LPR * 4;
+    constexpr int D = LPR * V4 * 4;          // row width: LPR lanes x V4 float4 per lane
+    using Row = RowVec<V4>;
     constexpr int G = kWave / LPR;           // table rows one wave instruction gathers
     constexpr int R4 = 4 * G;
     constexpr int CAP = kSegPerLane * LPR;   // group path: slots per segment = queue capacity per group
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     constexpr int kQueueBytes = kWavesPerBlock * kQueue * 8;
     static_assert(kTagLds <= kQueueBytes, "tag phases must fit in the queue space");
     __shared__ __attribute__((aligned(16))) char lds_raw[kQueueBytes];
-    __shared__ float4 part_acc[kWavesPerBlock][LPR];
+    __shared__ float4 part_acc[kWavesPerBlock][V4][LPR];
     __shared__ float part_sse[kWavesPerBlock];
     int (*q_oid)[kQueue] = reinterpret_cast<int (*)[kQueue]>(lds_raw);
     float (*q_r)[kQueue] = reinterpret_cast<float (*)[kQueue]>(lds_raw + kWavesPerBlock * kQueue * 4);
@@ -94,18 +99,25 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
 
     // torch.optim.SGD single-tensor path: g = g + lam*w ; buf = mu*buf + g (buf = g on the
     // first step) ; w = w - lr*buf.   Writes buf and the step-(t+1) weights of one row slice.
-    auto sgd_update = [&](const float4 &w, const float4 &m4, const float4 &acc, float *mom_p, float *next_p) {
-        float4 g, wn;
-        g.x = fmaf(lam, w.x, acc.x); g.y = fmaf(lam, w.y, acc.y);
-        g.z = fmaf(lam, w.z, acc.z); g.w = fmaf(lam, w.w, acc.w);
-        if (!first) {
-            g.x = __fadd_rn(__fmul_rn(mu, m4.x), g.x); g.y = __fadd_rn(__fmul_rn(mu, m4.y), g.y);
-            g.z = __fadd_rn(__fmul_rn(mu, m4.z), g.z); g.w = __fadd_rn(__fmul_rn(mu, m4.w), g.w);
+    auto sgd_update = [&](const Row &wr, const Row &mr, const Row &ar, float *mom_row, float *next_row) {
+        Row gr, nr;
+#pragma unroll
+        for (int i = 0; i < V4; ++i) {
+            const float4 w = wr.q[i], m4 = mr.q[i], acc = ar.q[i];
+            float4 g, wn;
+            g.x = fmaf(lam, w.x, acc.x); g.y = fmaf(lam, w.y, acc.y);
+            g.z = fmaf(lam, w.z, acc.z); g.w = fmaf(lam, w.w, acc.w);
+            if (!first) {
+                g.x = __fadd_rn(__fmul_rn(mu, m4.x), g.x); g.y = __fadd_rn(__fmul_rn(mu, m4.y), g.y);
+                g.z = __fadd_rn(__fmul_rn(mu, m4.z), g.z); g.w = __fadd_rn(__fmul_rn(mu, m4.w), g.w);
+            }
+            wn.x = fmaf(-lr, g.x, w.x); wn.y = fmaf(-lr, g.y, w.y);
+            wn.z = fmaf(-lr, g.z, w.z); wn.w = fmaf(-lr, g.w, w.w);
+            gr.q[i] = g;
+            nr.q[i] = wn;
         }
-        wn.x = fmaf(-lr, g.x, w.x); wn.y = fmaf(-lr, g.y, w.y);
-        wn.z = fmaf(-lr, g.z, w.z); wn.w = fmaf(-lr, g.w, w.w);
-        *reinterpret_cast<float4 *>(mom_p) = g;
-        *reinterpret_cast<float4 *>(next_p) = wn;
+        row_store<LPR, V4>(mom_row, sub, gr);
+        row_store<LPR, V4>(next_row, sub, nr);
     };
 
     // Schedule prefixes -> block ranges:
@@ -142,11 +154,11 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
         int4 ds = make_int4(0, 0, 0, 0);
         if (have) ds = sched[idx];
         const bool is_user = ds.x < S.n_user;
-        const size_t row_off = (size_t)(is_user ? ds.x : ds.x - S.n_user) * D + sub * 4;
-        float4 w = make_float4(0.f, 0.f, 0.f, 0.f), m4 = w, acc = w;
+        const size_t row_off = (size_t)(is_user ? ds.x : ds.x - S.n_user) * D;
+        Row w = row_zero<V4>(), m4 = w, acc = w;
         if (have) {
-            w = *reinterpret_cast<const float4 *>((is_user ? S.U[cur] : S.V[cur]) + row_off);
-            if (!first) m4 = *reinterpret_cast<const float4 *>((is_user ? S.mU : S.mV) + row_off);
+            w = row_load<LPR, V4>((is_user ? S.U[cur] : S.V[cur]) + row_off, sub);
+            if (!first) m4 = row_load<LPR, V4>((is_user ? S.mU : S.mV) + row_off, sub);
         }
         float sse = 0.f;
         if (!dense_only) {
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
                     int o[kGB];
                     float r[kGB];
                     bool act[kGB];
-                    float4 v[kGB];
+                    Row v[kGB];
 #pragma unroll
                     for (int k = 0; k < kGB; ++k) {
                         act[k] = t0 + k < qn;
@@ -211,23 +223,16 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
                     }
 #pragma unroll
                     for (int k = 0; k < kGB; ++k) {
-                        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (act[k]) v[k] = *reinterpret_cast<const float4 *>(other + (size_t)o[k] * D + sub * 4);
+                        v[k] = row_zero<V4>();
+                        if (act[k]) v[k] = row_load<LPR, V4>(other + (size_t)o[k] * D, sub);
                     }
 #pragma unroll
                     for (int k = 0; k < kGB; ++k) {
-                        float p = w.x * v[k].x;
-                        p = fmaf(w.y, v[k].y, p);
-                        p = fmaf(w.z, v[k].z, p);
-                        p = fmaf(w.w, v[k].w, p);
-                        p = group_sum<LPR>(p);
+                        const float p = group_sum<LPR>(row_dot<V4>(w, v[k]));
                         const float e = p - r[k];
                         const float ge = act[k] ? 2.0f * e : 0.0f;
                         if (act[k]) sse = fmaf(e, e, sse);
-                        acc.x = fmaf(ge, v[k].x, acc.x);
-                        acc.y = fmaf(ge, v[k].y, acc.y);
-                        acc.z = fmaf(ge, v[k].z, acc.z);
-                        acc.w = fmaf(ge, v[k].w, acc.w);
+                        row_axpy<V4>(acc, ge, v[k]);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -255,12 +260,12 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     float *__restrict__ mom = is_user ? S.mU : S.mV;
     const float *__restrict__ other = is_user ? S.V[cur] : S.U[cur];
 
-    const size_t row_off = (size_t)row * D + sub * 4;
+    const size_t row_off = (size_t)row * D;
     const int beg = ds.y, end = ds.z;
-    const float4 w = *reinterpret_cast<const float4 *>(w_cur + row_off);
-    float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!first && lane < LPR && wir == 0) m4 = *reinterpret_cast<const float4 *>(mom + row_off);   // early: hides under the scan
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const Row w = row_load<LPR, V4>(w_cur + row_off, sub);
+    Row m4 = row_zero<V4>();
+    if (!first && lane < LPR && wir == 0) m4 = row_load<LPR, V4>(mom + row_off, sub);   // early: hides under the scan
+    Row acc = row_zero<V4>();
     float sse = 0.f;
     int qh = 0, qt = 0;
 
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
         int o[4];
         float r[4];
         bool act[4];
-        float4 v[4];
+        Row v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int idx = head + k * G + grp;
@@ -280,23 +285,16 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (act[k]) v[k] = *reinterpret_cast<const float4 *>(other + (size_t)o[k] * D + sub * 4);
+            v[k] = row_zero<V4>();
+            if (act[k]) v[k] = row_load<LPR, V4>(other + (size_t)o[k] * D, sub);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float p = w.x * v[k].x;
-            p = fmaf(w.y, v[k].y, p);
-            p = fmaf(w.z, v[k].z, p);
-            p = fmaf(w.w, v[k].w, p);
-            p = group_sum<LPR>(p);
+            const float p = group_sum<LPR>(row_dot<V4>(w, v[k]));
             const float e = p - r[k];
             const float ge = act[k] ? 2.0f * e : 0.0f;
             if (act[k] && sub == 0) sse = fmaf(e, e, sse);
-            acc.x = fmaf(ge, v[k].x, acc.x);
-            acc.y = fmaf(ge, v[k].y, acc.y);
-            acc.z = fmaf(ge, v[k].z, acc.z);
-            acc.w = fmaf(ge, v[k].w, acc.w);
+            row_axpy<V4>(acc, ge, v[k]);
         }
     };
 
@@ -339,23 +337,33 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
         qh += R4;
     }
 
-    acc.x = cross_group_sum<LPR>(acc.x);
-    acc.y = cross_group_sum<LPR>(acc.y);
-    acc.z = cross_group_sum<LPR>(acc.z);
-    acc.w = cross_group_sum<LPR>(acc.w);
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        acc.q[i].x = cross_group_sum<LPR>(acc.q[i].x);
+        acc.q[i].y = cross_group_sum<LPR>(acc.q[i].y);
+        acc.q[i].z = cross_group_sum<LPR>(acc.q[i].z);
+        acc.q[i].w = cross_group_sum<LPR>(acc.q[i].w);
+    }
     sse = wave_sum(sse);
 
     if (heavy) {   // block-uniform branch: all four waves of a heavy row arrive
-        if (lane < LPR) part_acc[wave][lane] = acc;
+        if (lane < LPR) {
+#pragma unroll
+            for (int i = 0; i < V4; ++i) part_acc[wave][i][lane] = acc.q[i];
+        }
         if (lane == 0) part_sse[wave] = sse;
         __syncthreads();
         if (wave != 0) return;
         if (lane < LPR) {
-            acc = part_acc[0][lane];
 #pragma unroll
-            for (int k = 1; k < kWavesPerBlock; ++k) {
-                const float4 t = part_acc[k][lane];
-                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            for (int i = 0; i < V4; ++i) {
+                float4 a4 = part_acc[0][i][lane];
+#pragma unroll
+                for (int k = 1; k < kWavesPerBlock; ++k) {
+                    const float4 t = part_acc[k][i][lane];
+                    a4.x += t.x; a4.y += t.y; a4.z += t.z; a4.w += t.w;
+                }
+                acc.q[i] = a4;
             }
         }
         sse = 0.f;
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void materialize_rows_kernel(const ure_shar
     }
 }
 
-template <int LPR>
+template <int LPR, int V4>
 static void launch_step(const ure_job *job, int64_t tick, hipStream_t st)
 {
     // grid.x = the largest need of any shard AT THIS TICK (row workgroups + the tag riders its
@@ -446,7 +454,7 @@ static void launch_step(const ure_job *job, int64_t tick, hipStream_t st)
     }
     const int shard_fast = job->shard_fast && blocks <= 65535;
     dim3 grid = shard_fast ? dim3((unsigned)job->host.size(), (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)job->host.size());
-    hipLaunchKernelGGL(mf_step_kernel<LPR>, grid, dim3(kBlock), 0, st, job->dev, tick, shard_fast);
+    hipLaunchKernelGGL((mf_step_kernel<LPR, V4>), grid, dim3(kBlock), 0, st, job->dev, tick, shard_fast);
 }
 
 }  // namespace ure
@@ -473,7 +481,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
         if (steps > 65534) { delete job; return fail(-1, "ure_job_create: shard %d needs %lld steps/epoch (> 65534)", k, (long long)steps); }
         job->ticks = std::max(job->ticks, steps * S.epochs);
-        const int per_wave = kWave / (S.d / 4);
+        const int per_wave = kWave / (S.d <= 64 ? S.d / 4 : S.d / (4 * kWideV4));   // rows per wave = 64 / LPR (launch table in train_ticks)
         const int per_block = per_wave * kWavesPerBlock;
         const int blocks = S.n_block + (S.n_wave - S.n_block + kWavesPerBlock - 1) / kWavesPerBlock +
                            (S.n_active - S.n_wave + per_block - 1) / per_block + (S.lazy_rows ? 0 : (n_rows - S.n_active + per_block - 1) / per_block);
@@ -550,14 +558,14 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
             if (int rc = mark(assign_ev)) return rc;
         }
         if (int rc = mark(step_ev)) return rc;
-        switch (job->d / 4) {
-            case 1: launch_step<1>(job, t, st); break;
-            case 2: launch_step<2>(job, t, st); break;
-            case 4: launch_step<4>(job, t, st); break;
-            case 8: launch_step<8>(job, t, st); break;
-            case 16: launch_step<16>(job, t, st); break;
-            case 32: launch_step<32>(job, t, st); break;
-            case 64: launch_step<64>(job, t, st); break;
+        switch (job->d) {      // d <= 64: one float4 per lane; wider rows: two (more bytes in flight per wave)
+            case 4: launch_step<1, 1>(job, t, st); break;
+            case 8: launch_step<2, 1>(job, t, st); break;
+            case 16: launch_step<4, 1>(job, t, st); break;
+            case 32: launch_step<8, 1>(job, t, st); break;
+            case 64: launch_step<16, 1>(job, t, st); break;
+            case 128: launch_step<128 / (4 * kWideV4), kWideV4>(job, t, st); break;
+            case 256: launch_step<256 / (4 * kWideV4), kWideV4>(job, t, st); break;
             default: return fail(-1, "ure_job_train: unsupported d=%d", job->d);
         }
         if (int rc = mark(step_ev)) return rc;

@@ -56,6 +56,63 @@ struct ure_job {
 bool tag_prep_needed(const ure_job *job, int64_t tick);
 void launch_tag_prep(const ure_job *job, int64_t tick, hipStream_t st);
 
+// A lane's share of a table row: V4 float4 pieces.  Lane `sub` of the LPR lanes that share a row
+// owns float4 columns sub, sub + LPR, ... so that every load / store instruction of the group
+// covers one contiguous run of LPR * 16 bytes.  Row width d = LPR * V4 * 4.
+template <int V4>
+struct RowVec {
+    float4 q[V4];
+};
+template <int V4>
+__device__ __forceinline__ RowVec<V4> row_zero()
+{
+    RowVec<V4> r;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) r.q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return r;
+}
+template <int LPR, int V4>
+__device__ __forceinline__ RowVec<V4> row_load(const float *row, int sub)
+{
+    RowVec<V4> r;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) r.q[i] = *reinterpret_cast<const float4 *>(row + (i * LPR + sub) * 4);
+    return r;
+}
+template <int LPR, int V4>
+__device__ __forceinline__ void row_store(float *row, int sub, const RowVec<V4> &v)
+{
+#pragma unroll
+    for (int i = 0; i < V4; ++i) *reinterpret_cast<float4 *>(row + (i * LPR + sub) * 4) = v.q[i];
+}
+template <int V4>
+__device__ __forceinline__ float row_dot(const RowVec<V4> &a, const RowVec<V4> &b)
+{
+    float p = a.q[0].x * b.q[0].x;
+    p = fmaf(a.q[0].y, b.q[0].y, p);
+    p = fmaf(a.q[0].z, b.q[0].z, p);
+    p = fmaf(a.q[0].w, b.q[0].w, p);
+#pragma unroll
+    for (int i = 1; i < V4; ++i) {
+        p = fmaf(a.q[i].x, b.q[i].x, p);
+        p = fmaf(a.q[i].y, b.q[i].y, p);
+        p = fmaf(a.q[i].z, b.q[i].z, p);
+        p = fmaf(a.q[i].w, b.q[i].w, p);
+    }
+    return p;
+}
+template <int V4>
+__device__ __forceinline__ void row_axpy(RowVec<V4> &acc, float s, const RowVec<V4> &v)
+{
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        acc.q[i].x = fmaf(s, v.q[i].x, acc.q[i].x);
+        acc.q[i].y = fmaf(s, v.q[i].y, acc.q[i].y);
+        acc.q[i].z = fmaf(s, v.q[i].z, acc.q[i].z);
+        acc.q[i].w = fmaf(s, v.q[i].w, acc.q[i].w);
+    }
+}
+
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // Sum over the LPR consecutive lanes that share one table row (LPR = d/4 lanes,
