@@ -45,10 +45,11 @@ constexpr int kSuper = 4;       // 64-slot chunks scanned together on the wave /
 constexpr int kQueue = 512;     // per-wave match queue: ring of 512 on the wave path,
                                 // 64/LPR private queues of 8*LPR on the group path
 constexpr int kSegPerLane = 8;  // slots one lane scans per segment on the group path
-#ifndef URE_WIDE_V4
-#define URE_WIDE_V4 2
-#endif
-constexpr int kWideV4 = URE_WIDE_V4;  // float4 pieces per lane for rows wider than 64 floats
+// Lanes that share a table row.  Up to d = 32 every lane holds one float4; wider rows give every
+// lane two (d = 64: 8 lanes, 128: 16, 256: 32), which doubles the rows -- and the bytes in flight --
+// per wavefront.  Measured (us per launch): d = 64, 8 shards: 29.3 -> 26.2; d = 128, 25 M workload:
+// 1327 -> 1206; four pieces per lane at d = 128: 1530; two pieces at d = 32: 24.9 vs 18.6.
+__host__ __device__ constexpr int lanes_per_row(int d) { return d <= 32 ? d / 4 : d / 8; }
 
 __device__ __forceinline__ int shard_steps(const ure_shard_t &S) { return (S.N + S.batch - 1) / S.batch; }
 
@@ -481,7 +482,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
         if (steps > 65534) { delete job; return fail(-1, "ure_job_create: shard %d needs %lld steps/epoch (> 65534)", k, (long long)steps); }
         job->ticks = std::max(job->ticks, steps * S.epochs);
-        const int per_wave = kWave / (S.d <= 64 ? S.d / 4 : S.d / (4 * kWideV4));   // rows per wave = 64 / LPR (launch table in train_ticks)
+        const int per_wave = kWave / lanes_per_row(S.d);
         const int per_block = per_wave * kWavesPerBlock;
         const int blocks = S.n_block + (S.n_wave - S.n_block + kWavesPerBlock - 1) / kWavesPerBlock +
                            (S.n_active - S.n_wave + per_block - 1) / per_block + (S.lazy_rows ? 0 : (n_rows - S.n_active + per_block - 1) / per_block);
@@ -558,14 +559,14 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
             if (int rc = mark(assign_ev)) return rc;
         }
         if (int rc = mark(step_ev)) return rc;
-        switch (job->d) {      // d <= 64: one float4 per lane; wider rows: two (more bytes in flight per wave)
+        switch (job->d) {
             case 4: launch_step<1, 1>(job, t, st); break;
             case 8: launch_step<2, 1>(job, t, st); break;
             case 16: launch_step<4, 1>(job, t, st); break;
             case 32: launch_step<8, 1>(job, t, st); break;
-            case 64: launch_step<16, 1>(job, t, st); break;
-            case 128: launch_step<128 / (4 * kWideV4), kWideV4>(job, t, st); break;
-            case 256: launch_step<256 / (4 * kWideV4), kWideV4>(job, t, st); break;
+            case 64: launch_step<8, 2>(job, t, st); break;
+            case 128: launch_step<16, 2>(job, t, st); break;
+            case 256: launch_step<32, 2>(job, t, st); break;
             default: return fail(-1, "ure_job_train: unsupported d=%d", job->d);
         }
         if (int rc = mark(step_ev)) return rc;
