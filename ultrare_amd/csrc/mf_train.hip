@@ -134,18 +134,19 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     // read (materialize_rows_kernel) instead of being streamed through HBM every step
     const int nbD = S.lazy_rows ? 0 : (n_rows - S.n_active + kWavesPerBlock * G - 1) / (kWavesPerBlock * G);
     // While epoch e trains, its steps 0, 1, 2 carry the three phases of epoch e+1's batch tags as
-    // extra workgroups at the front of the grid (tag_prep.h); the launch boundary between steps
+    // extra workgroups at the end of the grid (tag_prep.h); the launch boundary between steps
     // orders the phases.
     const int nbR = tag_rider_blocks(S.N, S.n_slots, steps, s, epoch + 1 < S.epochs);
-    if (wg < nbR) {
-        if (s == 0) tag_partition(S, epoch + 1, wg, lds_raw);
-        else if (s == 1) tag_collect(S, wg, lds_raw);
-        else tag_derive(S, epoch + 1, wg, nbR);
+    const int nbRows = nbB + nbW + nbG + nbD;
+    const int blk = wg;
+    if (blk >= nbRows) {        // the riders come LAST: the longest row chains start first, the short rider
+        const int rb = blk - nbRows;   // workgroups fill the tail of the launch
+        if (rb >= nbR) return;
+        if (s == 0) tag_partition(S, epoch + 1, rb, lds_raw);
+        else if (s == 1) tag_collect(S, rb, lds_raw);
+        else tag_derive(S, epoch + 1, rb, nbR);
         return;
     }
-    const int blk = wg - nbR;
-
-    if (blk >= nbB + nbW + nbG + nbD) return;
     if (blk >= nbB + nbW) {
         // ------------------------------------------------ group path and decay-only path
         const bool dense_only = blk >= nbB + nbW + nbG;
