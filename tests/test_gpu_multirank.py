@@ -1,0 +1,93 @@
+"""The N > 1 path end to end on hardware: two ranks (gloo process group, both on the one
+visible GPU) run Sisa.learn / Sisa.unlearn shard-parallel -- shards placed by LPT, every rank
+replaying the RNG stream, isolated training, one broadcast of the trained tables, per-epoch logs
+gathered -- and must reproduce the single-process results and the reference goldens.
+(The production backend is RCCL; only the transport differs here.)"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, 'tests', 'golden')
+
+_WORKER = r'''
+import copy, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ultrare_amd.method.sisa import Sisa, assign_shards
+from ultrare_amd.read import RatingData, loadData, readRating
+out, S, E = sys.argv[2], 4, 3
+G = os.path.join(sys.argv[1], 'tests', 'golden')
+TRAIN, TEST = os.path.join(G, 'toy', '0_train.csv'), os.path.join(G, 'toy', '0_test.csv')
+torch.cuda.set_device(0)
+dist.init_process_group('gloo')
+rank = dist.get_rank()
+
+class P:
+    k, lam, seed, batch, lr, lr_decay, momentum, epochs, parallel = 16, 0.1, 42, 3000, 0.001, 0.95, 0.9, E, True
+    n_user, n_item = 1508, 2071
+
+def inputs(dels):
+    tr, idx = readRating(TRAIN, 1508, 5, dels, [], S, [])
+    te, _ = readRating(TEST, 1508, 5, [], [], S, idx)
+    return (idx, [loadData(RatingData(a), 3000, 24) for a in tr], [loadData(RatingData(a), 3000, 24, False) for a in te],
+            loadData(RatingData(np.hstack(te)), 3000, 24, False))
+
+idx, trd, ted, tot = inputs([])
+save = os.path.join(out, f'rank{rank}')
+os.makedirs(save, exist_ok=True)
+s = Sisa(P, 'mf', S, idx)
+torch.manual_seed(42)
+ml = s.learn(trd, ted, tot, 0, save)
+g = np.load(os.path.join(G, 'sisa_toy.npz'))
+dels = g['S4_unB_del_user'].tolist()
+idx2, trd2, ted2, tot2 = inputs(dels)
+s2 = Sisa(P, 'mf', S, idx2)
+torch.manual_seed(42)
+ml2 = s2.unlearn([copy.deepcopy(m) for m in ml], trd2, ted2, tot2, dels, 0, save)
+np.savez(os.path.join(out, f'res{rank}.npz'),
+         owner=assign_shards([len(d.dataset) for d in trd], 2),
+         merged=ml[0].user_mat.weight.detach().cpu().numpy(), un_merged=ml2[0].user_mat.weight.detach().cpu().numpy(),
+         log0=[s.log0['total_rmse'], s.log0['total_ndcg'], s.log0['total_hr']],
+         un_log0=[s2.log0['total_rmse'], s2.log0['total_ndcg'], s2.log0['total_hr']],
+         **{f'V{i}': ml[i].item_mat.weight.detach().cpu().numpy() for i in range(S)},
+         **{f'unV{i}': ml2[i].item_mat.weight.detach().cpu().numpy() for i in range(S)},
+         **{'log_' + k: np.asarray(v, dtype=np.float64) for k, v in s.log.items() if k != 'time'},
+         **{'unlog_' + k: np.asarray(v, dtype=np.float64) for k, v in s2.log.items() if k != 'time'})
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_share_one_gpu(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29641', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=500) == 0
+    r0, r1 = np.load(tmp_path / 'res0.npz'), np.load(tmp_path / 'res1.npz')
+    g = np.load(os.path.join(G, 'sisa_toy.npz'))
+    assert sorted(set(r0['owner'].tolist())) == [0, 1]                     # both ranks trained something
+    for key in r0.files:                                                   # every rank ends with the same state
+        assert np.array_equal(r0[key], r1[key]), key
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / np.abs(b).max())
+    for i in range(4):
+        assert rel(r0[f'V{i}'], g[f'S4_learn_V{i}']) < 1e-4
+        assert rel(r0[f'unV{i}'], g[f'S4_unB_V{i}']) < 1e-4
+    assert rel(r0['merged'], g['S4_learn_Umerged']) < 1e-4 and rel(r0['un_merged'], g['S4_unB_Umerged']) < 1e-4
+    np.testing.assert_allclose(r0['log0'], g['S4_learn_log0'], rtol=1e-4)
+    np.testing.assert_allclose(r0['un_log0'], g['S4_unB_log0'], rtol=1e-4)
+    for key in ('train_loss', 'test_rmse', 'test_ndcg', 'test_hr', 'total_rmse', 'total_ndcg', 'total_hr'):
+        np.testing.assert_allclose(r0['log_' + key], g['S4_learn_log_' + key], rtol=1e-4, err_msg=key)
+    for key in ('train_loss', 'test_rmse', 'total_rmse', 'total_ndcg', 'total_hr'):
+        np.testing.assert_allclose(r0['unlog_' + key], g['S4_unB_log_' + key], rtol=1e-4, err_msg=key)
+    # only rank 0 writes artifacts (scratch.py:131-144)
+    assert os.path.exists(tmp_path / 'rank0' / 'user_mat4.npy') and os.path.exists(tmp_path / 'rank0' / 'log0.npy')
+    assert not os.path.exists(tmp_path / 'rank1' / 'user_mat4.npy')
