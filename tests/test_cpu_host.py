@@ -329,3 +329,54 @@ def test_two_rank_protocol_over_gloo(tmp_path):
     for i in range(3):
         src = r0 if int(r0['owner'][i]) == 0 else r1
         assert np.array_equal(src[f'perm{i}'], want[i][2])
+
+
+def test_preprocess_restates_the_notebook(tmp_path):
+    """data/ml1m/pro.ipynb as a function: 5-core filter, id squeeze in first-appearance order,
+    per-user int(0.9 * n) split, checked against a direct pandas restatement of the cells."""
+    import pandas as pd
+    import random
+    from ultrare_amd.preprocess import preprocess
+    rs = np.random.RandomState(0)
+    n = 6000
+    u = rs.zipf(1.3, n) % 300 + 1
+    i = rs.zipf(1.2, n) % 400 + 1
+    df = pd.DataFrame({'uid': u, 'iid': i}).drop_duplicates()
+    df['rating'] = rs.randint(1, 6, len(df))
+    df['ts'] = 0
+    dat = tmp_path / 'ratings.dat'
+    dat.write_text(''.join(f'{a}::{b}::{c}::{d}\n' for a, b, c, d in df.values.tolist()))
+    info = preprocess(str(dat), str(tmp_path / 'out'), seed=5)
+    tr = pd.read_csv(tmp_path / 'out' / 'squ0_train.csv', header=None)
+    te = pd.read_csv(tmp_path / 'out' / 'squ0_test.csv', header=None)
+    # the notebook, cell by cell, in pandas
+    new = df.copy()
+    while True:
+        nf = 0
+        cnt = new.groupby('iid').size()
+        bad = cnt[cnt < 5].index
+        nf += len(bad)
+        new = new[~new.iid.isin(bad)]
+        cnt = new.groupby('uid').size()
+        bad = cnt[cnt < 5].index
+        nf += len(bad)
+        new = new[~new.uid.isin(bad)]
+        if nf == 0:
+            break
+    new = new.reset_index(drop=True)
+    new.uid -= 1
+    new.uid = new.uid.map({o: k for k, o in enumerate(new.uid.unique())})
+    new.iid = new.iid.map({o: k for k, o in enumerate(new.iid.unique())})
+    new = new.sort_values(by=['uid', 'iid']).reset_index(drop=True)
+    rng = random.Random(5)
+    tri = []
+    for uu in range(len(new.uid.unique())):
+        idx = new[new.uid == uu].index.to_list()
+        tri.extend(rng.sample(idx, int(len(idx) * 0.9)))
+    want_tr = new.iloc[np.sort(np.array(tri)), :]
+    want_te = new.drop(index=want_tr.index)
+    assert info['n_train'] == len(want_tr) == len(tr) and info['n_test'] == len(want_te) == len(te)
+    assert np.array_equal(tr[[0, 1]].values, want_tr[['uid', 'iid']].values)
+    assert np.array_equal(te[[0, 1]].values, want_te[['uid', 'iid']].values)
+    assert np.array_equal(tr[2].values, want_tr['rating'].values.astype(np.float16).astype(float))
+    assert info['n_user'] == len(new.uid.unique()) and info['n_item'] == len(new.iid.unique())
