@@ -9,8 +9,8 @@
 //   * One optimizer step = ONE kernel.  A wavefront owns a destination row (a user
 //     row of U or an item row of V).  It walks that row's CSR segment, keeps the
 //     entries whose batch number equals this step's, gathers the opposite table's
-//     row for each (16 B per lane, d/4 lanes per row, 64/(d/4) entries in flight per
-//     wave instruction), recomputes the error e = <u,v> - r and accumulates
+//     row for each (one or two 16-byte pieces per lane, LPR = lanes_per_row(d) lanes per
+//     row, 64/LPR rows per wave instruction), recomputes the error e = <u,v> - r and accumulates
 //     2e * other_row in registers.  The full gradient row therefore never leaves
 //     the wavefront: the SGD-momentum-L2 update is applied immediately and the row
 //     is written once into the *other* half of a ping-pong weight pair, so gathers
@@ -18,16 +18,17 @@
 //     the result is bitwise reproducible run to run.
 //   * Work is sized to the row: the heaviest rows get a whole 4-wave workgroup (partial
 //     sums meet in LDS in a fixed order), medium rows one wavefront, and the many small
-//     rows one LANE GROUP each (d/4 lanes), so a wavefront advances 64/(d/4) rows at
-//     once with private accumulators and no cross-lane reduction; rows the shard never
-//     touches only decay and are updated 64/(d/4) per wave instruction.  The kernel is
-//     bound by dependent-load latency at ml-1m scale, so every path issues its
-//     independent loads (tags, ids, ratings; four row gathers) together.
+//     rows one LANE GROUP each (LPR lanes), so a wavefront advances 64/LPR rows at once
+//     with private accumulators and no cross-lane reduction; rows the shard never touches
+//     only decay: they are advanced in closed form when the tables are read (lazy_rows) or
+//     updated 64/LPR per wave instruction.  The kernel is bound by dependent-load latency
+//     at ml-1m scale, so every path issues its independent loads (tags, ids, ratings; four
+//     to six row gathers) together.
 //   * Row segments live in one slot array in schedule order, 8-aligned and padded, so
 //     a lane scans 8 slots with one 16-byte load per array.
 //   * Batch membership is a 2-byte tag per slot, double-buffered by epoch parity; the
 //     first three steps of an epoch carry the preparation of the next epoch's tags as
-//     extra workgroups (tag_prep.h).
+//     extra workgroups at the end of the grid (tag_prep.h).
 //   * Shards are independent (sisa.py:33-36), so a job's shards share each launch
 //     (blockIdx.x = shard): one tick advances every shard by one optimizer step.
 //
