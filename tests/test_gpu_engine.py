@@ -74,6 +74,15 @@ def test_step_kernel_vs_oracle(toy, k, batch, thr):
     np.testing.assert_allclose(np.sqrt(job.epoch_sse(0) / len(train[0])), losses, rtol=1e-5)
 
 
+def test_out_of_order_ticks_are_refused(toy):
+    import ctypes
+    from ultrare_amd import _native as nv
+    train, _ = toy
+    _, _, job, _ = _train_gpu(train, 16, 3000, 1)
+    rc = nv.lib().ure_job_train(job._job, 3, 5, nv.stream_handle())
+    assert rc != 0 and b'in order' in nv.lib().ure_last_error()
+
+
 def test_bitwise_reproducible(toy):
     train, _ = toy
     a = _train_gpu(train, 32, 3000, 2)

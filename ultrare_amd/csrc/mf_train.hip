@@ -620,7 +620,11 @@ int ure_job_train(ure_job_t *j, int64_t tick0, int64_t tick1, void *stream)
 {
     auto *job = reinterpret_cast<ure::ure_job *>(j);
     URE_ARG(job && tick0 >= 0 && tick1 >= tick0);
-    return train_ticks(job, tick0, std::min(tick1, job->ticks), static_cast<hipStream_t>(stream), nullptr, nullptr);
+    if (tick0 != job->next_tick) return fail(-1, "ure_job_train: tick0=%lld but the job is at tick %lld (steps must run in order)", (long long)tick0, (long long)job->next_tick);
+    tick1 = std::min(tick1, job->ticks);
+    const int rc = train_ticks(job, tick0, tick1, static_cast<hipStream_t>(stream), nullptr, nullptr);
+    if (rc == 0) job->next_tick = std::max(tick0, tick1);
+    return rc;
 }
 
 int ure_job_train_profiled(ure_job_t *j, int64_t tick0, int64_t tick1, void *stream, double *step_ms, int64_t *n_step,
@@ -628,9 +632,12 @@ int ure_job_train_profiled(ure_job_t *j, int64_t tick0, int64_t tick1, void *str
 {
     auto *job = reinterpret_cast<ure::ure_job *>(j);
     URE_ARG(job && tick0 >= 0 && tick1 >= tick0 && step_ms && n_step && assign_ms && n_assign);
+    if (tick0 != job->next_tick) return fail(-1, "ure_job_train_profiled: tick0=%lld but the job is at tick %lld", (long long)tick0, (long long)job->next_tick);
     hipStream_t st = static_cast<hipStream_t>(stream);
     std::vector<hipEvent_t> se, ae;
-    int rc = train_ticks(job, tick0, std::min(tick1, job->ticks), st, &se, &ae);
+    tick1 = std::min(tick1, job->ticks);
+    int rc = train_ticks(job, tick0, tick1, st, &se, &ae);
+    if (rc == 0) job->next_tick = std::max(tick0, tick1);
     if (rc == 0) {
         hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail((int)e, "ure_job_train_profiled: %s", hipGetErrorString(e));

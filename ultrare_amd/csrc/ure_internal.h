@@ -38,6 +38,7 @@ struct ure_job {
     std::vector<ure_shard_t> host;
     ure_shard_t *dev = nullptr;
     int64_t ticks = 0;
+    int64_t next_tick = 0;               // ticks run so far (steps must run in order)
     std::vector<int> row_blocks;         // per shard: workgroups its rows need in a step launch
     int max_n = 0, max_small_n = 0;
     int64_t max_slots = 0;
