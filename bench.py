@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--d', type=int, default=None)
     ap.add_argument('--batch', type=int, default=30000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-unlearn', action='store_true', help='skip the learn/unlearn wall-time leg')
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU baseline work')
     ap.add_argument('--roofline-steps', type=int, default=3)
     ap.add_argument('--backend', default='nccl', help='process-group backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
@@ -189,6 +190,24 @@ def main():
                          f'{torch.get_num_threads()} torch threads, host has {os.cpu_count()} cpus',
                'prebatched_value': round(pre, 1)}
 
+    # ---- second half of the metric (rank 0, N = 1): Sisa.learn, then Sisa.unlearn after a 2 %
+    # random user deletion, 50 epochs, through the operator surface, wall clock with the per-epoch
+    # evaluations, row merge and final test included (outside the timed region above)
+    unlearn = None
+    if rank == 0 and world == 1 and a.workload == 'ml1m' and not a.no_unlearn:
+        job.close()
+        import importlib.util
+        sp = importlib.util.spec_from_file_location('e2e_sisa', os.path.join(ROOT, 'tools', 'e2e_sisa.py'))
+        e2e = importlib.util.module_from_spec(sp)
+        sp.loader.exec_module(e2e)
+        r = e2e.measure(a.shards, a.d, 50, 1, 2.0, data=data)
+        unlearn = {'learn_wall_s': r['learn_s'], 'unlearn_wall_s': r['unlearn_s'], 'epochs': 50,
+                   'deleted_users': r['deleted_users'], 'retrained_shards': r['retrained_shards'],
+                   'unlearn_interactions': r['unlearn_interactions'],
+                   'includes': 'host RNG + layout, 50 epochs of all retrained shards side by side, per-epoch shard/total '
+                               'evaluations, row merge, final test; inputs as in-memory loaders',
+                   'final_test': {'learn': r['log0'], 'unlearn': r['unlearn_log0']}}
+
     if rank == 0:
         arch = ''
         try:
@@ -199,7 +218,7 @@ def main():
         except Exception:
             pass
         out = {
-            'metric': 'training interactions/sec, ml-1m 5-shard SISA' if a.workload == 'ml1m' else f'training interactions/sec, synthetic ml-25m-scale {a.shards}-shard SISA',
+            'metric': 'training interactions/sec + unlearn retrain wall-time, ml-1m 5-shard SISA' if a.workload == 'ml1m' else f'training interactions/sec, synthetic ml-25m-scale {a.shards}-shard SISA',
             'value': round(n_total / wall, 1), 'unit': 'interactions/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(wall * 1e3 / a.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
@@ -211,7 +230,7 @@ def main():
                        'arch': arch},
             'device_ms_timed': round(dev_ms, 3), 'interactions_timed': n_total,
             'host_rng_prep_s': round(t_rng, 3),
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'cpu_baseline': cpu, 'unlearn': unlearn,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

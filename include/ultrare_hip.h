@@ -65,11 +65,18 @@ typedef struct ure_shard {
     uint32_t      *inv_stage;/* [N] scratch of the inverse's radix partition               */
     int32_t       *inv_off;  /* [R][R+1] scratch, R = ceil(N / 2048) (unused when R > 1024) */
     /* Row schedule, heaviest first: {row id, first slot, end slot (padded), nnz}.
-     * [0, n_block) one workgroup per row | [n_block, n_wave) one wavefront per row |
-     * [n_wave, n_active) one lane group (d/4 lanes) per row | [n_active, rows) rows with
-     * no interaction in this shard: they only decay.                                  */
+     * [0, n_active) rows with interactions in this shard | [n_active, rows) rows with none:
+     * they only decay.                                                                */
     const int32_t *sched;    /* [n_user + n_item][4]                                      */
-    int32_t        n_block, n_wave, n_active;
+    /* Work units of the step kernel (ure_host_build_units, depends on d): one lane group
+     * (d/4 lanes up to d = 32, d/8 beyond) walks one unit = a contiguous piece of one row's
+     * segment, {row id or -1, first slot, end slot, leader | count << 16 | multi << 30}; a
+     * workgroup takes 256 / lanes consecutive units, a row's units never straddle workgroups,
+     * `leader` is the index inside the workgroup of the row's first unit, `count` its number of
+     * units, `multi` is set on every unit of a workgroup that holds a row of several units.  */
+    const int32_t *units;    /* [n_units][4]                                              */
+    int32_t        n_units;  /* multiple of 256 / lanes                                   */
+    int32_t        n_active;
     int64_t        n_slots;
     /* model state (utils.py:31-40, scratch.py:64-69) */
     float *U[2];            /* [n_user][d] ping-pong: step t reads [t&1], writes [(t+1)&1] */
@@ -154,11 +161,15 @@ int ure_host_partition(const int32_t *uid, const int32_t *iid, const double *rat
                        int32_t *out_iid, float *out_rating);
 /* Builds the slot layout of struct ure_shard from a shard's triples: ent_oid / ent_r / ent_src
  * (capacity 2 n + 8 (n_user + n_item) slots, *n_slots receives the used count), sched
- * [n_user + n_item][4], the schedule prefixes, and optionally u_pos / i_pos [n] (slot of each
+ * [n_user + n_item][4], the number of active rows, and optionally u_pos / i_pos [n] (slot of each
  * interaction in its user's / item's segment). */
 int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *rating, int64_t n, int32_t n_user, int32_t n_item,
-                          int32_t block_nnz, int32_t group_nnz, int32_t *ent_oid, float *ent_r, int32_t *ent_src, int32_t *sched,
-                          int64_t *n_slots, int32_t *n_block, int32_t *n_wave, int32_t *n_active, int32_t *u_pos, int32_t *i_pos);
+                          int32_t *ent_oid, float *ent_r, int32_t *ent_src, int32_t *sched,
+                          int64_t *n_slots, int32_t *n_active, int32_t *u_pos, int32_t *i_pos);
+/* Cuts the active rows of a schedule into the work units of struct ure_shard for row width d and
+ * packs them into workgroups.  units == NULL: only *n_units is written (size query); otherwise
+ * `capacity` units may be written. */
+int ure_host_build_units(const int32_t *sched, int32_t n_active, int32_t d, int32_t *units, int64_t capacity, int64_t *n_units);
 
 /* ---------------------------------------------------------------------------
  * Evaluation (baseTest, utils.py:115-187)

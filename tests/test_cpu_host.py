@@ -158,14 +158,13 @@ def test_shard_layout_invariants():
     segment and once in its item's, segments are 8-aligned, padded slots never match."""
     from ultrare_amd.engine import ShardData
     tr = O.partition(*O.load_csv(TRAIN), [list(range(N_USER))])[0]
-    sh = ShardData(*tr, N_USER, N_ITEM, device=torch.device('cpu'), block_nnz=200, group_nnz=40, keep_positions=True)
+    sh = ShardData(*tr, N_USER, N_ITEM, device=torch.device('cpu'), keep_positions=True)
     sched = sh.sched.numpy()
     n = len(tr[0])
     assert sorted(sched[:, 0].tolist()) == list(range(N_USER + N_ITEM))
     assert (np.diff(sched[:, 3]) <= 0).all()                                  # heaviest first
     assert (sched[:, 1] % 8 == 0).all() and ((sched[:, 2] - sched[:, 1]) % 8 == 0).all()
     assert (sched[:, 2] - sched[:, 1] >= sched[:, 3]).all() and (sched[1:, 1] == sched[:-1, 2]).all()
-    assert sh.n_block == (sched[:, 3] > 200).sum() and sh.n_wave == (sched[:, 3] > 40).sum()
     assert sh.n_active == (sched[:, 3] > 0).sum() and sched[-1, 2] == sh.n_slots
     oid, r = sh.ent_oid.numpy(), sh.ent_r.numpy()
     up, ip = sh.u_pos, sh.i_pos
@@ -224,7 +223,7 @@ def test_native_ingest_matches_numpy(tmp_path):
         o += c
     # layout: identical to a stable-argsort construction
     tr = want[0]
-    lay = nv.build_layout(tr[0], tr[1], tr[2], N_USER, N_ITEM, 200, 40, want_pos=True)
+    lay = nv.build_layout(tr[0], tr[1], tr[2], N_USER, N_ITEM, want_pos=True)
     nnz = np.concatenate([np.bincount(tr[0], minlength=N_USER), np.bincount(tr[1], minlength=N_ITEM)])
     order = np.argsort(-nnz, kind='stable')
     assert np.array_equal(lay['sched'][:, 0], order) and np.array_equal(lay['sched'][:, 3], nnz[order])
@@ -237,7 +236,47 @@ def test_native_ingest_matches_numpy(tmp_path):
         want_pos[srt] = beg[base + keys[srt]] + (np.arange(len(keys)) - first)
         assert np.array_equal(pos, want_pos)
     with pytest.raises(nv.NativeError):
-        nv.build_layout(tr[0], tr[1] + N_ITEM, tr[2], N_USER, N_ITEM, 200, 40)
+        nv.build_layout(tr[0], tr[1] + N_ITEM, tr[2], N_USER, N_ITEM)
+
+
+@pytest.mark.parametrize('d', [4, 16, 32, 64, 256])
+def test_work_units_cover_every_row_once(d):
+    """ure_host_build_units: the units of a row tile its segment exactly, stay inside one workgroup,
+    name their leader and count; heavy rows (more pieces than lane groups) get longer pieces."""
+    from ultrare_amd import _native as nv
+    rs = np.random.RandomState(d)
+    n_rows = 700
+    nnz = np.sort(np.concatenate([[5000, 2049, 2048, 300], rs.randint(1, 90, n_rows - 30), np.zeros(26, dtype=np.int64)]))[::-1]
+    pad = (nnz + 7) // 8 * 8
+    beg = np.concatenate([[0], np.cumsum(pad)[:-1]])
+    sched = np.stack([rs.permutation(n_rows), beg, beg + pad, nnz], axis=1).astype(np.int32)
+    n_active = int((nnz > 0).sum())
+    units = nv.build_units(sched, n_active, d)
+    lanes = d // 4 if d <= 32 else d // 8
+    cap, upb = 8 * lanes, 256 // lanes
+    assert len(units) % upb == 0
+    real = units[units[:, 0] >= 0]
+    assert sorted(set(real[:, 0].tolist())) == sorted(sched[:n_active, 0].tolist())
+    by_row = {int(r): (int(b), int(e)) for r, b, e, _ in sched[:n_active]}
+    local = np.arange(len(units)) % upb
+    block = np.arange(len(units)) // upb
+    leader, count, multi = units[:, 3] & 0xFFFF, (units[:, 3] >> 16) & 0x3FFF, (units[:, 3] >> 30) & 1
+    for r, (b, e) in by_row.items():
+        idx = np.nonzero(units[:, 0] == r)[0]
+        assert (np.diff(idx) == 1).all() and len(set(block[idx])) == 1          # consecutive, one workgroup
+        assert (count[idx] == len(idx)).all() and (leader[idx] == local[idx[0]]).all()
+        assert units[idx[0], 1] == b and units[idx[-1], 2] == e and (units[idx[1:], 1] == units[idx[:-1], 2]).all()
+        lens = units[idx, 2] - units[idx, 1]
+        assert (lens % 8 == 0).all() and (lens > 0).all()
+        assert (lens <= cap).all() or len(idx) <= upb                            # longer pieces only for heavy rows
+        if e - b <= cap * upb:
+            assert (lens <= cap).all()
+    empty = units[:, 0] < 0
+    assert (count[empty] == 1).all() and (leader[empty] == local[empty]).all() and (units[empty, 1] == units[empty, 2]).all()
+    for blk in range(len(units) // upb):
+        m = block == blk
+        assert multi[m].min() == multi[m].max() == int((count[m] > 1).any())
+    assert nv.build_units(sched, 0, d).shape == (0, 4)
 
 
 def test_shard_placement_is_lpt():

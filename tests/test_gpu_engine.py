@@ -26,13 +26,13 @@ def toy():
     return O.partition(*tr, full)[0], O.partition(*te, full)[0]
 
 
-def _train_gpu(train, k, batch, epochs, seed=42, thr=(None, None), lr=1e-3, lam=0.1, mu=0.9):
+def _train_gpu(train, k, batch, epochs, seed=42, lr=1e-3, lam=0.1, mu=0.9, n_user=N_USER, n_item=N_ITEM):
     from ultrare_amd import engine, rng
     torch.manual_seed(seed)
-    U0, V0 = rng.mf_init(N_USER, N_ITEM, k)
+    U0, V0 = rng.mf_init(n_user, n_item, k)
     seeds = rng.epoch_seeds(epochs, False)
     perms = rng.epoch_perms(seeds, len(train[0]))
-    sh = engine.ShardData(*train, N_USER, N_ITEM, block_nnz=thr[0], group_nnz=thr[1])
+    sh = engine.ShardData(*train, n_user, n_item)
     job = engine.TrainJob([sh], [(U0, V0)], [perms], k, batch, epochs, lr, lam, mu, 0.95)
     job.run()
     torch.cuda.synchronize()
@@ -51,19 +51,17 @@ def test_full_mf_vs_reference_golden(toy, E):
     np.testing.assert_allclose(loss, g[f'E{E}_train_loss'], rtol=RTOL)
 
 
-@pytest.mark.parametrize('k,batch,thr', [(4, 1000, (None, None)), (8, 3000, (64, 16)), (16, 3000, (0, 0)),
-                                         (32, 5000, (10 ** 9, 10 ** 9)), (32, 3000, (10 ** 9, 0)), (64, 3000, (128, 8)),
-                                         (128, 30000, (256, 40)), (20, 3000, (None, None)), (256, 2000, (300, 100)),
-                                         (16, 15000, (None, None)), (16, 9454, (None, None))])
-def test_step_kernel_vs_oracle(toy, k, batch, thr):
-    """Every table width (incl. a padded one), every row path alone (all rows by
-    workgroup / by wavefront / by lane group) and mixed, batch larger than the shard (1 step
-    per epoch), 2 and 3 steps per epoch (the boundary between standalone and riding batch-tag
-    preparation); 2 epochs against the C oracle on identical init/perms."""
+@pytest.mark.parametrize('k,batch', [(4, 1000), (8, 3000), (16, 3000), (32, 5000), (32, 3000), (64, 3000), (128, 30000),
+                                     (20, 3000), (256, 2000), (16, 15000), (16, 9454)])
+def test_step_kernel_vs_oracle(toy, k, batch):
+    """Every table width (incl. a padded one; the narrow ones cut the toy rows into several work
+    units, whose partial sums meet in LDS), batch larger than the shard (1 step per epoch), 2 and 3
+    steps per epoch (the boundary between standalone and riding batch-tag preparation); 2 epochs
+    against the C oracle on identical init/perms."""
     train, _ = toy
     E = 2
     lr = 1e-3 if k <= 128 else 1e-5          # N(0,1) tables of width 256 diverge at 1e-3 (in the oracle too)
-    U, V, job, (U0, V0, perms) = _train_gpu(train, k, batch, E, thr=thr, lr=lr)
+    U, V, job, (U0, V0, perms) = _train_gpu(train, k, batch, E, lr=lr)
     st = O.MFState(U0.copy(), V0.copy())
     losses = []
     for t in range(E):
@@ -81,6 +79,28 @@ def test_out_of_order_ticks_are_refused(toy):
     _, _, job, _ = _train_gpu(train, 16, 3000, 1)
     rc = nv.lib().ure_job_train(job._job, 3, 5, nv.stream_handle())
     assert rc != 0 and b'in order' in nv.lib().ure_last_error()
+
+
+@pytest.mark.parametrize('k', [8, 32, 256])
+def test_heavy_rows_vs_oracle(k):
+    """Rows far longer than a workgroup's 2048 slots (one user who rated all 2600 items, one item
+    rated by all 300 users): their units take several passes and all lane groups of a workgroup."""
+    rs = np.random.RandomState(5)
+    n_user, n_item = 300, 2600
+    u = [np.zeros(n_item, dtype=np.int64)]
+    i = [np.arange(n_item)]
+    for a in range(1, n_user):
+        it = np.unique(np.concatenate([[7], rs.choice(n_item, rs.randint(1, 40), replace=False)]))
+        u.append(np.full(len(it), a)); i.append(it)
+    u, i = np.concatenate(u), np.concatenate(i)
+    order = rs.permutation(len(u))
+    train = (u[order].astype(np.int32), i[order].astype(np.int32), (rs.randint(1, 6, len(u)) / 5).astype(np.float32))
+    lr = 1e-3 if k <= 128 else 1e-5
+    U, V, job, (U0, V0, perms) = _train_gpu(train, k, 1500, 2, lr=lr, n_user=n_user, n_item=n_item)
+    st = O.MFState(U0.copy(), V0.copy())
+    losses = [O.train_epoch(st, train, perms[t], 1500, lr, 0.1, 0.9)[0] for t in range(2)]
+    assert rel(U, st.U) < 1e-5 and rel(V, st.V) < 1e-5
+    np.testing.assert_allclose(np.sqrt(job.epoch_sse(0) / len(train[0])), losses, rtol=1e-5)
 
 
 def test_bitwise_reproducible(toy):

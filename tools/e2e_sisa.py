@@ -18,19 +18,15 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--shards', type=int, default=5)
-    ap.add_argument('--k', type=int, default=32)
-    ap.add_argument('--epochs', type=int, default=50)
-    ap.add_argument('--parallel', type=int, default=1)
-    ap.add_argument('--delper', type=float, default=2.0)
-    a = ap.parse_args()
+def measure(shards=5, k=32, epochs=50, parallel=1, delper=2.0, data=None, reps=2):
+    """Wall time of Sisa.learn and Sisa.unlearn (per-epoch evals, merge and final test included)
+    on the ml-1m-shaped synthetic set; the last of `reps` repetitions is reported."""
+    a = argparse.Namespace(shards=shards, k=k, epochs=epochs, parallel=parallel, delper=delper)
     from ultrare_amd import synth
     from ultrare_amd.method.sisa import Sisa
     from ultrare_amd.read import RatingData, loadData
 
-    data = synth.make_dataset(**synth.ML1M)
+    data = data or synth.make_dataset(**synth.ML1M)
     n_user, n_item = data['n_user'], data['n_item']
     shard_of, groups = synth.uniform_shards(n_user, a.shards)
     del_user = np.random.RandomState(1).choice(n_user, int(a.delper / 100 * n_user), replace=False)
@@ -52,7 +48,7 @@ def main():
 
     out = {'shards': a.shards, 'k': a.k, 'epochs': a.epochs, 'parallel': bool(a.parallel),
            'train_rows': int(len(data['train'][0])), 'deleted_users': int(len(del_user))}
-    for rep in range(2):          # rep 0 warms allocator / caches / layout caches
+    for rep in range(reps):       # rep 0 warms allocator / caches / layout caches
         sisa = Sisa(P, 'mf', a.shards, groups)
         torch.manual_seed(42)
         t0 = time.perf_counter()
@@ -71,7 +67,18 @@ def main():
     out.update(learn_s=round(t_learn, 4), unlearn_s=round(t_unlearn, 4), retrained_shards=len(s2.retrained),
                learn_interactions_per_s=round(n_learn / t_learn, 1), log0=sisa.log0, unlearn_log0=s2.log0,
                unlearn_interactions=n_un)
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--shards', type=int, default=5)
+    ap.add_argument('--k', type=int, default=32)
+    ap.add_argument('--epochs', type=int, default=50)
+    ap.add_argument('--parallel', type=int, default=1)
+    ap.add_argument('--delper', type=float, default=2.0)
+    a = ap.parse_args()
+    print(json.dumps(measure(a.shards, a.k, a.epochs, a.parallel, a.delper)))
 
 
 if __name__ == '__main__':

@@ -23,7 +23,7 @@ class UreShard(ctypes.Structure):
     """struct ure_shard (include/ultrare_hip.h)."""
     _fields_ = [
         ('ent_oid', _vp), ('ent_r', _vp), ('ent_tag', _vp), ('ent_src', _vp), ('file_tag', _vp), ('inv_stage', _vp), ('inv_off', _vp),
-        ('sched', _vp), ('n_block', _i32), ('n_wave', _i32), ('n_active', _i32), ('n_slots', _i64),
+        ('sched', _vp), ('units', _vp), ('n_units', _i32), ('n_active', _i32), ('n_slots', _i64),
         ('U', _vp * 2), ('V', _vp * 2), ('mU', _vp), ('mV', _vp),
         ('U0', _vp), ('V0', _vp), ('lr_host', _vp), ('lazy_rows', _i32),
         ('snapU', _vp), ('snapV', _vp), ('snap_a', _vp),
@@ -56,8 +56,9 @@ _PROTOTYPES = {
                                          ctypes.POINTER(_i64), ctypes.c_int]),
     'ure_host_free': (None, [_vp]),
     'ure_host_partition': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, ctypes.c_double, _vp, _vp, _vp, _vp]),
-    'ure_host_build_layout': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
-                                             ctypes.POINTER(_i64), ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(_i32), _vp, _vp]),
+    'ure_host_build_layout': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp,
+                                             ctypes.POINTER(_i64), ctypes.POINTER(_i32), _vp, _vp]),
+    'ure_host_build_units': (ctypes.c_int, [_vp, _i32, _i32, _vp, _i64, ctypes.POINTER(_i64)]),
     'ure_score': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_int, _vp, _vp, _vp, _i64, ctypes.c_int, _vp, _vp, _vp]),
     'ure_eval_users': (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -148,7 +149,7 @@ def read_csv(path, threads=0):
     return u, i, r
 
 
-def build_layout(uid, iid, rating, n_user, n_item, block_nnz, group_nnz, want_pos=False):
+def build_layout(uid, iid, rating, n_user, n_item, want_pos=False):
     """ure_host_build_layout on numpy triples -> dict of numpy arrays + counts."""
     n = len(uid)
     cap = 2 * n + 8 * (n_user + n_item) + 8
@@ -158,12 +159,22 @@ def build_layout(uid, iid, rating, n_user, n_item, block_nnz, group_nnz, want_po
     sched = np.empty((n_user + n_item, 4), dtype=np.int32)
     u_pos = np.empty(n, dtype=np.int32) if want_pos else None
     i_pos = np.empty(n, dtype=np.int32) if want_pos else None
-    ns, nb, nw, na = _i64(), _i32(), _i32(), _i32()
-    check(lib().ure_host_build_layout(uid.ctypes.data, iid.ctypes.data, rating.ctypes.data, n, n_user, n_item, block_nnz, group_nnz,
+    ns, na = _i64(), _i32()
+    check(lib().ure_host_build_layout(uid.ctypes.data, iid.ctypes.data, rating.ctypes.data, n, n_user, n_item,
                                       ent_oid.ctypes.data, ent_r.ctypes.data, ent_src.ctypes.data, sched.ctypes.data,
-                                      ctypes.byref(ns), ctypes.byref(nb), ctypes.byref(nw), ctypes.byref(na),
+                                      ctypes.byref(ns), ctypes.byref(na),
                                       u_pos.ctypes.data if want_pos else None, i_pos.ctypes.data if want_pos else None),
           'ure_host_build_layout')
     k = ns.value
     return {'ent_oid': ent_oid[:k], 'ent_r': ent_r[:k], 'ent_src': ent_src[:k], 'sched': sched, 'n_slots': k,
-            'n_block': nb.value, 'n_wave': nw.value, 'n_active': na.value, 'u_pos': u_pos, 'i_pos': i_pos}
+            'n_active': na.value, 'u_pos': u_pos, 'i_pos': i_pos}
+
+
+def build_units(sched, n_active, d):
+    """ure_host_build_units: the work units [n_units, 4] of a row schedule for table width d."""
+    sched = np.ascontiguousarray(sched, dtype=np.int32)
+    n = _i64()
+    check(lib().ure_host_build_units(sched.ctypes.data, n_active, d, None, 0, ctypes.byref(n)), 'ure_host_build_units')
+    units = np.empty((max(n.value, 1), 4), dtype=np.int32)
+    check(lib().ure_host_build_units(sched.ctypes.data, n_active, d, units.ctypes.data, n.value, ctypes.byref(n)), 'ure_host_build_units')
+    return units[:n.value]

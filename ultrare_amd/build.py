@@ -1,6 +1,6 @@
 """Build libultrare_hip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
 
-    python -m ultrare_amd.build [--force]
+    python -m ultrare_amd.build [--force] [--timeline OUT.so]
 
 The library is compiled for MI355X only (--offload-arch=gfx950); hipcc
 cross-compiles without a GPU.  The built .so is git-ignored but travels with the
@@ -28,19 +28,23 @@ def _stale():
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=False, timeline=None):
+    """timeline=PATH builds a diagnostic library there instead (per-workgroup timestamps inside the
+    step kernel, -DURE_TIMELINE; see tools/exp_timeline.py) and leaves the product library alone."""
+    if not timeline and not force and not _stale():
         return LIB
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         raise RuntimeError('hipcc not found: libultrare_hip.so cannot be built')
-    cmd = [hipcc] + FLAGS + ['-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-o', LIB] + \
+    out = timeline or LIB
+    cmd = [hipcc] + FLAGS + (['-DURE_TIMELINE'] if timeline else []) + ['-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-o', out] + \
           [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    tl = sys.argv[sys.argv.index('--timeline') + 1] if '--timeline' in sys.argv else None
+    print(build(force='--force' in sys.argv, verbose=True, timeline=tl))

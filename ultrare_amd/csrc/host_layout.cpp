@@ -175,10 +175,10 @@ int ure_host_partition(const int32_t *uid, const int32_t *iid, const double *rat
 }
 
 int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *rating, int64_t n, int32_t n_user, int32_t n_item,
-                          int32_t block_nnz, int32_t group_nnz, int32_t *ent_oid, float *ent_r, int32_t *ent_src, int32_t *sched,
-                          int64_t *n_slots, int32_t *n_block, int32_t *n_wave, int32_t *n_active, int32_t *u_pos, int32_t *i_pos)
+                          int32_t *ent_oid, float *ent_r, int32_t *ent_src, int32_t *sched,
+                          int64_t *n_slots, int32_t *n_active, int32_t *u_pos, int32_t *i_pos)
 {
-    if (!uid || !iid || !rating || !ent_oid || !ent_r || !ent_src || !sched || !n_slots || !n_block || !n_wave || !n_active ||
+    if (!uid || !iid || !rating || !ent_oid || !ent_r || !ent_src || !sched || !n_slots || !n_active ||
         n <= 0 || n_user <= 0 || n_item <= 0)
         return ure::fail(-1, "ure_host_build_layout: bad arguments");
     const int64_t n_rows = (int64_t)n_user + n_item;
@@ -199,8 +199,7 @@ int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *r
     for (int64_t r = 0; r < n_rows; ++r) order[first[max_nnz - nnz[r]]++] = (int32_t)r;
     std::vector<int64_t> row_beg(n_rows);
     int64_t slots = 0;
-    int32_t nb = 0, nw = 0, na = 0;
-    const int64_t b_thr = std::max(block_nnz, group_nnz);
+    int32_t na = 0;
     for (int64_t q = 0; q < n_rows; ++q) {
         const int32_t r = order[q];
         const int64_t padded = (nnz[r] + 7) / 8 * 8;
@@ -210,15 +209,11 @@ int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *r
         sched[4 * q + 2] = (int32_t)(slots + padded);
         sched[4 * q + 3] = (int32_t)nnz[r];
         slots += padded;
-        nb += nnz[r] > b_thr;
-        nw += nnz[r] > group_nnz;
         na += nnz[r] > 0;
     }
     slots = std::max<int64_t>(slots, 8);
     if (slots >= ((int64_t)1 << 31)) return ure::fail(-1, "ure_host_build_layout: shard too large for 32-bit slot indices");
     *n_slots = slots;
-    *n_block = std::min(nb, nw);
-    *n_wave = nw;
     *n_active = na;
     std::memset(ent_oid, 0, sizeof(int32_t) * (size_t)slots);
     std::memset(ent_r, 0, sizeof(float) * (size_t)slots);
@@ -232,6 +227,77 @@ int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *r
         if (u_pos) u_pos[j] = (int32_t)pu;
         if (i_pos) i_pos[j] = (int32_t)pi;
     }
+    return 0;
+}
+
+// Work units of the step kernel.  A lane group of L lanes scans 8 L slots per pass, so a row is cut
+// into pieces of 8 L slots (one pass each); a row with more pieces than a workgroup has lane groups
+// (256 / L) is cut into 256 / L longer pieces instead.  Rows are taken heaviest first; when the next
+// heavy row does not fit into what is left of the workgroup, the gap is filled with the lightest
+// rows, so a row never straddles workgroups and its partial sums meet in LDS.
+int ure_host_build_units(const int32_t *sched, int32_t n_active, int32_t d, int32_t *units, int64_t capacity, int64_t *n_units)
+{
+    if (!sched || !n_units || n_active < 0 || d < 4 || d > 256 || (d & (d - 1)))
+        return ure::fail(-1, "ure_host_build_units: bad arguments");
+    const int lanes = d <= 32 ? d / 4 : d / 8;
+    const int cap = 8 * lanes, upb = 256 / lanes;
+    auto pieces = [&](int64_t q, int32_t *len) {
+        const int64_t slots = (int64_t)sched[4 * q + 2] - sched[4 * q + 1];
+        int64_t l = cap, nu = (slots + cap - 1) / cap;
+        if (nu > upb) {
+            l = ((slots + upb - 1) / upb + 7) / 8 * 8;
+            nu = (slots + l - 1) / l;
+        }
+        *len = (int32_t)l;
+        return (int32_t)nu;
+    };
+    int64_t out = 0;
+    int64_t i = 0, j = (int64_t)n_active - 1;
+    while (i <= j) {
+        const int64_t block0 = out;
+        int left = upb;
+        bool multi = false;
+        while (left > 0 && i <= j) {
+            int32_t len;
+            int64_t q = i;
+            int32_t nu = pieces(q, &len);
+            if (nu > left) {
+                q = j;
+                nu = pieces(q, &len);
+                if (nu > left) break;
+                --j;
+            } else {
+                ++i;
+            }
+            if (units) {
+                if (out + nu > capacity) return ure::fail(-1, "ure_host_build_units: capacity %lld too small", (long long)capacity);
+                const int32_t beg = sched[4 * q + 1], end = sched[4 * q + 2];
+                const int32_t leader = upb - left;
+                for (int32_t u = 0; u < nu; ++u) {
+                    int32_t *e = units + 4 * (out + u);
+                    e[0] = sched[4 * q + 0];
+                    e[1] = beg + u * len;
+                    e[2] = std::min(end, beg + (u + 1) * len);
+                    e[3] = leader | (nu << 16);
+                }
+            }
+            multi = multi || nu > 1;
+            out += nu;
+            left -= nu;
+        }
+        if (units) {
+            if (out + left > capacity) return ure::fail(-1, "ure_host_build_units: capacity %lld too small", (long long)capacity);
+            for (int k = 0; k < left; ++k) {
+                int32_t *e = units + 4 * (out + k);
+                e[0] = -1; e[1] = 0; e[2] = 0;
+                e[3] = (upb - left + k) | (1 << 16);
+            }
+        }
+        out += left;
+        if (units && multi)
+            for (int64_t u = block0; u < out; ++u) units[4 * u + 3] |= 1 << 30;
+    }
+    *n_units = out;
     return 0;
 }
 

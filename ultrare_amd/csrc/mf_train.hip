@@ -42,10 +42,8 @@
 
 namespace ure {
 
-constexpr int kSuper = 4;       // 64-slot chunks scanned together on the wave / block path
-constexpr int kQueue = 512;     // per-wave match queue: ring of 512 on the wave path,
-                                // 64/LPR private queues of 8*LPR on the group path
-constexpr int kSegPerLane = 8;  // slots one lane scans per segment on the group path
+constexpr int kQueue = 512;     // per-wave match queues: 64/LPR private queues of 8*LPR entries
+constexpr int kSegPerLane = 8;  // slots one lane scans per pass over its unit
 // Lanes that share a table row.  Up to d = 32 every lane holds one float4; wider rows give every
 // lane two (d = 64: 8 lanes, 128: 16, 256: 32), which doubles the rows -- and the bytes in flight --
 // per wavefront.  Measured (us per launch): d = 64, 8 shards: 29.3 -> 26.2; d = 128, 25 M workload:
@@ -55,24 +53,23 @@ __host__ __device__ constexpr int lanes_per_row(int d) { return d <= 32 ? d / 4 
 __device__ __forceinline__ int shard_steps(const ure_shard_t &S) { return (S.N + S.batch - 1) / S.batch; }
 
 template <int LPR, int V4>
-__global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__restrict__ shards, int64_t tick, int shard_fast)
+__device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, int64_t tick, int shard_fast)
 {
     constexpr int D = LPR * V4 * 4;          // row width: LPR lanes x V4 float4 per lane
     using Row = RowVec<V4>;
-    constexpr int G = kWave / LPR;           // table rows one wave instruction gathers
-    constexpr int R4 = 4 * G;
-    constexpr int CAP = kSegPerLane * LPR;   // group path: slots per segment = queue capacity per group
+    constexpr int G = kWave / LPR;           // lane groups per wavefront = table rows one instruction gathers
+    constexpr int UPB = kBlock / LPR;        // lane groups (work units) per workgroup
+    constexpr int CAP = kSegPerLane * LPR;   // slots a lane group scans per pass = capacity of its match queue
     // table rows a lane group gathers together on the group path: six while rows are narrow (swept on
     // hardware: 18.5 us vs 18.9 at four, 19.7 at eight for d = 32); four for wide rows, where the
     // extra registers cost occupancy (d = 128: 1.55 ms vs 1.34 ms per launch of the 25 M workload)
-    constexpr int kGB = LPR <= 8 ? 6 : 4;
+    constexpr int kGB = LPR <= 8 ? 5 : 4;
     // one raw LDS block: the row paths use it as match queues, the tag riders overlay their own
     // arrays on it (tag_prep.h)
     constexpr int kQueueBytes = kWavesPerBlock * kQueue * 8;
     static_assert(kTagLds <= kQueueBytes, "tag phases must fit in the queue space");
     __shared__ __attribute__((aligned(16))) char lds_raw[kQueueBytes];
-    __shared__ float4 part_acc[kWavesPerBlock][V4][LPR];
-    __shared__ float part_sse[kWavesPerBlock];
+    __shared__ float4 part_acc[UPB][V4][LPR];
     int (*q_oid)[kQueue] = reinterpret_cast<int (*)[kQueue]>(lds_raw);
     float (*q_r)[kQueue] = reinterpret_cast<float (*)[kQueue]>(lds_raw + kWavesPerBlock * kQueue * 4);
 
@@ -91,8 +88,7 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
     const int n_rows = S.n_user + S.n_item;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sub = lane & (LPR - 1), grp = lane / LPR;
-    const float lam = S.lam, mu = S.mu, lr = S.lr[epoch];
-    const int4 *__restrict__ sched = reinterpret_cast<const int4 *>(S.sched);
+    const float lam = S.lam, mu = S.mu, lr = ldg(S.lr + epoch);
     const int32_t *__restrict__ ent_oid = S.ent_oid;
     const float *__restrict__ ent_r = S.ent_r;
     const uint16_t *__restrict__ ent_tag = S.ent_tag + (size_t)(epoch & 1) * S.n_slots;
@@ -122,262 +118,187 @@ __global__ __launch_bounds__(kBlock) void mf_step_kernel(const ure_shard_t *__re
         row_store<LPR, V4>(next_row, sub, nr);
     };
 
-    // Schedule prefixes -> block ranges:
-    //   [0, n_block)         one row per workgroup   (4 waves scan the segment together)
-    //   [n_block, n_wave)    one row per wavefront
-    //   [n_wave, n_active)   one row per lane group  (64/LPR rows per wavefront)
-    //   [n_active, n_rows)   rows without interactions in this shard: decay only
-    const int nbB = S.n_block;
-    const int nbW = (S.n_wave - S.n_block + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int nbG = (S.n_active - S.n_wave + kWavesPerBlock * G - 1) / (kWavesPerBlock * G);
+    // Workgroup ranges of a shard:
+    //   [0, nbU)          work units: one lane group per unit, kBlock / LPR units per workgroup
+    //   [nbU, nbU + nbD)  rows without interactions in this shard: decay only (unless lazy_rows)
+    //   then              the tag riders
+    const int nbU = S.n_units / UPB;
     // lazy_rows: rows [n_active, n_rows) are never gathered by anyone and evolve linearly
     // (w, m)_t = A_t (w, m)_{t-1}; they are then advanced in closed form only when the tables are
     // read (materialize_rows_kernel) instead of being streamed through HBM every step
-    const int nbD = S.lazy_rows ? 0 : (n_rows - S.n_active + kWavesPerBlock * G - 1) / (kWavesPerBlock * G);
-    // While epoch e trains, its steps 0, 1, 2 carry the three phases of epoch e+1's batch tags as
-    // extra workgroups at the end of the grid (tag_prep.h); the launch boundary between steps
-    // orders the phases.
-    const int nbR = tag_rider_blocks(S.N, S.n_slots, steps, s, epoch + 1 < S.epochs);
-    const int nbRows = nbB + nbW + nbG + nbD;
+    const int nbD = S.lazy_rows ? 0 : (n_rows - S.n_active + UPB - 1) / UPB;
+    // While epoch e trains, its steps carry the three phases of epoch e+1's batch tags as extra
+    // workgroups at the end of the grid (tag_prep.h); the launch boundary between steps orders
+    // the phases.
+    const TagRide ride = tag_ride(S.N, S.n_slots, steps, s, epoch + 1 < S.epochs);
+    const int nbR = ride.count;
+    const int nbRows = nbU + nbD;
     const int blk = wg;
-    if (blk >= nbRows) {        // the riders come LAST: the longest row chains start first, the short rider
+    if (blk >= nbRows) {        // the riders come LAST: the row chains start first, the short rider
         const int rb = blk - nbRows;   // workgroups fill the tail of the launch
         if (rb >= nbR) return;
-        if (s == 0) tag_partition(S, epoch + 1, rb, lds_raw);
-        else if (s == 1) tag_collect(S, rb, lds_raw);
-        else tag_derive(S, epoch + 1, rb, nbR);
+        if (ride.phase == 0) tag_partition(S, epoch + 1, ride.first + rb, lds_raw);
+        else if (ride.phase == 1) tag_collect(S, ride.first + rb, lds_raw);
+        else tag_derive(S, epoch + 1, ride.first + rb, tag_derive_blocks(S.n_slots));
         return;
     }
-    if (blk >= nbB + nbW) {
-        // ------------------------------------------------ group path and decay-only path
-        const bool dense_only = blk >= nbB + nbW + nbG;
-        const int idx = dense_only ? S.n_active + ((blk - nbB - nbW - nbG) * kWavesPerBlock + wave) * G + grp
-                                   : S.n_wave + ((blk - nbB - nbW) * kWavesPerBlock + wave) * G + grp;
-        const bool have = idx < (dense_only ? n_rows : S.n_active);
-        int4 ds = make_int4(0, 0, 0, 0);
-        if (have) ds = sched[idx];
-        const bool is_user = ds.x < S.n_user;
-        const size_t row_off = (size_t)(is_user ? ds.x : ds.x - S.n_user) * D;
-        Row w = row_zero<V4>(), m4 = w, acc = w;
-        if (have) {
-            w = row_load<LPR, V4>((is_user ? S.U[cur] : S.V[cur]) + row_off, sub);
-            if (!first) m4 = row_load<LPR, V4>((is_user ? S.mU : S.mV) + row_off, sub);
-        }
-        float sse = 0.f;
-        if (!dense_only) {
-            const float *__restrict__ other = is_user ? S.V[cur] : S.U[cur];
-            int *gq = qo + grp * CAP;
-            float *gr = qr + grp * CAP;
-            const int beg = ds.y, end = have ? ds.z : 0;
-            for (int seg = beg;; seg += CAP) {
-                if (!__any(seg < end)) break;
-                // every lane scans 8 consecutive slots of its group's row (segments are 8-aligned)
-                const int p0 = seg + sub * kSegPerLane;
-                const bool valid = p0 < end;
-                uint4 t4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-                int4 o0 = make_int4(0, 0, 0, 0), o1 = o0;
-                float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-                if (valid) {
-                    t4 = *reinterpret_cast<const uint4 *>(ent_tag + p0);
-                    o0 = *reinterpret_cast<const int4 *>(ent_oid + p0);
-                    o1 = *reinterpret_cast<const int4 *>(ent_oid + p0 + 4);
-                    r0 = *reinterpret_cast<const float4 *>(ent_r + p0);
-                    r1 = *reinterpret_cast<const float4 *>(ent_r + p0 + 4);
-                }
-                const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
-                const int ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-                const float rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-                unsigned mb = 0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const unsigned tg = (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
-                    mb |= (tg == (unsigned)s ? 1u : 0u) << k;
-                }
-                // position of this lane's matches in its group's queue: CSR order = lane-major
-                const int c = __popc(mb);
-                int inc = c;
-#pragma unroll
-                for (int o = 1; o < LPR; o <<= 1) {
-                    const int t = __shfl_up(inc, o, LPR);
-                    if (sub >= o) inc += t;
-                }
-                const int qn = __shfl(inc, LPR - 1, LPR);      // matches of the whole group
-                int wpos = inc - c;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if ((mb >> k) & 1u) {
-                        gq[wpos] = ov[k];
-                        gr[wpos] = rv[k];
-                        ++wpos;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                // every group walks its own queue in order, four gathers in flight
-                for (int t0 = 0; __any(t0 < qn); t0 += kGB) {
-                    int o[kGB];
-                    float r[kGB];
-                    bool act[kGB];
-                    Row v[kGB];
-#pragma unroll
-                    for (int k = 0; k < kGB; ++k) {
-                        act[k] = t0 + k < qn;
-                        o[k] = act[k] ? gq[t0 + k] : 0;
-                        r[k] = act[k] ? gr[t0 + k] : 0.f;
-                    }
-#pragma unroll
-                    for (int k = 0; k < kGB; ++k) {
-                        v[k] = row_zero<V4>();
-                        if (act[k]) v[k] = row_load<LPR, V4>(other + (size_t)o[k] * D, sub);
-                    }
-#pragma unroll
-                    for (int k = 0; k < kGB; ++k) {
-                        const float p = group_sum<LPR>(row_dot<V4>(w, v[k]));
-                        const float e = p - r[k];
-                        const float ge = act[k] ? 2.0f * e : 0.0f;
-                        if (act[k]) sse = fmaf(e, e, sse);
-                        row_axpy<V4>(acc, ge, v[k]);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (have) {
-            sgd_update(w, m4, acc, (is_user ? S.mU : S.mV) + row_off, (is_user ? S.U[cur ^ 1] : S.V[cur ^ 1]) + row_off);
-            if (is_user && sub == 0 && sse != 0.f) S.sse[(size_t)epoch * S.n_user + ds.x] += sse;
-        }
-        return;
+    const int local = wave * G + grp;            // this lane group's unit inside the workgroup
+    const bool dense_only = blk >= nbU;
+    int4 du = make_int4(-1, 0, 0, local | (1 << 16));
+    if (dense_only) {
+        const int idx = S.n_active + (blk - nbU) * UPB + local;
+        if (idx < n_rows) du.x = ldg(S.sched + 4 * (size_t)idx);
+    } else {
+        du = ldg_i4(S.units + 4 * ((size_t)blk * UPB + local));
     }
-
-    // ---------------------------------------------------- block path and wave path
-    const bool heavy = blk < nbB;
-    const int sidx = heavy ? blk : S.n_block + (blk - nbB) * kWavesPerBlock + wave;
-    if (sidx >= S.n_wave) return;            // whole wave (wave path only)
-    const int wpr = heavy ? kWavesPerBlock : 1;
-    const int wir = heavy ? wave : 0;
-
-    const int4 ds = sched[sidx];
-    const bool is_user = ds.x < S.n_user;
-    const int row = is_user ? ds.x : ds.x - S.n_user;
-    const float *__restrict__ w_cur = is_user ? S.U[cur] : S.V[cur];
-    float *__restrict__ w_next = is_user ? S.U[cur ^ 1] : S.V[cur ^ 1];
-    float *__restrict__ mom = is_user ? S.mU : S.mV;
-    const float *__restrict__ other = is_user ? S.V[cur] : S.U[cur];
-
-    const size_t row_off = (size_t)row * D;
-    const int beg = ds.y, end = ds.z;
-    const Row w = row_load<LPR, V4>(w_cur + row_off, sub);
-    Row m4 = row_zero<V4>();
-    if (!first && lane < LPR && wir == 0) m4 = row_load<LPR, V4>(mom + row_off, sub);   // early: hides under the scan
-    Row acc = row_zero<V4>();
+    const bool have = du.x >= 0;
+    const int leader = du.w & 0xFFFF, count = (du.w >> 16) & 0x3FFF;
+    const bool multi = (du.w >> 30) & 1;         // workgroup-uniform: some row here has several units
+    const bool owner = have && local == leader;  // the unit that applies the row's update
+    const bool is_user = du.x < S.n_user;
+    const int row = is_user ? du.x : du.x - S.n_user;
+    const size_t row_off = (size_t)(have ? row : 0) * D;
+    Row w = row_zero<V4>(), m4 = w, acc = w;
+    if (have) {
+        w = row_load<LPR, V4>((is_user ? S.U[cur] : S.V[cur]) + row_off, sub);
+    }
     float sse = 0.f;
-    int qh = 0, qt = 0;
-
-    // Up to 4 rounds (4*G queued entries) with all four row gathers in flight together.
-    auto gather4 = [&](int head, int tail) {
-        int o[4];
-        float r[4];
-        bool act[4];
-        Row v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int idx = head + k * G + grp;
-            act[k] = idx < tail;
-            const int slot = idx & (kQueue - 1);
-            o[k] = act[k] ? qo[slot] : 0;
-            r[k] = qr[slot];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            v[k] = row_zero<V4>();
-            if (act[k]) v[k] = row_load<LPR, V4>(other + (size_t)o[k] * D, sub);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float p = group_sum<LPR>(row_dot<V4>(w, v[k]));
-            const float e = p - r[k];
-            const float ge = act[k] ? 2.0f * e : 0.0f;
-            if (act[k] && sub == 0) sse = fmaf(e, e, sse);
-            row_axpy<V4>(acc, ge, v[k]);
-        }
-    };
-
-    // Scan the row's segment 4 chunks (256 slots) at a time: tags, ids and ratings of a
-    // super-chunk are independent loads; matches are appended to the wave's ring in order.
-    for (int base = beg + wir * (kSuper * kWave); base < end; base += kSuper * kWave * wpr) {
-        bool m[kSuper];
-        int o[kSuper];
-        float r[kSuper];
-#pragma unroll
-        for (int c = 0; c < kSuper; ++c) {
-            const int p = base + c * kWave + lane;
-            m[c] = false; o[c] = 0; r[c] = 0.f;
-            if (p < end) {
-                m[c] = ent_tag[p] == (uint16_t)s;
-                o[c] = ent_oid[p];
-                r[c] = ent_r[p];
+    if (!dense_only) {
+        const float *__restrict__ other = is_user ? S.V[cur] : S.U[cur];
+        int *gq = qo + grp * CAP;
+        float *gr = qr + grp * CAP;
+        const int beg = du.y, end = have ? du.z : 0;
+        for (int seg = beg;; seg += CAP) {
+            if (!__any(seg < end)) break;
+            // every lane scans 8 consecutive slots of its group's unit (segments are 8-aligned)
+            const int p0 = seg + sub * kSegPerLane;
+            const bool valid = p0 < end;
+            uint4 t4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            int4 o0 = make_int4(0, 0, 0, 0), o1 = o0;
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+            if (valid) {
+                t4 = ldg_u4(ent_tag + p0);
+                o0 = ldg_i4(ent_oid + p0);
+                o1 = ldg_i4(ent_oid + p0 + 4);
+                r0 = ldg_f4(ent_r + p0);
+                r1 = ldg_f4(ent_r + p0 + 4);
             }
-        }
+            const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+            const int ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+            const float rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            unsigned mb = 0;
 #pragma unroll
-        for (int c = 0; c < kSuper; ++c) {
-            const unsigned long long mask = __ballot(m[c]);
-            if (m[c]) {
-                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                const int slot = (qt + rank) & (kQueue - 1);
-                qo[slot] = o[c];
-                qr[slot] = r[c];
+            for (int k = 0; k < 8; ++k) {
+                const unsigned tg = (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+                mb |= (tg == (unsigned)s ? 1u : 0u) << k;
             }
-            qt += __popcll(mask);
-        }
-        __builtin_amdgcn_wave_barrier();
-        while (qt - qh >= R4) {
-            gather4(qh, qt);
-            qh += R4;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    while (qt > qh) {
-        gather4(qh, qt);
-        qh += R4;
-    }
-
+            // position of this lane's matches in its group's queue: CSR order = lane-major
+            const int c = __popc(mb);
+            int inc = c;
 #pragma unroll
-    for (int i = 0; i < V4; ++i) {
-        acc.q[i].x = cross_group_sum<LPR>(acc.q[i].x);
-        acc.q[i].y = cross_group_sum<LPR>(acc.q[i].y);
-        acc.q[i].z = cross_group_sum<LPR>(acc.q[i].z);
-        acc.q[i].w = cross_group_sum<LPR>(acc.q[i].w);
-    }
-    sse = wave_sum(sse);
-
-    if (heavy) {   // block-uniform branch: all four waves of a heavy row arrive
-        if (lane < LPR) {
+            for (int o = 1; o < LPR; o <<= 1) {
+                const int t = __shfl_up(inc, o, LPR);
+                if (sub >= o) inc += t;
+            }
+            const int qn = __shfl(inc, LPR - 1, LPR);      // matches of the whole group
+            int wpos = inc - c;
 #pragma unroll
-            for (int i = 0; i < V4; ++i) part_acc[wave][i][lane] = acc.q[i];
-        }
-        if (lane == 0) part_sse[wave] = sse;
-        __syncthreads();
-        if (wave != 0) return;
-        if (lane < LPR) {
-#pragma unroll
-            for (int i = 0; i < V4; ++i) {
-                float4 a4 = part_acc[0][i][lane];
-#pragma unroll
-                for (int k = 1; k < kWavesPerBlock; ++k) {
-                    const float4 t = part_acc[k][i][lane];
-                    a4.x += t.x; a4.y += t.y; a4.z += t.z; a4.w += t.w;
+            for (int k = 0; k < 8; ++k) {
+                if ((mb >> k) & 1u) {
+                    gq[wpos] = ov[k];
+                    gr[wpos] = rv[k];
+                    ++wpos;
                 }
-                acc.q[i] = a4;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // every group walks its own queue in order, kGB gathers in flight
+            for (int t0 = 0; __any(t0 < qn); t0 += kGB) {
+                int o[kGB];
+                float r[kGB];
+                bool act[kGB];
+                Row v[kGB];
+#pragma unroll
+                for (int k = 0; k < kGB; ++k) {
+                    act[k] = t0 + k < qn;
+                    o[k] = act[k] ? gq[t0 + k] : 0;
+                    r[k] = act[k] ? gr[t0 + k] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < kGB; ++k) {
+                    v[k] = row_zero<V4>();
+                    if (act[k]) v[k] = row_load<LPR, V4>(other + (size_t)o[k] * D, sub);
+                }
+#pragma unroll
+                for (int k = 0; k < kGB; ++k) {
+                    const float p = group_sum<LPR>(row_dot<V4>(w, v[k]));
+                    const float e = p - r[k];
+                    const float ge = act[k] ? 2.0f * e : 0.0f;
+                    if (act[k]) sse = fmaf(e, e, sse);
+                    row_axpy<V4>(acc, ge, v[k]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // a row cut into several units: the partial gradient sums meet in LDS and the row's first
+        // unit adds them up in unit order (a fixed order: the result does not depend on timing)
+        if (multi) {
+            if (have && count > 1) {
+#pragma unroll
+                for (int i = 0; i < V4; ++i) part_acc[local][i][sub] = acc.q[i];
+                if (sub == 0) qr[grp * CAP] = sse;       // the group's queue is free by now
+            }
+            __syncthreads();
+            if (owner && count > 1) {
+#pragma unroll
+                for (int i = 0; i < V4; ++i) {
+                    float4 a4 = part_acc[leader][i][sub];
+                    for (int k = 1; k < count; ++k) {
+                        const float4 t = part_acc[leader + k][i][sub];
+                        a4.x += t.x; a4.y += t.y; a4.z += t.z; a4.w += t.w;
+                    }
+                    acc.q[i] = a4;
+                }
+                sse = 0.f;
+                for (int k = 0; k < count; ++k) sse += q_r[(leader + k) / G][((leader + k) % G) * CAP];
             }
         }
-        sse = 0.f;
-#pragma unroll
-        for (int k = 0; k < kWavesPerBlock; ++k) sse += part_sse[k];
     }
+    if (owner) {
+        if (!first) m4 = row_load<LPR, V4>((is_user ? S.mU : S.mV) + row_off, sub);
+        sgd_update(w, m4, acc, (is_user ? S.mU : S.mV) + row_off, (is_user ? S.U[cur ^ 1] : S.V[cur ^ 1]) + row_off);
+        // train loss (utils.py:82): each user row adds its own squared errors to its own slot of
+        // the epoch -- owner-only read-modify-write, so no atomics and a reproducible sum
+        if (is_user && sub == 0 && sse != 0.f) {
+            float *slot = S.sse + (size_t)epoch * S.n_user + row;
+            stg(slot, ldg(slot) + sse);
+        }
+    }
+}
 
-    if (lane < LPR) sgd_update(w, m4, acc, mom + row_off, w_next + row_off);
-    // train loss (utils.py:82): each user row adds its own squared errors to its own slot of
-    // the epoch -- owner-only read-modify-write, so no atomics and a reproducible sum
-    if (is_user && lane == 0 && sse != 0.f) S.sse[(size_t)epoch * S.n_user + row] += sse;
+#ifdef URE_TIMELINE
+// Diagnostic build (python -m ultrare_amd.build --timeline, tools/exp_timeline.py): every workgroup
+// records when it started and ended (100 MHz wall clock) so that the inside of a launch can be read.
+__device__ long long *g_timeline = nullptr;
+#endif
+
+template <int LPR, int V4>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(V4 == 1 ? 7 : 4))) void mf_step_kernel(const ure_shard_t *__restrict__ shards, int64_t tick, int shard_fast)
+{
+#ifdef URE_TIMELINE
+    const long long t0 = wall_clock64();
+#endif
+    mf_step<LPR, V4>(shards, tick, shard_fast);
+#ifdef URE_TIMELINE
+    __syncthreads();
+    if (g_timeline && threadIdx.x == 0) {
+        const size_t lin = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin < 16384) {
+            long long *e = g_timeline + ((size_t)(tick & 15) * 16384 + lin) * 2;
+            e[0] = t0;
+            e[1] = wall_clock64();
+        }
+    }
+#endif
 }
 
 // End-of-epoch snapshot of a shard's tables into snapU/snapV[epoch] (optional; used to rebuild the
@@ -391,26 +312,25 @@ __global__ __launch_bounds__(kBlock) void snapshot_kernel(const ure_shard_t *__r
     if (ticks_done > (int64_t)steps * S.epochs || ticks_done % steps != 0) return;   // only at an epoch end of this shard
     const int epoch = (int)(ticks_done / steps) - 1;
     const int cur = (int)(ticks_done & 1);
-    const float a = S.lazy_rows ? S.snap_a[epoch] : 0.f;
+    const float a = S.lazy_rows ? ldg(S.snap_a + epoch) : 0.f;
     const int d4 = S.d / 4;
     const int n_rows = S.n_user + S.n_item;
-    const int4 *__restrict__ sched = reinterpret_cast<const int4 *>(S.sched);
     float *__restrict__ su = S.snapU + (size_t)epoch * S.n_user * S.d;
     float *__restrict__ sv = S.snapV + (size_t)epoch * S.n_item * S.d;
     const int64_t total = (int64_t)n_rows * d4;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
         const int idx = (int)(t / d4);
-        const int row_id = sched[idx].x;
+        const int row_id = ldg(S.sched + 4 * (size_t)idx);
         const bool is_user = row_id < S.n_user;
         const size_t o = (size_t)(is_user ? row_id : row_id - S.n_user) * S.d + (size_t)(t % d4) * 4;
         float4 v;
         if (S.lazy_rows && idx >= S.n_active) {
-            const float4 w0 = *reinterpret_cast<const float4 *>((is_user ? S.U0 : S.V0) + o);
+            const float4 w0 = ldg_f4((is_user ? S.U0 : S.V0) + o);
             v = make_float4(a * w0.x, a * w0.y, a * w0.z, a * w0.w);
         } else {
-            v = *reinterpret_cast<const float4 *>((is_user ? S.U[cur] : S.V[cur]) + o);
+            v = ldg_f4((is_user ? S.U[cur] : S.V[cur]) + o);
         }
-        *reinterpret_cast<float4 *>((is_user ? su : sv) + o) = v;
+        stg_f4((is_user ? su : sv) + o, v);
     }
 }
 
@@ -431,14 +351,13 @@ __global__ __launch_bounds__(kBlock) void materialize_rows_kernel(const ure_shar
     const int d4 = S.d / 4;
     const int n_rows = S.n_user + S.n_item;
     const int64_t total = (int64_t)(n_rows - S.n_active) * d4;
-    const int4 *__restrict__ sched = reinterpret_cast<const int4 *>(S.sched);
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
-        const int row_id = sched[S.n_active + t / d4].x;
+        const int row_id = ldg(S.sched + 4 * (size_t)(S.n_active + t / d4));
         const bool is_user = row_id < S.n_user;
         const size_t o = (size_t)(is_user ? row_id : row_id - S.n_user) * S.d + (size_t)(t % d4) * 4;
-        const float4 w0 = *reinterpret_cast<const float4 *>((is_user ? S.U0 : S.V0) + o);
-        *reinterpret_cast<float4 *>((is_user ? S.U[cur] : S.V[cur]) + o) = make_float4(a * w0.x, a * w0.y, a * w0.z, a * w0.w);
-        *reinterpret_cast<float4 *>((is_user ? S.mU : S.mV) + o) = make_float4(b * w0.x, b * w0.y, b * w0.z, b * w0.w);
+        const float4 w0 = ldg_f4((is_user ? S.U0 : S.V0) + o);
+        stg_f4((is_user ? S.U[cur] : S.V[cur]) + o, make_float4(a * w0.x, a * w0.y, a * w0.z, a * w0.w));
+        stg_f4((is_user ? S.mU : S.mV) + o, make_float4(b * w0.x, b * w0.y, b * w0.z, b * w0.w));
     }
 }
 
@@ -453,7 +372,7 @@ static void launch_step(const ure_job *job, int64_t tick, hipStream_t st)
         const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
         if (tick >= steps * S.epochs) continue;
         const int64_t epoch = tick / steps;
-        blocks = std::max(blocks, job->row_blocks[k] + tag_rider_blocks(S.N, S.n_slots, (int)steps, (int)(tick - epoch * steps), epoch + 1 < S.epochs));
+        blocks = std::max(blocks, job->row_blocks[k] + tag_ride(S.N, S.n_slots, (int)steps, (int)(tick - epoch * steps), epoch + 1 < S.epochs).count);
     }
     const int shard_fast = job->shard_fast && blocks <= 65535;
     dim3 grid = shard_fast ? dim3((unsigned)job->host.size(), (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)job->host.size());
@@ -463,6 +382,10 @@ static void launch_step(const ure_job *job, int64_t tick, hipStream_t st)
 }  // namespace ure
 
 using namespace ure;
+
+#ifdef URE_TIMELINE
+extern "C" int ure_debug_timeline(void *buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(ure::g_timeline), &buf, sizeof(buf)); }
+#endif
 
 extern "C" {
 
@@ -475,8 +398,8 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         const ure_shard_t &S = shards[k];
         const int n_rows = S.n_user + S.n_item;
         const bool ok = S.N > 0 && S.n_user > 0 && S.n_item > 0 && S.batch > 0 && S.epochs > 0 && pow2(S.d) && S.d >= 4 &&
-                        S.d <= 256 && S.n_block >= 0 && S.n_block <= S.n_wave && S.n_wave <= S.n_active &&
-                        S.n_active <= n_rows && S.n_slots >= S.N && S.ent_oid && S.ent_r && S.ent_tag && S.ent_src &&
+                        S.d <= 256 && S.n_active >= 0 && S.n_active <= n_rows && S.units && S.n_units >= 0 &&
+                        S.n_units % (kBlock / lanes_per_row(S.d)) == 0 && S.n_slots >= S.N && S.ent_oid && S.ent_r && S.ent_tag && S.ent_src &&
                         S.file_tag && S.sched && S.U[0] && S.U[1] && S.V[0] && S.V[1] && S.mU && S.mV && S.perm && S.lr && S.sse &&
                         (!S.lazy_rows || (S.U0 && S.V0 && S.lr_host));
         if (!ok) { delete job; return fail(-1, "ure_job_create: shard %d has an invalid descriptor", k); }
@@ -484,10 +407,8 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
         if (steps > 65534) { delete job; return fail(-1, "ure_job_create: shard %d needs %lld steps/epoch (> 65534)", k, (long long)steps); }
         job->ticks = std::max(job->ticks, steps * S.epochs);
-        const int per_wave = kWave / lanes_per_row(S.d);
-        const int per_block = per_wave * kWavesPerBlock;
-        const int blocks = S.n_block + (S.n_wave - S.n_block + kWavesPerBlock - 1) / kWavesPerBlock +
-                           (S.n_active - S.n_wave + per_block - 1) / per_block + (S.lazy_rows ? 0 : (n_rows - S.n_active + per_block - 1) / per_block);
+        const int per_block = kBlock / lanes_per_row(S.d);
+        const int blocks = S.n_units / per_block + (S.lazy_rows ? 0 : (n_rows - S.n_active + per_block - 1) / per_block);
         job->row_blocks.push_back(blocks);
         job->max_n = std::max(job->max_n, S.N);
         job->max_slots = std::max(job->max_slots, S.n_slots);

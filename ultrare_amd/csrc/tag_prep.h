@@ -20,9 +20,9 @@
 //                        image with full-line stores;
 //   phase C  derive      ent_tag[p] = file_tag[ent_src[p]]: coalesced reads, L2-resident 2-byte
 //                        gathers, full-line stores.
-// While epoch e trains, steps 0, 1 and 2 of e carry phases A, B and C for epoch e+1 (ent_tag is
-// double-buffered by epoch parity); the kernel boundary between steps is the barrier between
-// phases.  Epoch 0, shards with fewer than 3 steps per epoch, and shards beyond kMaxRanges
+// While epoch e trains, its steps carry phases A, B and C for epoch e+1, each phase spread over a
+// third of the epoch's steps (ent_tag is double-buffered by epoch parity); the kernel boundary
+// between steps is the barrier between phases.  Epoch 0, shards with fewer than 3 steps per epoch, and shards beyond kMaxRanges
 // ranges (2 M interactions; plain scatter) use standalone launches instead.
 #pragma once
 #include "ure_internal.h"
@@ -72,7 +72,7 @@ __device__ inline void tag_partition(const ure_shard_t &S, int epoch, int c, cha
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int b = b_lo + k * kBlock + tid;
-        jv[k] = b < b_hi ? perm[b] : -1;
+        jv[k] = b < b_hi ? ldg(perm + b) : -1;
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -106,7 +106,7 @@ __device__ inline void tag_partition(const ure_shard_t &S, int epoch, int c, cha
     }
     if (tid == kBlock - 1) cnt[n_ranges] = scan[tid];
     __syncthreads();
-    for (int t = tid; t <= n_ranges; t += kBlock) off[t] = cnt[t];
+    for (int t = tid; t <= n_ranges; t += kBlock) stg(off + t, cnt[t]);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         if (jv[k] >= 0) {
@@ -116,7 +116,7 @@ __device__ inline void tag_partition(const ure_shard_t &S, int epoch, int c, cha
     }
     __syncthreads();
     const int total = cnt[n_ranges];
-    for (int t = tid; t < total; t += kBlock) stage[(size_t)b_lo + t] = buf[t];
+    for (int t = tid; t < total; t += kBlock) stg(stage + (size_t)b_lo + t, buf[t]);
 }
 
 // Phase B, workgroup `r` of tag_ranges(N) (256 threads).
@@ -133,8 +133,8 @@ __device__ inline void tag_collect(const ure_shard_t &S, int r, char *lds)
     const int tid = threadIdx.x;
     for (int t = tid; t < kRange; t += kBlock) img[t] = 0xFFFFu;        // an index the permutation misses never trains
     for (int c = tid; c < n_ranges; c += kBlock) {
-        lo[c] = off[(size_t)c * (n_ranges + 1) + r];
-        hi[c] = off[(size_t)c * (n_ranges + 1) + r + 1];
+        lo[c] = ldg(off + (size_t)c * (n_ranges + 1) + r);
+        hi[c] = ldg(off + (size_t)c * (n_ranges + 1) + r + 1);
     }
     __syncthreads();
     // bins are ~2K / n_ranges entries: a quarter wave per chunk keeps most lanes busy
@@ -142,13 +142,13 @@ __device__ inline void tag_collect(const ure_shard_t &S, int r, char *lds)
     for (int c = part; c < n_ranges; c += kBlock / 16) {
         const uint32_t *__restrict__ src = stage + (size_t)c * kRange;
         for (int t = lo[c] + sub; t < hi[c]; t += 16) {
-            const uint32_t e = src[t];
+            const uint32_t e = ldg(src + t);
             img[e & (kRange - 1)] = (uint16_t)(e >> kRangeBits);
         }
     }
     __syncthreads();
     const int j0 = r * kRange;
-    for (int t = tid; t < kRange && j0 + t < n; t += kBlock) file_tag[j0 + t] = img[t];
+    for (int t = tid; t < kRange && j0 + t < n; t += kBlock) stg(file_tag + j0 + t, img[t]);
 }
 
 // Phase C, workgroup `blk` of `n_blk` (256 threads, eight slots per thread).
@@ -159,24 +159,38 @@ __device__ inline void tag_derive(const ure_shard_t &S, int epoch, int blk, int 
     uint16_t *__restrict__ ent_tag = S.ent_tag + (size_t)(epoch & 1) * S.n_slots;
     const int64_t n8 = S.n_slots / 8;
     for (int64_t q = (int64_t)blk * kBlock + threadIdx.x; q < n8; q += (int64_t)n_blk * kBlock) {
-        const int4 s0 = *reinterpret_cast<const int4 *>(ent_src + q * 8);
-        const int4 s1 = *reinterpret_cast<const int4 *>(ent_src + q * 8 + 4);
+        const int4 s0 = ldg_i4(ent_src + q * 8);
+        const int4 s1 = ldg_i4(ent_src + q * 8 + 4);
         const int sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
         unsigned tg[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tg[k] = sv[k] >= 0 ? (unsigned)file_tag[sv[k]] : 0xFFFFu;
-        *reinterpret_cast<uint4 *>(ent_tag + q * 8) =
-            make_uint4(tg[0] | (tg[1] << 16), tg[2] | (tg[3] << 16), tg[4] | (tg[5] << 16), tg[6] | (tg[7] << 16));
+        for (int k = 0; k < 8; ++k) tg[k] = sv[k] >= 0 ? (unsigned)ldg(file_tag + sv[k]) : 0xFFFFu;
+        stg_u4(ent_tag + q * 8, make_uint4(tg[0] | (tg[1] << 16), tg[2] | (tg[3] << 16), tg[4] | (tg[5] << 16), tg[6] | (tg[7] << 16)));
     }
 }
 
 __host__ __device__ inline int tag_derive_blocks(int64_t n_slots) { return (int)((n_slots / 8 + kBlock - 1) / kBlock); }
 
-// Number of extra workgroups step `s` of an epoch carries for the NEXT epoch's tags.
-__host__ __device__ inline int tag_rider_blocks(int n, int64_t n_slots, int steps, int s, bool has_next)
+// The share of the NEXT epoch's tag preparation that step `s` of an epoch carries as extra
+// workgroups: with m = steps / 3, phase p runs in steps [p m, (p+1) m), an m-th of its workgroups
+// in each, so that no single launch carries a whole phase.
+struct TagRide {
+    int phase;      // 0 partition, 1 collect, 2 derive; -1 nothing
+    int first;      // first workgroup of the phase this step runs
+    int count;
+};
+__host__ __device__ inline TagRide tag_ride(int n, int64_t n_slots, int steps, int s, bool has_next)
 {
-    if (!has_next || steps < 3 || !tag_partitioned(n)) return 0;
-    return s == 0 || s == 1 ? tag_ranges(n) : s == 2 ? tag_derive_blocks(n_slots) : 0;
+    TagRide r{-1, 0, 0};
+    if (!has_next || steps < 3 || !tag_partitioned(n)) return r;
+    const int m = steps / 3, p = s / m;
+    if (p > 2) return r;
+    const int q = s - p * m;
+    const int64_t nb = p < 2 ? tag_ranges(n) : tag_derive_blocks(n_slots);
+    r.phase = p;
+    r.first = (int)(nb * q / m);
+    r.count = (int)(nb * (q + 1) / m) - r.first;
+    return r;
 }
 
 }  // namespace ure

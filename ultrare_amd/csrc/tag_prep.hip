@@ -43,8 +43,8 @@ __global__ __launch_bounds__(kBlock) void tag_scatter_kernel(const ure_shard_t *
     uint16_t *__restrict__ file_tag = S.file_tag;
     const BatchOf batch_of(S.batch);
     for (int b = blockIdx.x * kBlock + threadIdx.x; b < n; b += gridDim.x * kBlock) {
-        const int j = perm[b];
-        if ((unsigned)j < (unsigned)n) file_tag[j] = (uint16_t)batch_of(b);
+        const int j = ldg(perm + b);
+        if ((unsigned)j < (unsigned)n) stg(file_tag + j, (uint16_t)batch_of(b));
     }
 }
 

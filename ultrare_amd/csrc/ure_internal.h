@@ -57,6 +57,25 @@ struct ure_job {
 bool tag_prep_needed(const ure_job *job, int64_t tick);
 void launch_tag_prep(const ure_job *job, int64_t tick, hipStream_t st);
 
+// Global-memory accessors.  A pointer that a kernel reads out of a descriptor in memory (struct
+// ure_shard) has no address space the compiler can see, so a plain dereference becomes a flat_*
+// instruction: it counts in vmcnt AND lgkmcnt, completes out of order and forces every wait to be
+// a full `s_waitcnt vmcnt(0) lgkmcnt(0)` -- LDS reads then wait for all loads in flight.  Going
+// through address space 1 gives global_* instructions (counted waits, SGPR base where uniform).
+#define URE_AS1 __attribute__((address_space(1)))
+typedef float ure_f4 __attribute__((ext_vector_type(4)));
+typedef int ure_i4 __attribute__((ext_vector_type(4)));
+typedef unsigned ure_u4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ T ldg(const T *p) { return *(const T URE_AS1 *)p; }
+template <typename T>
+__device__ __forceinline__ void stg(T *p, T v) { *(T URE_AS1 *)p = v; }
+__device__ __forceinline__ float4 ldg_f4(const float *p) { const ure_f4 v = *(const ure_f4 URE_AS1 *)p; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ int4 ldg_i4(const int32_t *p) { const ure_i4 v = *(const ure_i4 URE_AS1 *)p; return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint4 ldg_u4(const void *p) { const ure_u4 v = *(const ure_u4 URE_AS1 *)p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void stg_f4(float *p, float4 v) { ure_f4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(ure_f4 URE_AS1 *)p = t; }
+__device__ __forceinline__ void stg_u4(void *p, uint4 v) { ure_u4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(ure_u4 URE_AS1 *)p = t; }
+
 // A lane's share of a table row: V4 float4 pieces.  Lane `sub` of the LPR lanes that share a row
 // owns float4 columns sub, sub + LPR, ... so that every load / store instruction of the group
 // covers one contiguous run of LPR * 16 bytes.  Row width d = LPR * V4 * 4.
@@ -77,14 +96,14 @@ __device__ __forceinline__ RowVec<V4> row_load(const float *row, int sub)
 {
     RowVec<V4> r;
 #pragma unroll
-    for (int i = 0; i < V4; ++i) r.q[i] = *reinterpret_cast<const float4 *>(row + (i * LPR + sub) * 4);
+    for (int i = 0; i < V4; ++i) r.q[i] = ldg_f4(row + (i * LPR + sub) * 4);
     return r;
 }
 template <int LPR, int V4>
 __device__ __forceinline__ void row_store(float *row, int sub, const RowVec<V4> &v)
 {
 #pragma unroll
-    for (int i = 0; i < V4; ++i) *reinterpret_cast<float4 *>(row + (i * LPR + sub) * 4) = v.q[i];
+    for (int i = 0; i < V4; ++i) stg_f4(row + (i * LPR + sub) * 4, v.q[i]);
 }
 template <int V4>
 __device__ __forceinline__ float row_dot(const RowVec<V4> &a, const RowVec<V4> &b)

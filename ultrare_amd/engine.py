@@ -21,10 +21,6 @@ import torch
 
 from . import _native as nv
 
-# rows with more entries than BLOCK_NNZ get a workgroup, more than GROUP_NNZ a wavefront,
-# the rest one lane group (d/4 lanes) each
-BLOCK_NNZ = int(os.environ.get('URE_BLOCK_NNZ', '1024'))
-GROUP_NNZ = int(os.environ.get('URE_GROUP_NNZ', '128'))
 SCORE_PARTIALS = 2048     # URE_SCORE_PARTIALS of the C ABI
 LAZY_ROWS = os.environ.get('URE_LAZY_ROWS', '1') != '0'
 
@@ -51,7 +47,7 @@ class ShardData:
     (users, then items) owns an 8-aligned, padded segment of one slot array; segments
     follow the row schedule (heaviest first)."""
 
-    def __init__(self, uid, iid, rating, n_user, n_item, device=None, block_nnz=None, group_nnz=None, keep_positions=False):
+    def __init__(self, uid, iid, rating, n_user, n_item, device=None, keep_positions=False):
         uid = np.ascontiguousarray(uid, dtype=np.int32)
         iid = np.ascontiguousarray(iid, dtype=np.int32)
         rating = np.ascontiguousarray(rating, dtype=np.float32)
@@ -64,13 +60,10 @@ class ShardData:
             raise ValueError('user or item id outside [0, n_user) x [0, n_item)')
         self.N, self.n_user, self.n_item = n, int(n_user), int(n_item)
         self.device = device or _device()
-        b_thr = BLOCK_NNZ if block_nnz is None else block_nnz
-        g_thr = GROUP_NNZ if group_nnz is None else group_nnz
-        lay = nv.build_layout(uid, iid, rating, n_user, n_item, min(b_thr, 2 ** 31 - 1), min(g_thr, 2 ** 31 - 1),
-                              want_pos=keep_positions)
+        lay = nv.build_layout(uid, iid, rating, n_user, n_item, want_pos=keep_positions)
         ent_oid, ent_r, ent_src, sched = lay['ent_oid'], lay['ent_r'], lay['ent_src'], lay['sched']
         u_pos, i_pos = lay['u_pos'], lay['i_pos']
-        self.n_slots, self.n_block, self.n_wave, self.n_active = lay['n_slots'], lay['n_block'], lay['n_wave'], lay['n_active']
+        self.n_slots, self.n_active = lay['n_slots'], lay['n_active']
         self.max_row = int(sched[0, 3])
         dev = self.device
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -83,6 +76,15 @@ class ShardData:
         self.inv_stage = torch.zeros(n, dtype=torch.int32, device=dev)
         self.inv_off = torch.zeros(max(ranges * (ranges + 1), 1) if ranges <= 1024 else 1, dtype=torch.int32, device=dev)
         self.sched = to(sched)
+        self._sched_host = sched
+        self._units = {}
+
+    def units(self, d):
+        """The work units of the step kernel for table width d (device int32 [n_units, 4])."""
+        if d not in self._units:
+            u = nv.build_units(self._sched_host, self.n_active, d)
+            self._units[d] = torch.from_numpy(np.ascontiguousarray(u)).to(self.device)
+        return self._units[d]
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in
@@ -147,7 +149,8 @@ class TrainJob:
             D = descs[s]
             for name in ('ent_oid', 'ent_r', 'ent_tag', 'ent_src', 'file_tag', 'inv_stage', 'inv_off', 'sched'):
                 setattr(D, name, nv.ptr(getattr(sh, name)))
-            D.n_block, D.n_wave, D.n_active, D.n_slots = sh.n_block, sh.n_wave, sh.n_active, sh.n_slots
+            units = sh.units(self.d)
+            D.units, D.n_units, D.n_active, D.n_slots = nv.ptr(units), units.shape[0], sh.n_active, sh.n_slots
             D.U[0], D.U[1] = nv.ptr(U[0]), nv.ptr(U[1])
             D.V[0], D.V[1] = nv.ptr(V[0]), nv.ptr(V[1])
             D.mU, D.mV = nv.ptr(mU), nv.ptr(mV)
