@@ -194,21 +194,20 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
             }
             // position of this lane's matches in its group's queue: CSR order = lane-major
             const int c = __popc(mb);
-            int inc = c;
-#pragma unroll
-            for (int o = 1; o < LPR; o <<= 1) {
-                const int t = __shfl_up(inc, o, LPR);
-                if (sub >= o) inc += t;
-            }
-            const int qn = __shfl(inc, LPR - 1, LPR);      // matches of the whole group
-            int wpos = inc - c;
+            const int inc = group_scan<LPR>(c, sub);
+            const int qn = (int)group_sum<LPR>((float)c);  // matches of the whole group (<= 256: exact)
+            // branch-free compaction: the lane's matches go to the front of the group's queue in slot
+            // order, everything else behind the qn matches -- each of the group's CAP slots gets its
+            // own queue position, so all eight writes are unconditional
+            int mpos = inc - c, upos = qn + sub * kSegPerLane - mpos;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                if ((mb >> k) & 1u) {
-                    gq[wpos] = ov[k];
-                    gr[wpos] = rv[k];
-                    ++wpos;
-                }
+                const bool hit = (mb >> k) & 1u;
+                const int pos = hit ? mpos : upos;
+                gq[pos] = ov[k];
+                gr[pos] = rv[k];
+                mpos += hit ? 1 : 0;
+                upos += hit ? 0 : 1;
             }
             __builtin_amdgcn_wave_barrier();
             // every group walks its own queue in order, kGB gathers in flight
@@ -217,17 +216,19 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
                 float r[kGB];
                 bool act[kGB];
                 Row v[kGB];
+                // branch-free on purpose: all queue reads, then all row gathers, are issued back to
+                // back (a conditional read or gather costs an exec-mask branch and a full wait each);
+                // entries beyond the group's count read a stale queue slot and gather row 0, and
+                // contribute nothing (ge = 0)
 #pragma unroll
                 for (int k = 0; k < kGB; ++k) {
+                    const int qi = min(t0 + k, CAP - 1);
                     act[k] = t0 + k < qn;
-                    o[k] = act[k] ? gq[t0 + k] : 0;
-                    r[k] = act[k] ? gr[t0 + k] : 0.f;
+                    o[k] = gq[qi];
+                    r[k] = gr[qi];
                 }
 #pragma unroll
-                for (int k = 0; k < kGB; ++k) {
-                    v[k] = row_zero<V4>();
-                    if (act[k]) v[k] = row_load<LPR, V4>(other + (size_t)o[k] * D, sub);
-                }
+                for (int k = 0; k < kGB; ++k) v[k] = row_load<LPR, V4>(other + (size_t)(act[k] ? o[k] : 0) * D, sub);
 #pragma unroll
                 for (int k = 0; k < kGB; ++k) {
                     const float p = group_sum<LPR>(row_dot<V4>(w, v[k]));

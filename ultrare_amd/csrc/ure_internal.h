@@ -135,13 +135,54 @@ __device__ __forceinline__ void row_axpy(RowVec<V4> &acc, float s, const RowVec<
 
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-// Sum over the LPR consecutive lanes that share one table row (LPR = d/4 lanes,
-// one float4 each).  xor-butterfly: every lane of the group ends with the total.
+// Cross-lane moves inside a row of 16 lanes as DPP modifiers (one VALU instruction, no trip through
+// the LDS crossbar as ds_bpermute / __shfl takes, and no lgkmcnt wait).
+constexpr int kDppQuadXor1 = 0xB1;       // quad_perm [1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;       // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;    // lane i <-> 7 - i within 8 lanes
+constexpr int kDppRowMirror = 0x140;     // lane i <-> 15 - i within 16 lanes
+constexpr int kDppRowShr = 0x110;        // + n: lane i reads lane i - n of its 16-lane row (0 when there is none)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+// Sum over the LPR consecutive lanes that share one table row (LPR = d/4 or d/8 lanes).  Every
+// lane of the group ends with the total; the additions pair the same values as an xor butterfly.
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v)
 {
+    if (LPR >= 2) v += dpp_f<kDppQuadXor1>(v);
+    if (LPR >= 4) v += dpp_f<kDppQuadXor2>(v);
+    if (LPR >= 8) v += dpp_f<kDppHalfMirror>(v);
+    if (LPR >= 16) v += dpp_f<kDppRowMirror>(v);
+    if (LPR >= 32) v += __shfl_xor(v, 16, kWave);
+    if (LPR >= 64) v += __shfl_xor(v, 32, kWave);
+    return v;
+}
+
+// Inclusive prefix sum over the LPR lanes of a group (lane `sub` of the group).
+template <int LPR>
+__device__ __forceinline__ int group_scan(int v, int sub)
+{
+    if (LPR > 16) {          // the group spans DPP rows: plain shuffles
 #pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, kWave);
+        for (int o = 1; o < LPR; o <<= 1) {
+            const int t = __shfl_up(v, o, LPR);
+            if (sub >= o) v += t;
+        }
+        return v;
+    }
+    if (LPR >= 2) { const int t = dpp_i<kDppRowShr + 1>(v); if (sub >= 1) v += t; }
+    if (LPR >= 4) { const int t = dpp_i<kDppRowShr + 2>(v); if (sub >= 2) v += t; }
+    if (LPR >= 8) { const int t = dpp_i<kDppRowShr + 4>(v); if (sub >= 4) v += t; }
+    if (LPR >= 16) { const int t = dpp_i<kDppRowShr + 8>(v); if (sub >= 8) v += t; }
     return v;
 }
 
