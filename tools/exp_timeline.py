@@ -30,7 +30,7 @@ perms = [rng.epoch_perms(rng.epoch_seeds(E, True), len(p[0])) for p in parts]
 shards = [engine.ShardData(*p, spec['n_user'], spec['n_item']) for p in parts]
 job = engine.TrainJob(shards, inits, perms, d, B, E, 1e-3, 0.1, 0.9)
 SLOTS = 16384
-buf = torch.zeros(16 * SLOTS * 2, dtype=torch.int64, device='cuda')
+buf = torch.zeros(16 * SLOTS * 8, dtype=torch.int64, device='cuda')
 L = nv.lib()
 L.ure_debug_timeline.argtypes = [ctypes.c_void_p]
 job.run(28)
@@ -39,7 +39,7 @@ assert L.ure_debug_timeline(ctypes.c_void_p(buf.data_ptr())) == 0
 job.run(14)
 torch.cuda.synchronize()
 L.ure_debug_timeline(ctypes.c_void_p(0))
-tl = buf.cpu().numpy().reshape(16, SLOTS, 2)
+tl = buf.cpu().numpy().reshape(16, SLOTS, 8)
 upb = 256 // (d // 4 if d <= 32 else d // 8)
 heavy = [((sh.units(d).cpu().numpy()[:, 3] >> 30) & 1).reshape(-1, upb)[:, 0] for sh in shards]
 spans = []
@@ -60,6 +60,14 @@ for tick in range(28, 42):
         if not m.any():
             continue
         dur = en[m] - st[m]
+        if kd != 'rider ':
+            ph = (t[idx[m]][:, 2:5] - base) / 100.0
+            ok = (t[idx[m]][:, 2:5] > 0).all(axis=1)
+            if ok.any():
+                a0, a1, a2 = ph[ok, 0] - st[m][ok], ph[ok, 1] - ph[ok, 0], ph[ok, 2] - ph[ok, 1]
+                a3 = en[m][ok] - ph[ok, 2]
+                print(f'   {kd} phases (first lane, med / p90 us): descriptor+row {np.median(a0):.2f}/{np.percentile(a0, 90):.2f}  scan {np.median(a1):.2f}/{np.percentile(a1, 90):.2f}  '
+                      f'gathers {np.median(a2):.2f}/{np.percentile(a2, 90):.2f}  combine+update {np.median(a3):.2f}/{np.percentile(a3, 90):.2f}')
         print(f'   {kd} n={m.sum():5d} start med {np.median(st[m]):6.2f} max {st[m].max():6.2f} | dur med {np.median(dur):6.2f} '
               f'p90 {np.percentile(dur, 90):6.2f} max {dur.max():6.2f} | end med {np.median(en[m]):6.2f} max {en[m].max():6.2f}')
 print('mean span', round(float(np.mean(spans)), 2), 'us')

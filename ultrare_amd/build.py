@@ -1,6 +1,6 @@
 """Build libultrare_hip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
 
-    python -m ultrare_amd.build [--force] [--timeline OUT.so]
+    python -m ultrare_amd.build [--force] [--timeline OUT.so] [--out OUT.so -DNAME=VALUE ...]
 
 The library is compiled for MI355X only (--offload-arch=gfx950); hipcc
 cross-compiles without a GPU.  The built .so is git-ignored but travels with the
@@ -28,16 +28,16 @@ def _stale():
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build(force=False, verbose=False, timeline=None):
+def build(force=False, verbose=False, timeline=None, defines=(), out=None):
     """timeline=PATH builds a diagnostic library there instead (per-workgroup timestamps inside the
     step kernel, -DURE_TIMELINE; see tools/exp_timeline.py) and leaves the product library alone."""
-    if not timeline and not force and not _stale():
+    if not timeline and not out and not force and not _stale():
         return LIB
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         raise RuntimeError('hipcc not found: libultrare_hip.so cannot be built')
-    out = timeline or LIB
-    cmd = [hipcc] + FLAGS + (['-DURE_TIMELINE'] if timeline else []) + ['-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-o', out] + \
+    out = timeline or out or LIB
+    cmd = [hipcc] + FLAGS + (['-DURE_TIMELINE'] if timeline else []) + ['-D' + d for d in defines] + ['-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-o', out] + \
           [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd), flush=True)
@@ -47,4 +47,6 @@ def build(force=False, verbose=False, timeline=None):
 
 if __name__ == '__main__':
     tl = sys.argv[sys.argv.index('--timeline') + 1] if '--timeline' in sys.argv else None
-    print(build(force='--force' in sys.argv, verbose=True, timeline=tl))
+    out = sys.argv[sys.argv.index('--out') + 1] if '--out' in sys.argv else None
+    defs = [a[2:] for a in sys.argv if a.startswith('-D')]
+    print(build(force='--force' in sys.argv, verbose=True, timeline=tl, defines=defs, out=out))

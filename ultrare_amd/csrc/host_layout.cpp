@@ -27,6 +27,10 @@
 
 #include "ultrare_hip.h"
 
+#ifndef URE_NARROW_MAX
+#define URE_NARROW_MAX 32     // as in ure_internal.h: widest row with one float4 per lane
+#endif
+
 namespace ure {
 int fail(int code, const char *fmt, ...);
 }
@@ -239,7 +243,7 @@ int ure_host_build_units(const int32_t *sched, int32_t n_active, int32_t d, int3
 {
     if (!sched || !n_units || n_active < 0 || d < 4 || d > 256 || (d & (d - 1)))
         return ure::fail(-1, "ure_host_build_units: bad arguments");
-    const int lanes = d <= 32 ? d / 4 : d / 8;
+    const int lanes = d <= URE_NARROW_MAX ? d / 4 : d / 8;
     const int cap = 8 * lanes, upb = 256 / lanes;
     auto pieces = [&](int64_t q, int32_t *len) {
         const int64_t slots = (int64_t)sched[4 * q + 2] - sched[4 * q + 1];

@@ -40,6 +40,20 @@
 #include <cstdlib>
 #include <vector>
 
+// Tuning knobs (defaults = the swept optimum; -D overrides are for sweeps only)
+#ifndef URE_KGB_NARROW
+#define URE_KGB_NARROW 5      // rows a lane group gathers together, d <= 32
+#endif
+#ifndef URE_KGB_WIDE
+#define URE_KGB_WIDE 4        // the same for d >= 64 (two float4 per lane)
+#endif
+#ifndef URE_WAVES_NARROW
+#define URE_WAVES_NARROW 7    // waves per SIMD the register allocator must leave room for, d <= 32
+#endif
+#ifndef URE_WAVES_WIDE
+#define URE_WAVES_WIDE 4
+#endif
+
 namespace ure {
 
 constexpr int kQueue = 512;     // per-wave match queues: 64/LPR private queues of 8*LPR entries
@@ -48,9 +62,24 @@ constexpr int kSegPerLane = 8;  // slots one lane scans per pass over its unit
 // lane two (d = 64: 8 lanes, 128: 16, 256: 32), which doubles the rows -- and the bytes in flight --
 // per wavefront.  Measured (us per launch): d = 64, 8 shards: 29.3 -> 26.2; d = 128, 25 M workload:
 // 1327 -> 1206; four pieces per lane at d = 128: 1530; two pieces at d = 32: 24.9 vs 18.6.
-__host__ __device__ constexpr int lanes_per_row(int d) { return d <= 32 ? d / 4 : d / 8; }
+__host__ __device__ constexpr int lanes_per_row(int d) { return d <= URE_NARROW_MAX ? d / 4 : d / 8; }
 
 __device__ __forceinline__ int shard_steps(const ure_shard_t &S) { return (S.N + S.batch - 1) / S.batch; }
+
+#ifdef URE_TIMELINE
+// Diagnostic build (python -m ultrare_amd.build --timeline, tools/exp_timeline.py): every workgroup
+// records when it started and ended, and its first lane when it passed the phases of the unit path
+// (100 MHz wall clock; 8 values per workgroup), so that the inside of a launch can be read.
+__device__ long long *g_timeline = nullptr;
+#define URE_STAMP(i)                                                                                          \
+    do {                                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                           \
+        const size_t lin_ = (size_t)blockIdx.y * gridDim.x + blockIdx.x;                                      \
+        if (g_timeline && threadIdx.x == 0 && lin_ < 16384) g_timeline[((size_t)(tick & 15) * 16384 + lin_) * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define URE_STAMP(i)
+#endif
 
 template <int LPR, int V4>
 __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, int64_t tick, int shard_fast)
@@ -63,7 +92,7 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
     // table rows a lane group gathers together on the group path: six while rows are narrow (swept on
     // hardware: 18.5 us vs 18.9 at four, 19.7 at eight for d = 32); four for wide rows, where the
     // extra registers cost occupancy (d = 128: 1.55 ms vs 1.34 ms per launch of the 25 M workload)
-    constexpr int kGB = LPR <= 8 ? 5 : 4;
+    constexpr int kGB = LPR <= 8 ? URE_KGB_NARROW : URE_KGB_WIDE;
     // one raw LDS block: the row paths use it as match queues, the tag riders overlay their own
     // arrays on it (tag_prep.h)
     constexpr int kQueueBytes = kWavesPerBlock * kQueue * 8;
@@ -163,8 +192,11 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
         w = row_load<LPR, V4>((is_user ? S.U[cur] : S.V[cur]) + row_off, sub);
     }
     float sse = 0.f;
+    URE_STAMP(2);     // unit descriptor and own row arrived
     if (!dense_only) {
         const float *__restrict__ other = is_user ? S.V[cur] : S.U[cur];
+        // the group's queue; positions are rotated by the group number so that the G groups of a wave,
+        // which write (and read) the same position at the same time, fall into different LDS banks
         int *gq = qo + grp * CAP;
         float *gr = qr + grp * CAP;
         const int beg = du.y, end = have ? du.z : 0;
@@ -203,13 +235,14 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const bool hit = (mb >> k) & 1u;
-                const int pos = hit ? mpos : upos;
+                const int pos = ((hit ? mpos : upos) + grp) & (CAP - 1);   // rotated by the group: see gq
                 gq[pos] = ov[k];
                 gr[pos] = rv[k];
                 mpos += hit ? 1 : 0;
                 upos += hit ? 0 : 1;
             }
             __builtin_amdgcn_wave_barrier();
+            if (seg == beg) URE_STAMP(3);     // first pass scanned and compacted
             // every group walks its own queue in order, kGB gathers in flight
             for (int t0 = 0; __any(t0 < qn); t0 += kGB) {
                 int o[kGB];
@@ -222,7 +255,7 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
                 // contribute nothing (ge = 0)
 #pragma unroll
                 for (int k = 0; k < kGB; ++k) {
-                    const int qi = min(t0 + k, CAP - 1);
+                    const int qi = (min(t0 + k, CAP - 1) + grp) & (CAP - 1);
                     act[k] = t0 + k < qn;
                     o[k] = gq[qi];
                     r[k] = gr[qi];
@@ -240,6 +273,7 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
             }
             __builtin_amdgcn_wave_barrier();
         }
+        URE_STAMP(4);     // all gathers done
         // a row cut into several units: the partial gradient sums meet in LDS and the row's first
         // unit adds them up in unit order (a fixed order: the result does not depend on timing)
         if (multi) {
@@ -276,14 +310,8 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
     }
 }
 
-#ifdef URE_TIMELINE
-// Diagnostic build (python -m ultrare_amd.build --timeline, tools/exp_timeline.py): every workgroup
-// records when it started and ended (100 MHz wall clock) so that the inside of a launch can be read.
-__device__ long long *g_timeline = nullptr;
-#endif
-
 template <int LPR, int V4>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(V4 == 1 ? 7 : 4))) void mf_step_kernel(const ure_shard_t *__restrict__ shards, int64_t tick, int shard_fast)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(V4 == 1 ? URE_WAVES_NARROW : URE_WAVES_WIDE))) void mf_step_kernel(const ure_shard_t *__restrict__ shards, int64_t tick, int shard_fast)
 {
 #ifdef URE_TIMELINE
     const long long t0 = wall_clock64();
@@ -294,7 +322,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(V4 == 1 
     if (g_timeline && threadIdx.x == 0) {
         const size_t lin = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
         if (lin < 16384) {
-            long long *e = g_timeline + ((size_t)(tick & 15) * 16384 + lin) * 2;
+            long long *e = g_timeline + ((size_t)(tick & 15) * 16384 + lin) * 8;
             e[0] = t0;
             e[1] = wall_clock64();
         }
@@ -487,7 +515,7 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
             case 4: launch_step<1, 1>(job, t, st); break;
             case 8: launch_step<2, 1>(job, t, st); break;
             case 16: launch_step<4, 1>(job, t, st); break;
-            case 32: launch_step<8, 1>(job, t, st); break;
+            case 32: launch_step<lanes_per_row(32), 32 / (4 * lanes_per_row(32))>(job, t, st); break;
             case 64: launch_step<8, 2>(job, t, st); break;
             case 128: launch_step<16, 2>(job, t, st); break;
             case 256: launch_step<32, 2>(job, t, st); break;

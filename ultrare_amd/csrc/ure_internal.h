@@ -10,6 +10,12 @@
 
 #include "ultrare_hip.h"
 
+// Widest table row whose lanes hold ONE float4 each (d / 4 lanes per row); wider rows give every
+// lane two (d / 8 lanes per row).  Shared by the step kernel and ure_host_build_units.
+#ifndef URE_NARROW_MAX
+#define URE_NARROW_MAX 32
+#endif
+
 namespace ure {
 
 constexpr int kWave = 64;            // gfx950 wavefront
