@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define URE_ABI_VERSION 1
+#define URE_ABI_VERSION 2
 #define URE_MAX_MODELS_PER_CALL 32
 #define URE_SCORE_PARTIALS 2048       /* length of ure_score's sse buffer */
 

@@ -11,7 +11,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libultrare_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_MODELS_PER_CALL = 32
 
 _vp = ctypes.c_void_p

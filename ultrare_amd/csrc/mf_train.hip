@@ -6,29 +6,29 @@
 //   DataLoader batching       read.py:108-133         (batch s = perm[s*B:(s+1)*B])
 //
 // Design (MI355X-first, not a translation of the autograd graph):
-//   * One optimizer step = ONE kernel.  A wavefront owns a destination row (a user
-//     row of U or an item row of V).  It walks that row's CSR segment, keeps the
-//     entries whose batch number equals this step's, gathers the opposite table's
-//     row for each (one or two 16-byte pieces per lane, LPR = lanes_per_row(d) lanes per
-//     row, 64/LPR rows per wave instruction), recomputes the error e = <u,v> - r and accumulates
-//     2e * other_row in registers.  The full gradient row therefore never leaves
-//     the wavefront: the SGD-momentum-L2 update is applied immediately and the row
-//     is written once into the *other* half of a ping-pong weight pair, so gathers
-//     of this step always see step-t weights.  No atomics, no gradient tables, and
+//   * One optimizer step = ONE kernel, owner-computes.  Whoever owns a destination row (a user
+//     row of U or an item row of V) walks that row's segment of slots, keeps the entries whose
+//     batch number equals this step's, gathers the opposite table's row for each (one or two
+//     16-byte pieces per lane, LPR = lanes_per_row(d) lanes per row, 64/LPR rows per wave
+//     instruction), recomputes the error e = <u,v> - r and accumulates 2e * other_row in
+//     registers.  The gradient row never leaves the owner: the SGD-momentum-L2 update is applied
+//     immediately and the row is written once into the *other* half of a ping-pong weight pair,
+//     so gathers of this step always see step-t weights.  No atomics, no gradient tables, and
 //     the result is bitwise reproducible run to run.
-//   * Work is sized to the row: the heaviest rows get a whole 4-wave workgroup (partial
-//     sums meet in LDS in a fixed order), medium rows one wavefront, and the many small
-//     rows one LANE GROUP each (LPR lanes), so a wavefront advances 64/LPR rows at once
-//     with private accumulators and no cross-lane reduction; rows the shard never touches
-//     only decay: they are advanced in closed form when the tables are read (lazy_rows) or
-//     updated 64/LPR per wave instruction.  The kernel is bound by dependent-load latency
-//     at ml-1m scale, so every path issues its independent loads (tags, ids, ratings; four
-//     to six row gathers) together.
+//   * The unit of work is one scan pass, not a row: a LANE GROUP (LPR lanes) walks one work unit =
+//     8*LPR consecutive slots of a row (ure_host_build_units).  A row cut into several units has
+//     them in one workgroup; their partial sums meet in LDS and the row's first unit adds them in
+//     unit order.  Every workgroup therefore does the same amount of work -- with row-sized work
+//     the heaviest rows set the length of a launch (profiles/r01/NOTES.md).  Rows the shard never
+//     touches only decay: they are advanced in closed form when the tables are read (lazy_rows) or
+//     updated 256/LPR per workgroup.
+//   * The unit loop is branch free: eight unconditional queue writes per lane (matches first, the
+//     rest behind), queue reads and row gathers issued back to back, lane-group sums by DPP.
 //   * Row segments live in one slot array in schedule order, 8-aligned and padded, so
 //     a lane scans 8 slots with one 16-byte load per array.
-//   * Batch membership is a 2-byte tag per slot, double-buffered by epoch parity; the
-//     first three steps of an epoch carry the preparation of the next epoch's tags as
-//     extra workgroups at the end of the grid (tag_prep.h).
+//   * Batch membership is a 2-byte tag per slot, double-buffered by epoch parity; the steps of an
+//     epoch carry the preparation of the next epoch's tags as extra workgroups at the end of the
+//     grid (tag_prep.h).
 //   * Shards are independent (sisa.py:33-36), so a job's shards share each launch
 //     (blockIdx.x = shard): one tick advances every shard by one optimizer step.
 //

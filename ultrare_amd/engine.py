@@ -10,6 +10,7 @@ HBM layout of one shard:
   ent_src[n_slots] i32     slot -> file-order index of its interaction (-1 in padding)
   file_tag[N] u16          scratch: batch of interaction j in the epoch being prepared
   sched[n_user+n_item][4] i32   {row id, first slot, end slot, nnz}, heaviest row first
+  units[n_units][4] i32    work units of the step kernel for one table width (ShardData.units(d))
   U[2][n_user][d] V[2][n_item][d] f32 ping-pong weights ; mU, mV momentum
   perm[epochs][N] i32 ; lr[epochs] f32 ; sse[epochs][n_user] f32 (per-user squared error)
 """
