@@ -82,7 +82,7 @@ __device__ long long *g_timeline = nullptr;
 #endif
 
 template <int LPR, int V4>
-__device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, int64_t tick, int shard_fast)
+__device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, int shard_fast)
 {
     constexpr int D = LPR * V4 * 4;          // row width: LPR lanes x V4 float4 per lane
     using Row = RowVec<V4>;
@@ -107,10 +107,24 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
     // the shard count is a multiple of 8 -- each XCD's L2 then holds only its own shards' tables.
     // (A speed matter only; for other shard counts every shard simply spreads over all XCDs.)
     const ure_shard_t &S = shards[shard_fast ? blockIdx.x : blockIdx.y];
+    const shard_aux &A = aux[shard_fast ? blockIdx.x : blockIdx.y];
     const int wg = (int)(shard_fast ? blockIdx.y : blockIdx.x);
-    const int steps = shard_steps(S);
+    // One round of scalar loads for everything the unit path reads from the descriptor: left alone,
+    // the compiler loads each field in the basic block that first uses it -- eight dependent rounds of
+    // s_load + s_waitcnt in the prologue of every workgroup.  The empty asm statement only pins the
+    // values (their loads) here, ahead of the first branch.
+    {
+        const int p_epochs = S.epochs, p_nu = S.n_user, p_ni = S.n_item, p_units = S.n_units, p_act = S.n_active, p_lazy = S.lazy_rows;
+        const int64_t p_slots = S.n_slots;
+        const float p_lam = S.lam, p_mu = S.mu;
+        asm volatile("" ::"s"(p_epochs), "s"(p_nu), "s"(p_ni), "s"(p_units), "s"(p_act), "s"(p_lazy), "s"(p_slots), "s"(p_lam), "s"(p_mu),
+                     "s"(S.lr), "s"(S.sched), "s"(S.units), "s"(S.ent_oid), "s"(S.ent_r), "s"(S.ent_tag), "s"(S.U[0]), "s"(S.U[1]),
+                     "s"(S.V[0]), "s"(S.V[1]), "s"(S.mU), "s"(S.mV), "s"(S.sse), "s"(A.steps), "s"(A.inv_steps), "s"(A.ride_m),
+                     "s"(A.ride_ab), "s"(A.ride_c), "s"(A.ranges), "s"(A.derive_blocks));
+    }
+    const int steps = A.steps;
     if (tick >= (int64_t)steps * S.epochs) return;
-    const int epoch = (int)(tick / steps);
+    const int epoch = (int)epoch_of(A, tick);
     const int s = (int)(tick - (int64_t)epoch * steps);
     const int cur = (int)(tick & 1);
     const bool first = tick == 0;
@@ -159,7 +173,7 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
     // While epoch e trains, its steps carry the three phases of epoch e+1's batch tags as extra
     // workgroups at the end of the grid (tag_prep.h); the launch boundary between steps orders
     // the phases.
-    const TagRide ride = tag_ride(S.N, S.n_slots, steps, s, epoch + 1 < S.epochs);
+    const TagRide ride = tag_ride(A, s, epoch + 1 < S.epochs);
     const int nbR = ride.count;
     const int nbRows = nbU + nbD;
     const int blk = wg;
@@ -168,7 +182,7 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
         if (rb >= nbR) return;
         if (ride.phase == 0) tag_partition(S, epoch + 1, ride.first + rb, lds_raw);
         else if (ride.phase == 1) tag_collect(S, ride.first + rb, lds_raw);
-        else tag_derive(S, epoch + 1, ride.first + rb, tag_derive_blocks(S.n_slots));
+        else tag_derive(S, epoch + 1, ride.first + rb, A.derive_blocks);
         return;
     }
     const int local = wave * G + grp;            // this lane group's unit inside the workgroup
@@ -311,12 +325,12 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
 }
 
 template <int LPR, int V4>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(V4 == 1 ? URE_WAVES_NARROW : URE_WAVES_WIDE))) void mf_step_kernel(const ure_shard_t *__restrict__ shards, int64_t tick, int shard_fast)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(V4 == 1 ? URE_WAVES_NARROW : URE_WAVES_WIDE))) void mf_step_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, int shard_fast)
 {
 #ifdef URE_TIMELINE
     const long long t0 = wall_clock64();
 #endif
-    mf_step<LPR, V4>(shards, tick, shard_fast);
+    mf_step<LPR, V4>(shards, aux, tick, shard_fast);
 #ifdef URE_TIMELINE
     __syncthreads();
     if (g_timeline && threadIdx.x == 0) {
@@ -401,11 +415,11 @@ static void launch_step(const ure_job *job, int64_t tick, hipStream_t st)
         const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
         if (tick >= steps * S.epochs) continue;
         const int64_t epoch = tick / steps;
-        blocks = std::max(blocks, job->row_blocks[k] + tag_ride(S.N, S.n_slots, (int)steps, (int)(tick - epoch * steps), epoch + 1 < S.epochs).count);
+        blocks = std::max(blocks, job->row_blocks[k] + tag_ride(job->aux_host[k], (int)(tick - epoch * steps), epoch + 1 < S.epochs).count);
     }
     const int shard_fast = job->shard_fast && blocks <= 65535;
     dim3 grid = shard_fast ? dim3((unsigned)job->host.size(), (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)job->host.size());
-    hipLaunchKernelGGL((mf_step_kernel<LPR, V4>), grid, dim3(kBlock), 0, st, job->dev, tick, shard_fast);
+    hipLaunchKernelGGL((mf_step_kernel<LPR, V4>), grid, dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, shard_fast);
 }
 
 }  // namespace ure
@@ -462,6 +476,9 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
     hipError_t e = hipMalloc(&job->dev, sizeof(ure_shard_t) * n_shards);
     if (e == hipSuccess) e = hipMemcpy(job->dev, job->host.data(), sizeof(ure_shard_t) * n_shards, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&job->dev_ab, sizeof(double) * 2 * n_shards);
+    for (int k = 0; k < n_shards; ++k) job->aux_host.push_back(make_shard_aux(shards[k]));
+    if (e == hipSuccess) e = hipMalloc(&job->dev_aux, sizeof(shard_aux) * n_shards);
+    if (e == hipSuccess) e = hipMemcpy(job->dev_aux, job->aux_host.data(), sizeof(shard_aux) * n_shards, hipMemcpyHostToDevice);
     if (e != hipSuccess) { const int rc = fail((int)e, "ure_job_create: %s", hipGetErrorString(e)); ure_job_destroy(reinterpret_cast<ure_job_t *>(job)); return rc; }
     *out = reinterpret_cast<ure_job_t *>(job);
     return 0;
@@ -473,6 +490,7 @@ int ure_job_destroy(ure_job_t *j)
     if (!job) return 0;
     if (job->dev) (void)hipFree(job->dev);
     if (job->dev_ab) (void)hipFree(job->dev_ab);
+    if (job->dev_aux) (void)hipFree(job->dev_aux);
     delete job;
     return 0;
 }

@@ -171,25 +171,62 @@ __device__ inline void tag_derive(const ure_shard_t &S, int epoch, int blk, int 
 
 __host__ __device__ inline int tag_derive_blocks(int64_t n_slots) { return (int)((n_slots / 8 + kBlock - 1) / kBlock); }
 
+// Per-shard constants derived once by ure_job_create (device array next to the descriptors), so
+// that the step kernel's prologue does no integer division: a 64-bit division costs a wave ~150
+// scalar instructions, and every workgroup of every launch starts with three of them otherwise.
+struct shard_aux {
+    uint64_t inv_steps;     // ceil(2^64 / steps), 0 for steps == 1: tick / steps = umul64hi(tick, inv_steps)
+    int32_t steps;          // optimizer steps per epoch = ceil(N / B)
+    int32_t ride_m;         // steps / 3, or 0 when the shard's tags are prepared by standalone launches
+    int32_t ride_ab;        // workgroups of phase A (and of B) carried by one step = ceil(ranges / m)
+    int32_t ride_c;         // the same for phase C
+    int32_t ranges;         // tag_ranges(N)
+    int32_t derive_blocks;  // tag_derive_blocks(n_slots)
+};
+
+inline shard_aux make_shard_aux(const ure_shard_t &S)
+{
+    shard_aux a{};
+    a.steps = (int32_t)(((int64_t)S.N + S.batch - 1) / S.batch);
+    a.inv_steps = a.steps == 1 ? 0 : ~0ull / (uint64_t)a.steps + 1;
+    a.ranges = tag_ranges(S.N);
+    a.derive_blocks = tag_derive_blocks(S.n_slots);
+    a.ride_m = a.steps >= 3 && tag_partitioned(S.N) ? a.steps / 3 : 0;
+    if (a.ride_m) {
+        a.ride_ab = (a.ranges + a.ride_m - 1) / a.ride_m;
+        a.ride_c = (a.derive_blocks + a.ride_m - 1) / a.ride_m;
+    }
+    return a;
+}
+
+__host__ __device__ inline int64_t epoch_of(const shard_aux &a, int64_t tick)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    return a.inv_steps ? (int64_t)__umul64hi((uint64_t)tick, a.inv_steps) : tick;
+#else
+    return tick / a.steps;
+#endif
+}
+
 // The share of the NEXT epoch's tag preparation that step `s` of an epoch carries as extra
-// workgroups: with m = steps / 3, phase p runs in steps [p m, (p+1) m), an m-th of its workgroups
-// in each, so that no single launch carries a whole phase.
+// workgroups: with m = steps / 3, phase p runs in steps [p m, (p+1) m), ceil(workgroups / m) of its
+// workgroups in each, so that no single launch carries a whole phase.
 struct TagRide {
     int phase;      // 0 partition, 1 collect, 2 derive; -1 nothing
     int first;      // first workgroup of the phase this step runs
     int count;
 };
-__host__ __device__ inline TagRide tag_ride(int n, int64_t n_slots, int steps, int s, bool has_next)
+__host__ __device__ inline TagRide tag_ride(const shard_aux &a, int s, bool has_next)
 {
     TagRide r{-1, 0, 0};
-    if (!has_next || steps < 3 || !tag_partitioned(n)) return r;
-    const int m = steps / 3, p = s / m;
-    if (p > 2) return r;
+    const int m = a.ride_m;
+    if (!has_next || m == 0 || s >= 3 * m) return r;
+    const int p = s >= 2 * m ? 2 : s >= m ? 1 : 0;
     const int q = s - p * m;
-    const int64_t nb = p < 2 ? tag_ranges(n) : tag_derive_blocks(n_slots);
+    const int c = p < 2 ? a.ride_ab : a.ride_c, nb = p < 2 ? a.ranges : a.derive_blocks;
     r.phase = p;
-    r.first = (int)(nb * q / m);
-    r.count = (int)(nb * (q + 1) / m) - r.first;
+    r.first = q * c;
+    r.count = max(0, min(c, nb - r.first));
     return r;
 }
 

@@ -40,6 +40,7 @@ int fail(int code, const char *fmt, ...);
     } while (0)
 
 // A set of shards trained side by side (ure_job_t of the C ABI).
+struct shard_aux;
 struct ure_job {
     std::vector<ure_shard_t> host;
     ure_shard_t *dev = nullptr;
@@ -53,6 +54,8 @@ struct ure_job {
     std::vector<std::vector<float>> lr_host;           // per shard: learning rate of each epoch (for the closed form)
     std::vector<double> ab_host;                       // per shard (a, b) of the lazily advanced rows
     double *dev_ab = nullptr;
+    std::vector<struct shard_aux> aux_host;            // per shard: derived constants (tag_prep.h)
+    struct shard_aux *dev_aux = nullptr;
     bool shard_fast = true;              // shard = fast index of the workgroup id (XCD affinity for 8k shards)
     bool snapshots = false;
     unsigned snap_blocks = 1;
