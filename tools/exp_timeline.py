@@ -48,7 +48,9 @@ for tick in range(28, 42):
     idx = np.nonzero(t[:, 0] > 0)[0]
     base = t[idx, 0].min()
     st, en = (t[idx, 0] - base) / 100.0, (t[idx, 1] - base) / 100.0        # us (100 MHz counter)
-    wg, sh = idx // S, idx % S                                             # grid = (shards, workgroups)
+    x, j = idx & 7, idx >> 3                                               # sliced mapping of mf_step (URE_SHARD_FAST=2)
+    sl = S * x + j % S
+    sh, wg = sl >> 3, (j // S) * 8 + (sl & 7)
     kind = np.full(len(idx), 'rider ', dtype='U6')
     for k in range(S):
         m = (sh == k) & (wg < len(heavy[k]))

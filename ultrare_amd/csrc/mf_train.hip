@@ -102,13 +102,28 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
     int (*q_oid)[kQueue] = reinterpret_cast<int (*)[kQueue]>(lds_raw);
     float (*q_r)[kQueue] = reinterpret_cast<float (*)[kQueue]>(lds_raw + kWavesPerBlock * kQueue * 4);
 
-    // grid = (shards, workgroups): the shard is the FAST index of the linear workgroup id, so with
-    // the dispatcher's round-robin placement all workgroups of shard k run on XCD (k mod 8) whenever
-    // the shard count is a multiple of 8 -- each XCD's L2 then holds only its own shards' tables.
-    // (A speed matter only; for other shard counts every shard simply spreads over all XCDs.)
-    const ure_shard_t &S = shards[shard_fast ? blockIdx.x : blockIdx.y];
-    const shard_aux &A = aux[shard_fast ? blockIdx.x : blockIdx.y];
-    const int wg = (int)(shard_fast ? blockIdx.y : blockIdx.x);
+    // Workgroup -> (shard, workgroup of the shard).  The dispatcher deals consecutive workgroup ids out
+    // to the 8 XCDs round robin, and every XCD has its own L2, which starts each launch cold for the
+    // rewritten tables: the fewer shards an XCD works on, the fewer times a gathered row is fetched.
+    // Default (URE_SHARD_FAST=2): the sliced mapping below -- at most two shards per XCD for ANY
+    // shard count (bench, 5 shards: 14.5 -> 13.0 us per launch).  URE_SHARD_FAST=1: grid = (shards,
+    // workgroups), shard k on XCD k mod 8 when the count is a multiple of 8; 0: grid = (workgroups, shards).
+    // A speed matter only: nothing depends on where a workgroup runs.
+    int shard_idx = (int)(shard_fast ? blockIdx.x : blockIdx.y);
+    int wg = (int)(shard_fast ? blockIdx.y : blockIdx.x);
+    if (shard_fast >> 1) {
+        // sliced mapping (1-D grid): the 8 S slices (shard k, workgroups = r mod 8) are dealt out S per XCD
+        // in shard order, so an XCD's L2 sees at most two shards' tables for any shard count, and every
+        // XCD gets the same number of workgroups of every weight class
+        const unsigned n_sh = (unsigned)shard_fast >> 8;
+        const unsigned x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        const unsigned jq = j / n_sh, jr = j - jq * n_sh;
+        const unsigned slice = n_sh * x + jr;
+        shard_idx = (int)(slice >> 3);
+        wg = (int)(jq * 8 + (slice & 7u));
+    }
+    const ure_shard_t &S = shards[shard_idx];
+    const shard_aux &A = aux[shard_idx];
     // One round of scalar loads for everything the unit path reads from the descriptor: left alone,
     // the compiler loads each field in the basic block that first uses it -- eight dependent rounds of
     // s_load + s_waitcnt in the prologue of every workgroup.  The empty asm statement only pins the
@@ -417,8 +432,13 @@ static void launch_step(const ure_job *job, int64_t tick, hipStream_t st)
         const int64_t epoch = tick / steps;
         blocks = std::max(blocks, job->row_blocks[k] + tag_ride(job->aux_host[k], (int)(tick - epoch * steps), epoch + 1 < S.epochs).count);
     }
-    const int shard_fast = job->shard_fast && blocks <= 65535;
-    dim3 grid = shard_fast ? dim3((unsigned)job->host.size(), (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)job->host.size());
+    int shard_fast = job->shard_fast && blocks <= 65535;
+    const unsigned n_sh = (unsigned)job->host.size();
+    dim3 grid = shard_fast ? dim3(n_sh, (unsigned)blocks) : dim3((unsigned)blocks, n_sh);
+    if (job->shard_sliced && n_sh < (1u << 16) && (uint64_t)((blocks + 7) / 8) * 8 * n_sh < (1ull << 31)) {
+        shard_fast = 2 | (int)(n_sh << 8);
+        grid = dim3((unsigned)((blocks + 7) / 8) * 8 * n_sh);
+    }
     hipLaunchKernelGGL((mf_step_kernel<LPR, V4>), grid, dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, shard_fast);
 }
 
@@ -461,7 +481,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         if (small) job->max_small_n = std::max(job->max_small_n, S.N);
     }
     job->d = shards[0].d;
-    if (const char *e = std::getenv("URE_SHARD_FAST")) job->shard_fast = e[0] != '0';
+    if (const char *e = std::getenv("URE_SHARD_FAST")) { job->shard_fast = e[0] != '0'; job->shard_sliced = e[0] == '2'; }
     for (int k = 0; k < n_shards; ++k) {
         const ure_shard_t &S = shards[k];
         job->lr_host.emplace_back(S.lr_host ? std::vector<float>(S.lr_host, S.lr_host + S.epochs) : std::vector<float>());

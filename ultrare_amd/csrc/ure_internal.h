@@ -56,6 +56,7 @@ struct ure_job {
     double *dev_ab = nullptr;
     std::vector<struct shard_aux> aux_host;            // per shard: derived constants (tag_prep.h)
     struct shard_aux *dev_aux = nullptr;
+    bool shard_sliced = true;            // 1-D grid, shards dealt out to XCDs in slices (URE_SHARD_FAST=2, the default)
     bool shard_fast = true;              // shard = fast index of the workgroup id (XCD affinity for 8k shards)
     bool snapshots = false;
     unsigned snap_blocks = 1;
