@@ -103,6 +103,32 @@ def test_heavy_rows_vs_oracle(k):
     np.testing.assert_allclose(np.sqrt(job.epoch_sse(0) / len(train[0])), losses, rtol=1e-5)
 
 
+@pytest.mark.parametrize('mode', ['0', '1', '2'])
+def test_workgroup_mappings_agree(toy, mode, monkeypatch):
+    """URE_SHARD_FAST picks how workgroups are dealt out to shards / XCDs (plain 2-D grid, shard-fast,
+    sliced = default): a placement matter only, so three shards side by side must train bit for bit
+    the same under each."""
+    from ultrare_amd import engine, rng
+    raw = O.load_csv(os.path.join(G, 'toy', '0_train.csv'))
+    parts = O.partition(*raw, O.uniform_groups(N_USER, 3))
+    k, B, E = 16, 3000, 2
+
+    def run():
+        torch.manual_seed(11)
+        inits = [rng.mf_init(N_USER, N_ITEM, k) for _ in parts]
+        perms = [rng.epoch_perms(rng.epoch_seeds(E, True), len(p[0])) for p in parts]
+        job = engine.TrainJob([engine.ShardData(*p, N_USER, N_ITEM) for p in parts], inits, perms, k, B, E, 1e-3, 0.1, 0.9)
+        job.run()
+        torch.cuda.synchronize()
+        return [t.clone() for s_ in range(len(parts)) for t in job.tables(s_)]
+
+    monkeypatch.delenv('URE_SHARD_FAST', raising=False)
+    want = run()
+    monkeypatch.setenv('URE_SHARD_FAST', mode)
+    got = run()
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+
+
 def test_bitwise_reproducible(toy):
     train, _ = toy
     a = _train_gpu(train, 32, 3000, 2)
