@@ -200,6 +200,18 @@ int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const
 int ure_eval_reduce(const int32_t *hits, const double *ndcg, int32_t n_users, const double *sse, int64_t n_rows, double *out3,
                     void *stream);
 
+/* scratch.py:83-97 for all epochs of a shard at once: a SERIES of n_series evaluations on one test
+ * set whose ensembles are the n_fixed fixed models (in list order; the models trained before the
+ * shard) followed by (U_series + e * stride_u, V_series + e * stride_v), e.g. the end-of-epoch
+ * snapshots of struct ure_shard.  Four launches in all; every member's result is identical to
+ * ure_score + ure_eval_users + ure_eval_reduce on its own model list.  Scratch (device): base [n]
+ * (unused when n_fixed == 0), pred [n_series][n], sse [n_series][URE_SCORE_PARTIALS], hits and ndcg
+ * [n_series][n_users]; out [n_series][3] = (rmse, ndcg, hr) of each member. */
+int ure_eval_series(const float *const *U_fixed, const float *const *V_fixed, int n_fixed, const float *U_series,
+                    const float *V_series, int64_t stride_u, int64_t stride_v, int n_series, const int32_t *uid, const int32_t *iid,
+                    const float *rating, int64_t n, int d, const int32_t *off, int32_t n_users, const double *log2_tab, float *base,
+                    float *pred, double *sse, int32_t *hits, double *ndcg, double *out, void *stream);
+
 /* sisa.py:55-56,110-111: dst[rows[t]][:] = src[rows[t]][:]. */
 int ure_merge_rows(float *dst, const float *src, const int64_t *rows, int64_t n_rows, int d, void *stream);
 

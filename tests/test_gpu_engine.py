@@ -129,6 +129,35 @@ def test_workgroup_mappings_agree(toy, mode, monkeypatch):
     assert all(torch.equal(a, b) for a, b in zip(want, got))
 
 
+def test_eval_series_equals_single_evaluations(toy):
+    """ure_eval_series (all epochs of a shard in four launches) against one evaluate() per epoch on
+    the same model lists: identical results, with and without fixed models, chunked or not."""
+    from ultrare_amd import engine, rng
+    train, test = toy
+    torch.manual_seed(3)
+    k, E = 16, 5
+    inits = [rng.mf_init(N_USER, N_ITEM, k) for _ in range(3)]
+    perms = rng.epoch_perms(rng.epoch_seeds(E, False), len(train[0]))
+    job = engine.TrainJob([engine.ShardData(*train, N_USER, N_ITEM)], [inits[0]], [perms], k, 3000, E, 1e-3, 0.1, 0.9, snapshots=True)
+    job.run()
+    ev = engine.EvalSet(*test)
+    fixed = [tuple(t.to(ev.device).contiguous() for t in init) for init in inits[1:]]
+    snapU, snapV = job.snapshots_of(0)
+    for before in ([], fixed):
+        want = torch.zeros(E, 3, dtype=torch.float64, device=ev.device)
+        for e in range(E):
+            ev.evaluate(before + [job.snapshot(0, e)], job.d, out=want[e])
+        for cap in (engine.SERIES_SCRATCH_BYTES, 4 * ev.n * 2):          # second: two members per call
+            engine.SERIES_SCRATCH_BYTES, old = cap, engine.SERIES_SCRATCH_BYTES
+            ev._series_cap = 0
+            try:
+                got = ev.evaluate_series(before, snapU, snapV, job.d, torch.zeros(E, 3, dtype=torch.float64, device=ev.device))
+            finally:
+                engine.SERIES_SCRATCH_BYTES = old
+            torch.cuda.synchronize()
+            assert torch.equal(got, want)
+
+
 def test_bitwise_reproducible(toy):
     train, _ = toy
     a = _train_gpu(train, 32, 3000, 2)

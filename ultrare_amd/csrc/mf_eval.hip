@@ -92,6 +92,62 @@ __global__ __launch_bounds__(kBlock) void score_kernel(TableList T, int n_models
     }
 }
 
+// One launch for a SERIES of ensembles that differ in their last model only (scratch.py:83-97 over
+// the epochs of a shard: the models trained before it + its own model after epoch e): blockIdx.y = e,
+// base[j] = the running sum over the fixed models (ure_score with first = 1, last = 0; NULL when
+// there are none), the last model's tables are U + e * stride_u, V + e * stride_v.  The additions
+// happen in the same order as in score_kernel over the whole list, so the results are identical.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void score_series_kernel(const float *__restrict__ U, const float *__restrict__ V,
+                                                               int64_t stride_u, int64_t stride_v, int n_total,
+                                                               const int32_t *__restrict__ uid, const int32_t *__restrict__ iid,
+                                                               const float *__restrict__ rating, int64_t n,
+                                                               const float *__restrict__ base, float *__restrict__ pred,
+                                                               double *__restrict__ sse)
+{
+    constexpr int D = LPR * 4;
+    constexpr int G = kWave / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (LPR - 1), grp = lane / LPR;
+    const int64_t wave_id = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+    U += (size_t)blockIdx.y * stride_u;
+    V += (size_t)blockIdx.y * stride_v;
+    pred += (size_t)blockIdx.y * n;
+    sse += (size_t)blockIdx.y * URE_SCORE_PARTIALS;
+    float sq = 0.f;
+    for (int64_t j0 = wave_id * G; j0 < n; j0 += n_waves * G) {
+        const int64_t j = j0 + grp;
+        const bool act = j < n;
+        const int u = act ? uid[j] : 0, i = act ? iid[j] : 0;
+        float acc = (act && base) ? base[j] : 0.f;
+        const float4 a = *reinterpret_cast<const float4 *>(U + (size_t)u * D + sub * 4);
+        const float4 b = *reinterpret_cast<const float4 *>(V + (size_t)i * D + sub * 4);
+        float p = a.x * b.x;
+        p = fmaf(a.y, b.y, p);
+        p = fmaf(a.z, b.z, p);
+        p = fmaf(a.w, b.w, p);
+        acc += group_sum<LPR>(p);
+        acc = acc / (float)n_total;
+        if (act && sub == 0) {
+            const float e = acc - rating[j];
+            sq = fmaf(e, e, sq);
+            pred[j] = acc;
+        }
+    }
+    __shared__ float part[kWavesPerBlock];
+    sq = wave_sum(sq);
+    if (lane == 0) part[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < kWavesPerBlock; ++k) t += (double)part[k];
+        sse[blockIdx.x] = t;
+    }
+    for (int t = gridDim.x + threadIdx.x; blockIdx.x == 0 && t < URE_SCORE_PARTIALS; t += kBlock) sse[t] = 0.0;
+}
+
 // (value, position) keys ordered lexicographically; "better" = later in a stable
 // ascending argsort, i.e. earlier in its reverse (utils.py:169-170).
 __device__ __forceinline__ bool key_gt(float v, int i, float bv, int bi) { return v > bv || (v == bv && i > bi); }
@@ -174,12 +230,16 @@ __device__ __forceinline__ void top_k_multi(const float (&val)[kRegItems], int c
 __global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__restrict__ off, int32_t n_users,
                                                             const float *__restrict__ pred, const float *__restrict__ rating,
                                                             const double *__restrict__ log2_tab,
-                                                            int32_t *__restrict__ hits, double *__restrict__ ndcg)
+                                                            int32_t *__restrict__ hits, double *__restrict__ ndcg, int64_t pred_stride)
 {
     constexpr int K = 10;
     const int lane = threadIdx.x & 63;
     const int user = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
     if (user >= n_users) return;
+    // blockIdx.y = member of a series of evaluations that share the test set (ure_eval_series)
+    pred += (size_t)blockIdx.y * pred_stride;
+    hits += (size_t)blockIdx.y * n_users;
+    ndcg += (size_t)blockIdx.y * n_users;
     const int beg = off[user], cnt = off[user + 1] - beg;
     int tp[K], tr[K];
     if (cnt <= kWave) {
@@ -240,6 +300,11 @@ __global__ __launch_bounds__(1024) void eval_reduce_kernel(const int32_t *__rest
                                                            int32_t n_users, const double *__restrict__ sse, int64_t n_rows,
                                                            double *__restrict__ out3)
 {
+    // blockIdx.x = member of a series (ure_eval_series); a single evaluation is a series of one
+    hits += (size_t)blockIdx.x * n_users;
+    ndcg += (size_t)blockIdx.x * n_users;
+    sse += (size_t)blockIdx.x * URE_SCORE_PARTIALS;
+    out3 += (size_t)blockIdx.x * 3;
     __shared__ double sn[1024];
     __shared__ long long sh[1024];
     double an = 0.0;
@@ -297,6 +362,18 @@ static void launch_score(const TableList &T, int nm, int nt, int first, int last
                        rating, n, pred, sse);
 }
 
+template <int LPR>
+static void launch_score_series(const float *U, const float *V, int64_t su, int64_t sv, int n_series, int nt, const int32_t *uid,
+                                const int32_t *iid, const float *rating, int64_t n, const float *base, float *pred, double *sse,
+                                hipStream_t st)
+{
+    constexpr int G = kWave / LPR;
+    const int64_t waves = (n + G - 1) / G;
+    const unsigned blocks = (unsigned)std::min<int64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, URE_SCORE_PARTIALS);
+    hipLaunchKernelGGL(score_series_kernel<LPR>, dim3(blocks ? blocks : 1, (unsigned)n_series), dim3(kBlock), 0, st, U, V, su, sv, nt,
+                       uid, iid, rating, n, base, pred, sse);
+}
+
 }  // namespace ure
 
 using namespace ure;
@@ -338,7 +415,7 @@ int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const
     if (n_users == 0) return 0;
     const unsigned blocks = (unsigned)((n_users + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(eval_users_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), off, n_users, pred,
-                       rating, log2_tab, hits, ndcg);
+                       rating, log2_tab, hits, ndcg, (int64_t)0);
     URE_HIP(hipGetLastError());
     return 0;
 }
@@ -349,6 +426,42 @@ int ure_eval_reduce(const int32_t *hits, const double *ndcg, int32_t n_users, co
     URE_ARG(hits && ndcg && sse && out3 && n_users >= 0 && n_rows > 0);
     hipLaunchKernelGGL(eval_reduce_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), hits, ndcg, n_users, sse, n_rows,
                        out3);
+    URE_HIP(hipGetLastError());
+    return 0;
+}
+
+int ure_eval_series(const float *const *U_fixed, const float *const *V_fixed, int n_fixed, const float *U_series,
+                    const float *V_series, int64_t stride_u, int64_t stride_v, int n_series, const int32_t *uid, const int32_t *iid,
+                    const float *rating, int64_t n, int d, const int32_t *off, int32_t n_users, const double *log2_tab, float *base,
+                    float *pred, double *sse, int32_t *hits, double *ndcg, double *out, void *stream)
+{
+    URE_ARG(n_fixed >= 0 && (n_fixed == 0 || (U_fixed && V_fixed && base)) && U_series && V_series && n_series > 0 && n_series <= 65535);
+    URE_ARG(uid && iid && rating && n > 0 && pow2(d) && d >= 4 && d <= 256 && off && n_users >= 0 && log2_tab && pred && sse && hits &&
+            ndcg && out);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the fixed models' running sum, in list order, once for the whole series
+    for (int c0 = 0; c0 < n_fixed; c0 += URE_MAX_MODELS_PER_CALL) {
+        const int c = std::min(n_fixed - c0, URE_MAX_MODELS_PER_CALL);
+        if (int rc = ure_score(U_fixed + c0, V_fixed + c0, c, n_fixed + 1, c0 == 0, 0, uid, iid, rating, n, d, base, nullptr, stream)) return rc;
+    }
+    const float *b = n_fixed ? base : nullptr;
+    const int nt = n_fixed + 1;
+    switch (d / 4) {
+        case 1: launch_score_series<1>(U_series, V_series, stride_u, stride_v, n_series, nt, uid, iid, rating, n, b, pred, sse, st); break;
+        case 2: launch_score_series<2>(U_series, V_series, stride_u, stride_v, n_series, nt, uid, iid, rating, n, b, pred, sse, st); break;
+        case 4: launch_score_series<4>(U_series, V_series, stride_u, stride_v, n_series, nt, uid, iid, rating, n, b, pred, sse, st); break;
+        case 8: launch_score_series<8>(U_series, V_series, stride_u, stride_v, n_series, nt, uid, iid, rating, n, b, pred, sse, st); break;
+        case 16: launch_score_series<16>(U_series, V_series, stride_u, stride_v, n_series, nt, uid, iid, rating, n, b, pred, sse, st); break;
+        case 32: launch_score_series<32>(U_series, V_series, stride_u, stride_v, n_series, nt, uid, iid, rating, n, b, pred, sse, st); break;
+        case 64: launch_score_series<64>(U_series, V_series, stride_u, stride_v, n_series, nt, uid, iid, rating, n, b, pred, sse, st); break;
+        default: return fail(-1, "ure_eval_series: unsupported d=%d", d);
+    }
+    if (n_users > 0) {
+        const unsigned blocks = (unsigned)((n_users + kWavesPerBlock - 1) / kWavesPerBlock);
+        hipLaunchKernelGGL(eval_users_kernel, dim3(blocks, (unsigned)n_series), dim3(kBlock), 0, st, off, n_users, pred, rating, log2_tab,
+                           hits, ndcg, n);
+    }
+    hipLaunchKernelGGL(eval_reduce_kernel, dim3((unsigned)n_series), dim3(1024), 0, st, hits, ndcg, n_users, sse, n, out);
     URE_HIP(hipGetLastError());
     return 0;
 }

@@ -23,6 +23,7 @@ import torch
 from . import _native as nv
 
 SCORE_PARTIALS = 2048     # URE_SCORE_PARTIALS of the C ABI
+SERIES_SCRATCH_BYTES = 256 << 20     # prediction scratch of one ure_eval_series call
 LAZY_ROWS = os.environ.get('URE_LAZY_ROWS', '1') != '0'
 
 
@@ -210,6 +211,11 @@ class TrainJob:
         st = self.state[s]
         return st['snapU'][epoch], st['snapV'][epoch]
 
+    def snapshots_of(self, s):
+        """All end-of-epoch tables of shard s: (U [epochs, n_user, d], V [epochs, n_item, d])."""
+        st = self.state[s]
+        return st['snapU'], st['snapV']
+
     def materialize(self, stream=None):
         """Bring the lazily advanced rows (lazy_rows) up to date in the current tables."""
         if self.lazy_rows and self._fresh != self.done:
@@ -313,6 +319,39 @@ class EvalSet:
         ndcg = self.ndcg[:self.n_users].cpu().numpy()
         rmse = float(np.sqrt(sse / self.n))
         return rmse, float(np.mean(ndcg)), float(np.mean(hits / top_k))
+
+    def evaluate_series(self, fixed, U_series, V_series, d, out, stream=None):
+        """scratch.py:83-97 for every epoch of a shard in four launches (ure_eval_series): member e of
+        the series is the ensemble `fixed` + [(U_series[e], V_series[e])]; out[e] (device float64
+        [E, 3]) receives its (rmse, ndcg, hr).  Nothing synchronises."""
+        E = int(U_series.shape[0])
+        assert out.shape == (E, 3) and out.dtype == torch.float64 and out.is_contiguous()
+        assert U_series.is_contiguous() and V_series.is_contiguous() and U_series.shape[2] == d and V_series.shape[2] == d
+        if self.n == 0:
+            return out.fill_(float('nan'))
+        L, st = nv.lib(), nv.stream_handle(stream)
+        per_call = max(1, min(E, SERIES_SCRATCH_BYTES // (4 * self.n)))
+        if getattr(self, '_series_cap', 0) < per_call:
+            dev = self.device
+            self._series = {'base': torch.empty(self.n, dtype=torch.float32, device=dev),
+                            'pred': torch.empty(per_call, self.n, dtype=torch.float32, device=dev),
+                            'sse': torch.empty(per_call, SCORE_PARTIALS, dtype=torch.float64, device=dev),
+                            'hits': torch.empty(per_call, max(self.n_users, 1), dtype=torch.int32, device=dev),
+                            'ndcg': torch.empty(per_call, max(self.n_users, 1), dtype=torch.float64, device=dev)}
+            self._series_cap = per_call
+        b = self._series
+        for U, V in fixed:
+            assert U.is_contiguous() and V.is_contiguous() and U.shape[1] == d and V.shape[1] == d
+        Up = (ctypes.c_void_p * max(len(fixed), 1))(*[U.data_ptr() for U, _ in fixed])
+        Vp = (ctypes.c_void_p * max(len(fixed), 1))(*[V.data_ptr() for _, V in fixed])
+        for e0 in range(0, E, per_call):
+            m = min(per_call, E - e0)
+            nv.check(L.ure_eval_series(Up, Vp, len(fixed), nv.ptr(U_series[e0]), nv.ptr(V_series[e0]), U_series.stride(0),
+                                       V_series.stride(0), m, nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating), self.n, d,
+                                       nv.ptr(self.off), self.n_users, nv.ptr(self.log2), nv.ptr(b['base']), nv.ptr(b['pred']),
+                                       nv.ptr(b['sse']), nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), st),
+                     'ure_eval_series')
+        return out
 
     def predictions(self):
         """Ensemble predictions of the last evaluate() in the caller's original row order."""

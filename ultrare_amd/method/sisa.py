@@ -170,12 +170,12 @@ class Sisa(Scratch):
                         before.append(out[j])
                 before = [padded_tables(m)[:2] for m in before]
                 pos = mine.index(i)
-                res = torch.zeros(self.epochs, 2, 3, dtype=torch.float64, device=engine._device())
-                for e in range(self.epochs):                # queued on the stream: no synchronisation per call
-                    ms = before + [job.snapshot(pos, e)]
-                    test_ev.evaluate(ms, job.d, out=res[e, 0])
-                    total_ev.evaluate(ms, job.d, out=res[e, 1])
-                res = res.cpu().numpy()
+                # all epochs of the shard at once: the ensembles differ in their last model only
+                res = torch.zeros(2, self.epochs, 3, dtype=torch.float64, device=engine._device())
+                snapU, snapV = job.snapshots_of(pos)
+                test_ev.evaluate_series(before, snapU, snapV, job.d, res[0])
+                total_ev.evaluate_series(before, snapU, snapV, job.d, res[1])
+                res = res.cpu().numpy().transpose(1, 0, 2)
                 for c, key in enumerate(('test_rmse', 'test_ndcg', 'test_hr')):
                     entry[key] = [float(x) for x in res[:, 0, c]]
                 for c, key in enumerate(('total_rmse', 'total_ndcg', 'total_hr')):
