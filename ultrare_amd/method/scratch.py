@@ -25,9 +25,11 @@ def _is_empty(x):
     return isinstance(x, (list, tuple)) and len(x) == 0
 
 
-def prepare_shard(train_loader, n_user, n_item, k, epochs, has_total, given_model=''):
+def prepare_shard(train_loader, n_user, n_item, k, epochs, has_total, given_model='', defer=False):
     """Host part of one Scratch.train call: consume the RNG stream exactly like the
-    reference (model init, then per-epoch seeds) and expand the permutations."""
+    reference (model init, then per-epoch seeds) and expand the permutations.  defer=True returns
+    the permutations as a future (rng.epoch_perms_async): the expansion then runs beside the
+    caller's next draws."""
     loader = as_loader(train_loader)
     if _is_empty(given_model) or given_model == '':
         init = MF(n_user, n_item, k)                       # 4 normal fills on the CPU generator
@@ -37,7 +39,9 @@ def prepare_shard(train_loader, n_user, n_item, k, epochs, has_total, given_mode
         V0 = given_model.item_mat.weight.detach().float().cpu()
     seeds = rng.epoch_seeds(epochs, has_total)
     n = len(loader.dataset)
-    if loader.shuffle:
+    if loader.shuffle and defer:
+        perms = rng.epoch_perms_async(seeds, n, threads=PERM_THREADS, pooled=True)
+    elif loader.shuffle:
         perms = rng.epoch_perms(seeds, n, threads=PERM_THREADS, pooled=True)
     else:
         perms = torch.arange(n, dtype=torch.int32).repeat(epochs, 1)

@@ -56,7 +56,7 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
     for pos, i in enumerate(ids):
         if owner[pos] == rank:
             if on_device:
-                prepared[i] = prepare_shard(train_dlist[i], n_user, n_item, k, epochs, True)
+                prepared[i] = prepare_shard(train_dlist[i], n_user, n_item, k, epochs, True, defer=True)
             else:   # host-only (tests): same draws, no HBM layout
                 init = MF(n_user, n_item, k)
                 seeds = rng.epoch_seeds(epochs, True)
@@ -66,6 +66,9 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
         else:
             rng.mf_init(n_user, n_item, k)
             rng.epoch_seeds(epochs, True)
+    for i, (shard, init, perms) in list(prepared.items()):      # permutations expanded in the background: collect
+        if hasattr(perms, 'result'):
+            prepared[i] = (shard, init, perms.result())
     return prepared
 
 

@@ -107,6 +107,35 @@ def epoch_perms(seeds, n, threads=0, pooled=False):
     return out
 
 
+_EXPANDER = None
+
+
+def epoch_perms_async(seeds, n, threads=0, pooled=False):
+    """epoch_perms on a background thread: returns a future whose result() is the tensor.  The seeds
+    are already drawn, so expanding them needs nothing from torch's generator and overlaps with the
+    caller's next draws (the next shard's model init); the native call runs without the GIL."""
+    global _EXPANDER
+    if _EXPANDER is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _EXPANDER = ThreadPoolExecutor(max_workers=1, thread_name_prefix='ure-perms')
+    from . import _native as nv
+    nv.lib()                                            # load the library on the calling thread
+    if len(seeds) == 0 or n == 0 or n >= (2 ** 32 - 1) // 20:
+        out = epoch_perms(seeds, n, threads, pooled)    # nothing to expand, or ATen's huge-n algorithm (torch itself): done here
+
+        class _Done:
+            def result(self_inner):
+                return out
+        return _Done()
+    out = POOL.take((len(seeds), n), torch.int32) if pooled else torch.empty(len(seeds), n, dtype=torch.int32)
+    sd = np.asarray(seeds, dtype=np.uint64).astype(np.int64)
+
+    def work():
+        nv.check(nv.lib().ure_host_randperm(sd.ctypes.data, len(sd), n, out.data_ptr(), int(threads or 0)), 'ure_host_randperm')
+        return out
+    return _EXPANDER.submit(work)
+
+
 def seed_all(seed):
     """method/utils.py:21-25 as written (numpy + the device generator; NOT the torch
     CPU generator -- SURVEY D7: the harness seeds that one)."""
