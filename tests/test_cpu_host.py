@@ -153,6 +153,25 @@ def test_host_randperm_equals_torch(n):
         assert torch.equal(row, rng.epoch_perm(s, n))
 
 
+def test_epoch_seeds_batched_draw_equals_scalar_draws():
+    """rng.epoch_seeds takes all of an epoch loop's int64 draws in one call; the reference draws them
+    one by one (scratch.py:78-97 creates 3-4 loader iterators per epoch)."""
+    from ultrare_amd import rng
+    for with_total in (False, True):
+        torch.manual_seed(123)
+        got = rng.epoch_seeds(57, with_total)
+        after = rng.draw_seed()
+        torch.manual_seed(123)
+        want = []
+        for _ in range(57):
+            rng.draw_seed()
+            want.append(rng.draw_seed())
+            rng.draw_seed()
+            if with_total:
+                rng.draw_seed()
+        assert got == want and after == rng.draw_seed()
+
+
 def test_shard_layout_invariants():
     """The slot array the kernels walk: every interaction appears once in its user's
     segment and once in its item's, segments are 8-aligned, padded slots never match."""

@@ -18,9 +18,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def measure(shards=5, k=32, epochs=50, parallel=1, delper=2.0, data=None, reps=2):
+def measure(shards=5, k=32, epochs=50, parallel=1, delper=2.0, data=None, reps=3):
     """Wall time of Sisa.learn and Sisa.unlearn (per-epoch evals, merge and final test included)
-    on the ml-1m-shaped synthetic set; the last of `reps` repetitions is reported."""
+    on the ml-1m-shaped synthetic set; the last of `reps` repetitions is reported (the first two warm
+    the device allocator and the pinned permutation pool)."""
     a = argparse.Namespace(shards=shards, k=k, epochs=epochs, parallel=parallel, delper=delper)
     from ultrare_amd import synth
     from ultrare_amd.method.sisa import Sisa

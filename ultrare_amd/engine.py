@@ -144,6 +144,8 @@ class TrainJob:
             mU = torch.zeros(sh.n_user, self.d, dtype=torch.float32, device=dev)
             mV = torch.zeros(sh.n_item, self.d, dtype=torch.float32, device=dev)
             perm = torch.as_tensor(perm)
+            if getattr(perm, '_ure_event', None) is not None:       # uploaded on a side stream (rng.epoch_perms_async)
+                torch.cuda.current_stream(dev).wait_event(perm._ure_event)
             assert perm.shape == (self.epochs, sh.N), f'perm of shard {s} must be [epochs, N]'
             perm = perm.to(device=dev, dtype=torch.int32).contiguous()
             sse = torch.zeros(self.epochs, sh.n_user, dtype=torch.float32, device=dev)

@@ -40,7 +40,7 @@ def prepare_shard(train_loader, n_user, n_item, k, epochs, has_total, given_mode
     seeds = rng.epoch_seeds(epochs, has_total)
     n = len(loader.dataset)
     if loader.shuffle and defer:
-        perms = rng.epoch_perms_async(seeds, n, threads=PERM_THREADS, pooled=True)
+        perms = rng.epoch_perms_async(seeds, n, threads=PERM_THREADS, pooled=True, device=engine._device())
     elif loader.shuffle:
         perms = rng.epoch_perms(seeds, n, threads=PERM_THREADS, pooled=True)
     else:

@@ -32,14 +32,13 @@ def epoch_seeds(epochs, with_total_test):
     """Per epoch the reference draws: train loader base seed, sampler seed, group-test
     loader base seed and (SISA only) total-test loader base seed (scratch.py:78-97).
     Returns the sampler seeds; the others only advance the stream."""
-    seeds = []
-    for _ in range(epochs):
-        draw_seed()
-        seeds.append(draw_seed())
-        draw_seed()
-        if with_total_test:
-            draw_seed()
-    return seeds
+    per = 4 if with_total_test else 3
+    if epochs <= 0:
+        return []
+    # one vectorised draw: random_() fills serially from the same generator, so the values are those of
+    # `per * epochs` scalar draws (checked in tests/test_cpu_host.py)
+    draws = torch.empty(epochs * per, dtype=torch.int64).random_()
+    return [int(v) for v in draws[1::per].tolist()]
 
 
 def epoch_perm(seed, n):
@@ -86,7 +85,13 @@ POOL = _HostPool()
 def release(perms):
     """Hand a permutation buffer from epoch_perms(pooled=True) back (after it was uploaded)."""
     if torch.is_tensor(perms):
-        POOL.give(perms)
+        host = getattr(perms, '_ure_host', None)
+        if host is not None:                    # uploaded by the background worker: wait for that copy
+            perms._ure_event.synchronize()
+            POOL.give(host)
+            perms._ure_host = None
+        else:
+            POOL.give(perms)
 
 
 def epoch_perms(seeds, n, threads=0, pooled=False):
@@ -110,10 +115,17 @@ def epoch_perms(seeds, n, threads=0, pooled=False):
 _EXPANDER = None
 
 
-def epoch_perms_async(seeds, n, threads=0, pooled=False):
+_UPLOAD_STREAMS = {}
+
+
+def epoch_perms_async(seeds, n, threads=0, pooled=False, device=None):
     """epoch_perms on a background thread: returns a future whose result() is the tensor.  The seeds
     are already drawn, so expanding them needs nothing from torch's generator and overlaps with the
-    caller's next draws (the next shard's model init); the native call runs without the GIL."""
+    caller's next draws (the next shard's model init); the native call runs without the GIL.
+    With `device` the worker also uploads the permutations on a side stream as soon as they exist;
+    result() is then the DEVICE tensor, carrying `_ure_event` (recorded after the copy: consumers
+    make their stream wait for it, engine.TrainJob does) and `_ure_host` (the pinned source,
+    handed back by release() once the copy is done)."""
     global _EXPANDER
     if _EXPANDER is None:
         from concurrent.futures import ThreadPoolExecutor
@@ -130,9 +142,31 @@ def epoch_perms_async(seeds, n, threads=0, pooled=False):
     out = POOL.take((len(seeds), n), torch.int32) if pooled else torch.empty(len(seeds), n, dtype=torch.int32)
     sd = np.asarray(seeds, dtype=np.uint64).astype(np.int64)
 
+    on_dev = ready = None
+    if device is not None and torch.device(device).type == 'cuda':
+        # destination allocated here, on the caller's stream (the allocator's pools are per stream);
+        # the side stream starts its copy only after whatever the caller's stream was doing with that memory
+        dev = torch.device(device)
+        on_dev = torch.empty((len(seeds), n), dtype=torch.int32, device=dev)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+
     def work():
         nv.check(nv.lib().ure_host_randperm(sd.ctypes.data, len(sd), n, out.data_ptr(), int(threads or 0)), 'ure_host_randperm')
-        return out
+        if on_dev is None:
+            return out
+        dev = on_dev.device
+        with torch.cuda.device(dev):
+            st = _UPLOAD_STREAMS.get(dev)
+            if st is None:
+                st = _UPLOAD_STREAMS[dev] = torch.cuda.Stream(dev)
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                on_dev.copy_(out, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(st)
+        on_dev._ure_event, on_dev._ure_host = ev, out
+        return on_dev
     return _EXPANDER.submit(work)
 
 
