@@ -161,7 +161,9 @@ def main():
     # be collected from inside the process); the committed summary is quoted with its source
     traffic, traffic_src = None, None
     import glob
-    pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', '*pmc_hbm_traffic.json')))
+    import re
+    pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', '*pmc_hbm_traffic.json')),
+                 key=lambda f: [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', os.path.relpath(f, ROOT))])   # v9 < v10
     if pmc and a.workload == 'ml1m' and a.d == 32 and a.shards == 5 and a.batch == 30000:
         try:
             with open(pmc[-1]) as f:
