@@ -19,6 +19,8 @@ from ..read import as_loader
 from .utils import MF, padded_tables, seed_all
 
 PERM_THREADS = int(os.environ.get('URE_PERM_THREADS', str(min(16, os.cpu_count() or 1))))
+# end-of-epoch snapshots kept on the device for the per-epoch test series (per shard job)
+SNAPSHOT_LIMIT_BYTES = int(float(os.environ.get('URE_SNAPSHOT_LIMIT_GB', '8')) * 2 ** 30)
 
 
 def _is_empty(x):
@@ -96,20 +98,31 @@ class Scratch(object):
         has_total = not _is_empty(test_total)
         shard, init, perms = prepare_shard(train_data, self.n_user, self.n_item, self.k, self.epochs, has_total, given_model)
         batch = as_loader(train_data).batch_size
+        # verbose 0: nothing is printed per epoch, so the epochs run back to back, every epoch end is kept
+        # on the device (snapshots) and the two test series of scratch.py:83-97 are computed afterwards
+        # in four launches each (ure_eval_series); otherwise each epoch synchronises to print
+        queued = verbose == 0
+        snap_bytes = self.epochs * (self.n_user + self.n_item) * engine.pad_dim(self.k) * 4
+        series = queued and snap_bytes <= SNAPSHOT_LIMIT_BYTES
         job = engine.TrainJob([shard], [init], [perms], self.k, batch, self.epochs, self.lr, self.lam, self.momentum,
-                              self.lr_decay)
+                              self.lr_decay, snapshots=series)
         rng.release(perms)                                  # uploaded: the host buffer goes back to the pool
         test_ev = as_loader(test_data).eval_set()
         total_ev = as_loader(test_total).eval_set() if has_total else None
         before = [padded_tables(m)[:2] for m in self._models_before()]
         n_train = shard.N
 
-        # verbose 0: nothing is printed per epoch, so the two tests of every epoch are queued on the
-        # stream and all results are read once at the end; otherwise each epoch synchronises to print
-        queued = verbose == 0
         res = torch.zeros(self.epochs, 2, 3, dtype=torch.float64, device=shard.device) if queued else None
         times = []
-        for t in range(self.epochs):
+        if series:
+            job.run()
+            res = torch.zeros(2, self.epochs, 3, dtype=torch.float64, device=shard.device)
+            snapU, snapV = job.snapshots_of(0)
+            test_ev.evaluate_series(before, snapU, snapV, job.d, res[0])
+            (total_ev if has_total else test_ev).evaluate_series(before, snapU, snapV, job.d, res[1])
+            res = res.transpose(0, 1).contiguous()
+            times = ['00:00:00'] * self.epochs
+        for t in range(0 if not series else self.epochs, self.epochs):
             if verbose == 2:
                 print(f'Epoch: [{t+1:>3d}/{self.epochs:>3d}] --------------------')
             epoch_start = time.time()

@@ -23,11 +23,10 @@ from torch import nn
 
 from .. import engine
 from ..read import as_loader
-from .scratch import Scratch, prepare_shard
+from .scratch import Scratch, prepare_shard, SNAPSHOT_LIMIT_BYTES
 from .utils import MF, baseTest, padded_tables, seed_all
 
 
-SNAPSHOT_LIMIT_BYTES = int(float(os.environ.get('URE_SNAPSHOT_LIMIT_GB', '8')) * 2 ** 30)
 
 
 def _dist():
