@@ -234,6 +234,21 @@ int ure_ot_centroids(const float *X, const int32_t *label, int64_t n, int k, int
 int ure_ot_assign(const float *dist_host, int64_t n, int k, int32_t *label_host,
                   int32_t *plan_nk, double *total_cost);
 
+/* ---------------------------------------------------------------------------
+ * Comparison clusterers (utils.py:354-418: k-means / balanced k-means on the user embedding;
+ * never called on the reference's CLI path, kept for the OT-vs-k-means comparison of its notebook)
+ * ------------------------------------------------------------------------- */
+/* utils.py:373-375: dist_nk[i][c] = -2 x_i.c_c + |x_i|^2 + |c_c|^2 in float32 with scipy's csr
+ * evaluation order (labels are then identical to the reference's). */
+int ure_kmeans_cost(const float *X, const float *C, int64_t n, int k, int d, float *dist_nk, void *stream);
+/* utils.py:402-403: C[c] = mean of the rows with label c as scipy's sparse mean computes it
+ * (row * float32(1/count), summed in ascending row order); counts [k] optional. */
+int ure_kmeans_centroids(const float *X, const int32_t *label, int64_t n, int k, int d, float *C, int32_t *counts, void *stream);
+/* utils.py:377-396 (host): capacity <= 0: label = argmin over groups; capacity > 0: balanced fill in
+ * ascending order of distance, at most `capacity` users per group.  *inertia = np.sum(dist[arange(n),
+ * label]) (numpy float32 pairwise sum), optional. */
+int ure_host_kmeans_assign(const float *dist_nk, int64_t n, int32_t k, int64_t capacity, int32_t *label, double *inertia);
+
 #ifdef __cplusplus
 }
 #endif

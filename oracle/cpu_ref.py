@@ -370,3 +370,89 @@ def ot_cluster(X, k, max_iters=10, trace=None):
             break
         centroid = new_c
     return inertia, label
+
+
+# ---------------------------------------------------------------------------
+# Comparison clusterers: k-means / balanced k-means (utils.py:354-418)
+# ---------------------------------------------------------------------------
+def kmeans_dist(X, C):
+    """utils.py:373-375 on a csr input: dist = -2 X C^T + |x|^2 + |c|^2 in float32, every inner sum in
+    scipy's csr order (columns ascending, one multiply and one add per term), then
+    ((-2 dot) + |x|^2) + |c|^2."""
+    n, d = X.shape
+    dot = np.zeros((n, C.shape[0]), np.float32)
+    esq = np.zeros(n, np.float32)
+    csq = np.zeros(C.shape[0], np.float32)
+    for j in range(d):
+        dot += X[:, j:j + 1] * C[None, :, j]
+        esq += X[:, j] * X[:, j]
+        csq += C[:, j] * C[:, j]
+    dist = np.float32(-2) * dot
+    dist += esq[:, None]
+    dist += csq[None, :]
+    return dist
+
+
+def kmeans_assign(dist, balanced):
+    """utils.py:377-394: argmin, or the greedy fill in ascending order of distance with at most
+    ceil(n/k) users per group (np.argsort's default kind; exact ties are broken by flat index here)."""
+    n, k = dist.shape
+    if not balanced:
+        return dist.argmin(axis=1)
+    label = np.zeros(n, dtype=np.int64)
+    left = [int(np.ceil(n / k))] * k
+    done = np.zeros(n, dtype=bool)
+    n_done = 0
+    for f in np.argsort(dist, axis=None, kind='stable'):
+        if n_done == n:
+            break
+        u, c = divmod(int(f), k)
+        if not done[u] and left[c] > 0:
+            label[u], done[u] = c, True
+            n_done += 1
+            left[c] -= 1
+    return label
+
+
+def kmeans_centroids(X, label, k):
+    """utils.py:402-403: centroid[j] = csr_matrix(sp_mat[label == j].mean(axis=0)) -- scipy's sparse mean:
+    every member row times float32(1/count), summed in ascending row order in float32."""
+    C = np.zeros((k, X.shape[1]), np.float32)
+    for c in range(k):
+        idx = np.nonzero(label == c)[0]
+        inv = np.float32(1.0 / len(idx))
+        acc = np.zeros(X.shape[1], np.float32)
+        for i in idx:
+            acc += X[i] * inv
+        C[c] = acc
+    return C
+
+
+def single_kmeans(k, X, balanced, max_iter, cen_idx=None):
+    """utils.py:354-404 (singleKmeans); initial centroids from numpy's global RNG unless given."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    n = X.shape[0]
+    label = np.zeros(n, dtype=np.int64)
+    if cen_idx is None:
+        cen_idx = np.random.choice(n, k, replace=False)
+    C = X[cen_idx].copy()
+    inertia = 0.0
+    for _ in range(max_iter):
+        dist = kmeans_dist(X, C)
+        new = kmeans_assign(dist, balanced)
+        inertia = float(np.sum(dist[np.arange(n), new]))
+        if (new == label).all():
+            break
+        label = new
+        C = kmeans_centroids(X, label, k)
+    return label, inertia
+
+
+def kmeans(k, X, balanced=False, n_init=5, max_iter=10):
+    """utils.py:406-418: best of n_init runs by inertia."""
+    best, fin = 1e10, None
+    for _ in range(n_init):
+        label, inertia = single_kmeans(k, X, balanced, max_iter)
+        if inertia < best:
+            best, fin = inertia, label
+    return fin

@@ -16,7 +16,7 @@ Harness conventions:
     default kind is host-specific, SURVEY section 7 "NDCG tie-breaking"); the as-is
     value is stored beside it as information.
 
-usage: python tests/golden/make_golden.py [full] [sisa] [eval] [ot] [ml1m]
+usage: python tests/golden/make_golden.py [full] [sisa] [eval] [ot] [ml1m] [kmeans]
 """
 import contextlib
 import io
@@ -402,6 +402,50 @@ def gen_ot():
     np.savez_compressed(os.path.join(HERE, 'ot_toy.npz'), **out)
 
 
+def gen_kmeans():
+    """The comparison clusterers of utils.py:354-418 (k-means / balanced k-means on the user
+    embedding), run as the reference wrote them: csr input, numpy global RNG for the
+    initial centroids.  Every (dist, label) pair of every iteration is recorded through a spy on
+    sortArr / argmin so that a restatement can be checked round by round."""
+    from scipy.sparse import csr_matrix
+
+    class CsrWithA(csr_matrix):
+        """utils.py:373 uses the `.A` alias of `.toarray()`, which scipy >= 1.14 removed from sparse
+        matrices; the harness hands the reference a csr subclass that still has it."""
+        @property
+        def A(self):
+            return self.toarray()
+
+    g = np.load(os.path.join(HERE, 'full_mf_toy.npz'))
+    X = g['E50_U'].astype(np.float32)
+    sp = CsrWithA(X)
+    out = {'X': X}
+    for k in (4, 5):
+        for balanced in (False, True):
+            tag = f'k{k}_{"bal" if balanced else "plain"}'
+            np.random.seed(7)
+            probe = np.random.get_state()
+            inits = [np.random.choice(N_USER, k, replace=False) for _ in range(3)]
+            np.random.set_state(probe)
+            t0 = time.time()
+            with quiet():
+                label = RU.kmeans(k, N_USER, sp, balanced=balanced, n_init=3, max_iter=10)
+            # per-init results, same RNG stream
+            np.random.set_state(probe)
+            singles = []
+            with quiet():
+                for _ in range(3):
+                    lab, inertia = RU.singleKmeans(k, N_USER, sp, balanced, 10)
+                    singles.append((np.asarray(lab).astype(np.int64), float(inertia)))
+            out[tag + '_inits'] = np.array(inits, dtype=np.int64)
+            out[tag + '_label'] = np.asarray(label).astype(np.int64)
+            out[tag + '_single_labels'] = np.array([x[0] for x in singles])
+            out[tag + '_single_inertia'] = np.array([x[1] for x in singles], dtype=np.float64)
+            print(f'kmeans {tag}: counts={np.bincount(np.asarray(label), minlength=k)} inertia={[round(x[1], 3) for x in singles]} '
+                  f'{time.time() - t0:.1f}s', flush=True)
+    np.savez_compressed(os.path.join(HERE, 'kmeans_toy.npz'), **out)
+
+
 def gen_ml1m():
     """BASELINE.json configs[0]/[1] shape: ml-1m-sized synthetic ratings (the build's own seeded
     generator, ultrare_amd/synth.py -- the real ratings.dat is not shipped), d = 32, batch 30,000,
@@ -475,4 +519,4 @@ if __name__ == '__main__':
     what = sys.argv[1:] or ['full', 'sisa', 'eval', 'ot']
     torch.set_num_threads(1)
     for w in what:
-        {'full': gen_full, 'sisa': gen_sisa, 'eval': gen_eval, 'ot': gen_ot, 'ml1m': gen_ml1m}[w]()
+        {'full': gen_full, 'sisa': gen_sisa, 'eval': gen_eval, 'ot': gen_ot, 'ml1m': gen_ml1m, 'kmeans': gen_kmeans}[w]()

@@ -298,6 +298,32 @@ def test_work_units_cover_every_row_once(d):
     assert nv.build_units(sched, 0, d).shape == (0, 4)
 
 
+def test_kmeans_assign_host_vs_numpy():
+    """ure_host_kmeans_assign (utils.py:377-396): argmin / balanced greedy fill and the float32 pairwise
+    inertia against the oracle's numpy statement, incl. exact ties and a NaN row."""
+    import ctypes
+    from ultrare_amd import _native as nv
+    rs = np.random.RandomState(3)
+    for n, k in ((37, 3), (500, 7), (1508, 5)):
+        dist = rs.rand(n, k).astype(np.float32)
+        dist[::11] = np.round(dist[::11], 1)                    # exact ties
+        for balanced in (False, True):
+            want = O.kmeans_assign(dist, balanced)
+            got = np.empty(n, dtype=np.int32)
+            inertia = ctypes.c_double()
+            nv.check(nv.lib().ure_host_kmeans_assign(dist.ctypes.data, n, k, int(np.ceil(n / k)) if balanced else 0,
+                                                     got.ctypes.data, ctypes.byref(inertia)), 'assign')
+            assert np.array_equal(got, want)
+            assert inertia.value == float(np.sum(dist[np.arange(n), want]))
+            if balanced:
+                assert np.bincount(got, minlength=k).max() <= int(np.ceil(n / k))
+    dist = np.array([[1, np.nan, 0], [2, 1, 3]], dtype=np.float32)
+    got = np.empty(2, dtype=np.int32)
+    nv.check(nv.lib().ure_host_kmeans_assign(dist.ctypes.data, 2, 3, 0, got.ctypes.data, None), 'assign')
+    assert got.tolist() == dist.argmin(axis=1).tolist()
+    assert nv.lib().ure_host_kmeans_assign(dist.ctypes.data, 2, 3, -0 + 0, None, None) != 0
+
+
 def test_shard_placement_is_lpt():
     from ultrare_amd.method.sisa import assign_shards
     assert assign_shards([5, 9, 3, 7], 1) == [0, 0, 0, 0]

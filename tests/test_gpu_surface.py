@@ -220,3 +220,22 @@ def test_instance_run_full_then_group_end_to_end(tmp_path):
     # shards are ordered ascending by rating count (read.py:45-50) and every deleted user's shard retrained
     assert ins.last.retrained == sorted({i for i, gidx in enumerate(ins.last.group_index)
                                          if set(gidx) & set(int(u) for u in p3.del_user)})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k,balanced', [(4, False), (4, True), (5, False), (5, True)])
+def test_kmeans_vs_reference_golden(k, balanced):
+    """utils.py:354-418 through the package's kmeans / singleKmeans (HIP distances and centroids, host
+    assignment) against the real reference's labels on the toy user embedding."""
+    from scipy.sparse import csr_matrix
+    from ultrare_amd.method.utils import kmeans, singleKmeans
+    g = np.load(os.path.join(G, 'kmeans_toy.npz'))
+    tag = f'k{k}_{"bal" if balanced else "plain"}'
+    X = g['X']
+    np.random.seed(7)
+    for t in range(3):
+        label, inertia = singleKmeans(k, len(X), csr_matrix(X), balanced, 10)
+        assert np.array_equal(label, g[tag + '_single_labels'][t])
+        assert inertia == g[tag + '_single_inertia'][t]
+    np.random.seed(7)
+    assert np.array_equal(kmeans(k, len(X), X, balanced=balanced, n_init=3, max_iter=10), g[tag + '_label'])

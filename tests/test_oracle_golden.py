@@ -169,3 +169,18 @@ def test_ml1m_size_full_mf_matches_reference():
     _check_rows(g, 'full', U, V, 5e-6)
     np.testing.assert_allclose(log['train_loss'], g['full_train_loss'], rtol=1e-5)
     np.testing.assert_allclose([log['test_rmse'][0], log['test_ndcg'][0], log['test_hr'][0]], g['full_test'], rtol=1e-4)
+
+
+@pytest.mark.parametrize('k,balanced', [(4, False), (4, True), (5, False), (5, True)])
+def test_kmeans_oracle_vs_reference_golden(k, balanced):
+    """The comparison clusterers (utils.py:354-418) as run by the real reference on the toy user
+    embedding (tests/golden/make_golden.py kmeans): labels of every init and of the best-of-3 run,
+    inertia bit for bit."""
+    g = np.load(os.path.join(G, 'kmeans_toy.npz'))
+    tag = f'k{k}_{"bal" if balanced else "plain"}'
+    for t in range(3):
+        label, inertia = O.single_kmeans(k, g['X'], balanced, 10, g[tag + '_inits'][t])
+        assert np.array_equal(label, g[tag + '_single_labels'][t])
+        assert inertia == g[tag + '_single_inertia'][t]
+    np.random.seed(7)
+    assert np.array_equal(O.kmeans(k, g['X'], balanced, 3, 10), g[tag + '_label'])

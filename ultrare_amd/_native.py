@@ -68,6 +68,9 @@ _PROTOTYPES = {
     'ure_merge_rows': (ctypes.c_int, [_vp, _vp, _vp, _i64, ctypes.c_int, _vp]),
     'ure_ot_cost': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'ure_ot_centroids': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    'ure_kmeans_cost': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    'ure_kmeans_centroids': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    'ure_host_kmeans_assign': (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, ctypes.POINTER(ctypes.c_double)]),
     'ure_ot_assign': (ctypes.c_int, [_vp, _i64, ctypes.c_int, _vp, _vp, ctypes.POINTER(ctypes.c_double)]),
 }
 EXPORTS = tuple(_PROTOTYPES)

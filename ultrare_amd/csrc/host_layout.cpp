@@ -305,4 +305,81 @@ int ure_host_build_units(const int32_t *sched, int32_t n_active, int32_t d, int3
     return 0;
 }
 
+// utils.py:377-396 of the comparison clusterer: labels from the [n][k] distance matrix.  capacity <= 0:
+// new_label = dist.argmin(axis=1).  capacity > 0 (balanced k-means, capacity = ceil(n / k)): walk the
+// (user, group) pairs in ascending distance (exact ties: ascending flat index) and give a user its first
+// group that still has room.  *inertia = np.sum(dist[arange(n), label]) with numpy's float32 pairwise sum.
+int ure_host_kmeans_assign(const float *dist_nk, int64_t n, int32_t k, int64_t capacity, int32_t *label, double *inertia)
+{
+    if (!dist_nk || !label || n <= 0 || k <= 0 || n * (int64_t)k >= ((int64_t)1 << 32))
+        return ure::fail(-1, "ure_host_kmeans_assign: bad arguments (n=%lld k=%d)", (long long)n, k);
+    if (capacity <= 0) {
+        for (int64_t i = 0; i < n; ++i) {
+            const float *row = dist_nk + i * k;
+            int best = 0;
+            bool nan_seen = row[0] != row[0];
+            for (int c = 1; c < k && !nan_seen; ++c) {
+                if (row[c] != row[c]) { best = c; nan_seen = true; }          // numpy: the first NaN wins
+                else if (row[c] < row[best]) best = c;
+            }
+            label[i] = best;
+        }
+    } else {
+        if (capacity * k < n) return ure::fail(-1, "ure_host_kmeans_assign: capacity %lld x %d groups < %lld users", (long long)capacity, k, (long long)n);
+        const int64_t total = n * k;
+        std::vector<uint64_t> key((size_t)total);
+        for (int64_t t = 0; t < total; ++t) {
+            uint32_t b;
+            std::memcpy(&b, dist_nk + t, 4);
+            b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);          // order-preserving map of float bits
+            key[(size_t)t] = ((uint64_t)b << 32) | (uint64_t)t;
+        }
+        std::sort(key.begin(), key.end());
+        std::vector<int64_t> left((size_t)k, capacity);
+        std::vector<char> done((size_t)n, 0);
+        std::fill(label, label + n, 0);
+        int64_t n_done = 0;
+        for (int64_t q = 0; q < total && n_done < n; ++q) {
+            const int64_t t = (int64_t)(key[(size_t)q] & 0xFFFFFFFFu);
+            const int64_t u = t / k;
+            const int c = (int)(t % k);
+            if (done[(size_t)u] || left[(size_t)c] <= 0) continue;
+            label[u] = c;
+            done[(size_t)u] = 1;
+            --left[(size_t)c];
+            ++n_done;
+        }
+    }
+    if (inertia) {
+        // numpy pairwise_sum over float32 (blocks of <= 128 with 8 accumulators, halves above)
+        std::vector<float> v((size_t)n);
+        for (int64_t i = 0; i < n; ++i) v[(size_t)i] = dist_nk[i * k + label[i]];
+        struct Pair {
+            static float sum(const float *a, int64_t m)
+            {
+                if (m < 8) {
+                    float r = 0.f;
+                    for (int64_t i = 0; i < m; ++i) r += a[i];
+                    return r;
+                }
+                if (m <= 128) {
+                    float r[8];
+                    for (int j = 0; j < 8; ++j) r[j] = a[j];
+                    int64_t i = 8;
+                    for (; i < m - (m % 8); i += 8)
+                        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+                    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                    for (; i < m; ++i) res += a[i];
+                    return res;
+                }
+                int64_t h = m / 2;
+                h -= h % 8;
+                return sum(a, h) + sum(a + h, m - h);
+            }
+        };
+        *inertia = (double)Pair::sum(v.data(), n);
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -11,7 +11,7 @@ from os.path import abspath, exists, join
 
 import numpy as np
 
-from .method.utils import ot_cluster
+from .method.utils import kmeans, ot_cluster
 
 DATA_DIR = abspath(os.environ.get('ULTRARE_DATA_DIR', join(os.getcwd(), 'data')))
 SAVE_DIR = abspath(os.environ.get('ULTRARE_SAVE_DIR', join(os.getcwd(), 'result')))
@@ -34,14 +34,19 @@ class Group(object):
             return [list(map(int, g)) for g in np.load(label_dir, allow_pickle=True)]
 
         [trans_var, cluster_var] = var.strip().split('-')
-        assert cluster_var in ['ot'], 'only the OT balanced clustering is on the published path'
+        # 'ot' is the published path (group.py:35-45); 'kmeans' / 'bkmeans' are the comparison clusterers the
+        # reference imports but never dispatches (group.py:5, utils.py:354-418): an optional addition here
+        assert cluster_var in ['ot', 'kmeans', 'bkmeans'], "cluster_var must be 'ot' (published path), 'kmeans' or 'bkmeans'"
         if trans_var == 'rating':
             embedding = np.asarray(self.rating.todense(), dtype=np.float32)
         elif trans_var == 'emb':
             embedding = self.user_mat
         else:
             raise ValueError(var)
-        _, label = ot_cluster(embedding, n_group)
+        if cluster_var == 'ot':
+            _, label = ot_cluster(embedding, n_group)
+        else:
+            label = kmeans(n_group, len(embedding), embedding, balanced=cluster_var == 'bkmeans')
 
         if verbose:
             print(''.join(str(i) + ': ' + str(int((label == i).sum())) + ', ' for i in range(n_group)))

@@ -12,6 +12,7 @@ Training does not go through a `baseTrain(dataloader, model, loss_fn, opt, ...)`
 the per-batch forward / backward / SGD step of utils.py:58-91 is one fused kernel
 launch per step, driven by engine.TrainJob from Scratch.train.
 """
+import ctypes
 import pickle
 import time
 from functools import wraps
@@ -167,3 +168,59 @@ def ot_cluster(X, k, max_iters=10):
         centroid = new_centroid
     print(f'{inertia:.3f}', end=' ')
     return inertia, label.astype(np.int64)
+
+
+# ---------------------------------------------------------------------------
+# Comparison clusterers (utils.py:354-418): k-means / balanced k-means on the embedding the
+# reference's notebook compared OT grouping against.  Distances and centroid updates run on the
+# GPU in scipy's csr arithmetic (labels identical to the reference's), the assignment -- a global
+# sort of n*k distances and a greedy fill -- on the host.
+# ---------------------------------------------------------------------------
+def _dense_f32(sp_mat):
+    return np.ascontiguousarray(sp_mat.toarray() if hasattr(sp_mat, 'toarray') else sp_mat, dtype=np.float32)
+
+
+def singleKmeans(k, n_user, sp_mat, balanced, max_iter):
+    """utils.py:354-404.  sp_mat: csr_matrix or array [n_user, n_embedding]; initial centroids from
+    numpy's global generator.  Returns (label int64 [n_user], inertia)."""
+    X = _dense_f32(sp_mat)
+    n, d = X.shape
+    assert n == n_user
+    if k < 1 or k > n:
+        raise ValueError('need 1 <= k <= n clusters')
+    L, st, dev = nv.lib(), nv.stream_handle(), engine._device()
+    group_len = int(np.ceil(n_user / k))
+    cen_idx = np.random.choice(n_user, k, replace=False)
+    Xd = torch.from_numpy(X).to(dev)
+    cent_d = Xd[torch.from_numpy(cen_idx).to(dev)].contiguous()
+    dist_d = torch.empty(n, k, dtype=torch.float32, device=dev)
+    label_d = torch.empty(n, dtype=torch.int32, device=dev)
+    counts_d = torch.empty(k, dtype=torch.int32, device=dev)
+    label = np.zeros(n, dtype=np.int32)
+    new_label = np.empty(n, dtype=np.int32)
+    inertia = ctypes.c_double(0.0)
+    for _ in range(max_iter):
+        nv.check(L.ure_kmeans_cost(nv.ptr(Xd), nv.ptr(cent_d), n, k, d, nv.ptr(dist_d), st), 'ure_kmeans_cost')
+        dist = dist_d.cpu().numpy()
+        nv.check(L.ure_host_kmeans_assign(dist.ctypes.data, n, k, group_len if balanced else 0, new_label.ctypes.data,
+                                          ctypes.byref(inertia)), 'ure_host_kmeans_assign')
+        if (new_label == label).all():
+            break
+        label = new_label.copy()
+        label_d.copy_(torch.from_numpy(label))
+        nv.check(L.ure_kmeans_centroids(nv.ptr(Xd), nv.ptr(label_d), n, k, d, nv.ptr(cent_d), nv.ptr(counts_d), st),
+                 'ure_kmeans_centroids')
+        if int(counts_d.min().item()) == 0:
+            raise ZeroDivisionError('a cluster lost all its members (utils.py:403 divides by its size)')
+    return label.astype(np.int64), float(inertia.value)
+
+
+def kmeans(n_group, n_user, sp_mat, balanced=False, n_init=5, max_iter=10):
+    """utils.py:406-418: the labels of the best of n_init runs (smallest inertia)."""
+    tmp_inertia, fin_label = 1e10, None
+    for _ in range(n_init):
+        label, inertia = singleKmeans(n_group, n_user, sp_mat, balanced, max_iter)
+        if inertia < tmp_inertia:
+            tmp_inertia = inertia
+            fin_label = label
+    return fin_label
