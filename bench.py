@@ -209,6 +209,10 @@ def main():
                    'includes': 'host RNG + layout, 50 epochs of all retrained shards side by side, per-epoch shard/total '
                                'evaluations, row merge, final test; inputs as in-memory loaders',
                    'final_test': {'learn': r['log0'], 'unlearn': r['unlearn_log0']}}
+        # BASELINE.json configs[4]: 16 shards (d = the reference's default k = 16), 2 % random deletion
+        r16 = e2e.measure(16, 16, 50, 1, 2.0, data=data)
+        unlearn['config4_16_shards_k16'] = {'learn_wall_s': r16['learn_s'], 'unlearn_wall_s': r16['unlearn_s'],
+                                            'retrained_shards': r16['retrained_shards'], 'deleted_users': r16['deleted_users']}
 
     if rank == 0:
         arch = ''
