@@ -158,6 +158,28 @@ def test_eval_series_equals_single_evaluations(toy):
             assert torch.equal(got, want)
 
 
+def test_many_epochs_vs_oracle(toy):
+    """120 epochs of two shards side by side (the batch tags of epoch e+1 are prepared by extra workgroups of
+    epoch e's launches into the other half of a double buffer, 119 times over) against the C oracle, with the
+    StepLR decay crossing its boundaries (epochs 50 and 100)."""
+    from ultrare_amd import engine, rng
+    raw = O.load_csv(os.path.join(G, 'toy', '0_train.csv'))
+    parts = O.partition(*raw, O.uniform_groups(N_USER, 2))
+    k, B, E = 16, 1500, 120
+    torch.manual_seed(9)
+    inits = [rng.mf_init(N_USER, N_ITEM, k) for _ in parts]
+    perms = [rng.epoch_perms(rng.epoch_seeds(E, True), len(p[0])) for p in parts]
+    job = engine.TrainJob([engine.ShardData(*p, N_USER, N_ITEM) for p in parts], inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95)
+    job.run()
+    torch.cuda.synchronize()
+    for s_, p in enumerate(parts):
+        st = O.MFState(inits[s_][0].numpy().copy(), inits[s_][1].numpy().copy())
+        losses = [O.train_epoch(st, p, perms[s_][t].numpy(), B, 1e-3 * 0.95 ** (t // 50), 0.1, 0.9)[0] for t in range(E)]
+        U, V = job.tables(s_)
+        assert rel(U.cpu().numpy(), st.U) < 1e-4 and rel(V.cpu().numpy(), st.V) < 1e-4
+        np.testing.assert_allclose(np.sqrt(job.epoch_sse(s_) / len(p[0])), losses, rtol=1e-4)
+
+
 def test_bitwise_reproducible(toy):
     train, _ = toy
     a = _train_gpu(train, 32, 3000, 2)
