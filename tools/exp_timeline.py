@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument('--lib', default=os.path.join(ROOT, 'tools', 'ab', 'libtimeline.so'))
+ap.add_argument('--shards', type=int, default=5)
 a = ap.parse_args()
 from ultrare_amd import _native as nv
 nv.LIB_PATH = os.path.abspath(a.lib)
@@ -21,7 +22,7 @@ from ultrare_amd import engine, rng, synth
 
 spec = synth.ML1M
 data = synth.make_dataset(**spec)
-S, d, B, E = 5, 32, 30000, 12
+S, d, B, E = a.shards, 32, 30000, 12
 shard_of, _ = synth.uniform_shards(spec['n_user'], S)
 parts = synth.split_shards(data['train'], shard_of, S)
 torch.manual_seed(42)
@@ -56,6 +57,16 @@ for tick in range(28, 42):
         m = (sh == k) & (wg < len(heavy[k]))
         kind[m] = np.where(heavy[k][wg[m]] > 0, 'multi ', 'single')
     spans.append(en.max())
+    if tick == 34:      # the slowest workgroups of one launch: which units do they hold?
+        dur_all = en - st
+        for q in np.argsort(-dur_all)[:12]:
+            if kind[q] == 'rider ':
+                print(f'      slow: rider shard {sh[q]} wg {wg[q]} dur {dur_all[q]:.2f} start {st[q]:.2f}')
+                continue
+            un = shards[sh[q]].units(d).cpu().numpy()[wg[q] * upb:(wg[q] + 1) * upb]
+            lens = un[:, 2] - un[:, 1]
+            print(f'      slow: shard {sh[q]} wg {wg[q]} dur {dur_all[q]:.2f} start {st[q]:.2f} rows {len(set(un[un[:, 0] >= 0, 0].tolist()))} '
+                  f'max unit {lens.max()} slots {lens.sum()} max count {((un[:, 3] >> 16) & 0x1FFF).max()}')
     print(f'tick {tick}: {len(idx)} workgroups, span {en.max():.2f} us')
     for kd in ('multi ', 'single', 'rider '):
         m = kind == kd
