@@ -57,6 +57,12 @@ for tick in range(28, 42):
         m = (sh == k) & (wg < len(heavy[k]))
         kind[m] = np.where(heavy[k][wg[m]] > 0, 'multi ', 'single')
     spans.append(en.max())
+    if tick == 34:      # per XCD (workgroup id mod 8): which shards it serves, how long its row workgroups take
+        for x in range(8):
+            m = ((idx & 7) == x) & (kind != 'rider ')
+            dx = en[m] - st[m]
+            print(f'      xcd {x}: shards {sorted(set(sh[m].tolist()))} row workgroups {m.sum()} dur med {np.median(dx):.2f} p90 {np.percentile(dx, 90):.2f} '
+                  f'max {dx.max():.2f} end max {en[m].max():.2f} | riders {(((idx & 7) == x) & (kind == "rider ")).sum()}')
     if tick == 34:      # the slowest workgroups of one launch: which units do they hold?
         dur_all = en - st
         for q in np.argsort(-dur_all)[:12]:
