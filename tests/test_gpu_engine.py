@@ -143,7 +143,8 @@ def test_eval_series_equals_single_evaluations(toy):
     ev = engine.EvalSet(*test)
     fixed = [tuple(t.to(ev.device).contiguous() for t in init) for init in inits[1:]]
     snapU, snapV = job.snapshots_of(0)
-    for before in ([], fixed):
+    many = [tuple(torch.randn_like(t) * 0.3 for t in fixed[0]) for _ in range(35)]       # more than one chunk of 32 fixed models
+    for before in ([], fixed, many):
         want = torch.zeros(E, 3, dtype=torch.float64, device=ev.device)
         for e in range(E):
             ev.evaluate(before + [job.snapshot(0, e)], job.d, out=want[e])

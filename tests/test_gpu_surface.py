@@ -239,3 +239,18 @@ def test_kmeans_vs_reference_golden(k, balanced):
         assert inertia == g[tag + '_single_inertia'][t]
     np.random.seed(7)
     assert np.array_equal(kmeans(k, len(X), X, balanced=balanced, n_init=3, max_iter=10), g[tag + '_label'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,k,d,balanced', [(300, 3, 200, True), (1000, 7, 33, False), (640, 4, 8, True)])
+def test_kmeans_kernels_vs_oracle_random(n, k, d, balanced):
+    """ure_kmeans_cost / ure_kmeans_centroids / ure_host_kmeans_assign on random data of odd shapes (any d, e.g. a
+    rating matrix as embedding) against the numpy statements of the oracle, one full singleKmeans run."""
+    from ultrare_amd.method.utils import singleKmeans
+    rs = np.random.RandomState(n + d)
+    X = (rs.randn(n, d) * (rs.rand(n, d) < 0.6)).astype(np.float32)        # sparse-ish, like ratings
+    np.random.seed(3)
+    want_label, want_inertia = O.single_kmeans(k, X, balanced, 6)
+    np.random.seed(3)
+    label, inertia = singleKmeans(k, n, X, balanced, 6)
+    assert np.array_equal(label, want_label) and inertia == want_inertia
