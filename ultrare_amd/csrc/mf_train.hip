@@ -29,8 +29,9 @@
 //   * Batch membership is a 2-byte tag per slot, double-buffered by epoch parity; the steps of an
 //     epoch carry the preparation of the next epoch's tags as extra workgroups at the end of the
 //     grid (tag_prep.h).
-//   * Shards are independent (sisa.py:33-36), so a job's shards share each launch
-//     (blockIdx.x = shard): one tick advances every shard by one optimizer step.
+//   * Shards are independent (sisa.py:33-36), so a job's shards share each launch: one tick advances
+//     every shard by one optimizer step.  Workgroups are dealt out to (shard, workgroup) so that an XCD
+//     works on at most two shards (sliced mapping, see mf_step).
 //
 // Algorithmic bytes per interaction and step: 16 + 16 d sparse,
 // 20 P dense; this kernel moves 16 P dense (no gradient read) + the tag scan.
