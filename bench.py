@@ -9,16 +9,29 @@ Workload (BASELINE.json configs[1]): ml-1m-shaped synthetic ratings (6040 x 3416
 shards resident in HBM and trained side by side, one optimizer step of each per launch.
 A "step" of this bench = one epoch of the largest shard = `ticks_per_step` launches; the
 number of interactions processed in the timed ticks is counted exactly.
-N > 1: weak scaling -- every rank trains its own 5-shard job (shards are independent,
-sisa.py:33-36; there is no data-path collective), value = all ranks' interactions /
-max-over-ranks time.
+
+N > 1 -- one process per GPU over RCCL.  Started by the driver under torch.distributed.run
+(RANK / WORLD_SIZE in the environment) or, when WORLD_SIZE is unset, by this script itself:
+it starts N rank processes before anything touches the GPU and relays rank 0's JSON line.
+  * headline `value`: weak scaling -- every rank trains its own 5-shard ml-1m job (shards are
+    independent, sisa.py:33-36; no data-path collective), value = all ranks' interactions /
+    max-over-ranks time;
+  * `exchange`: the path's one collective (sisa.py:52-58), the all-gather of every shard's own
+    user rows + item table, timed over RCCL on the tables just trained;
+  * `north_star_splits`: ONE job's shards placed across the ranks by longest-processing-time-first
+    (strong scaling) for BASELINE.json configs[2] (8 shards, d = 64), configs[3] (25 M ratings,
+    32 shards, d = 128) and configs[4] (16-shard learn + unlearn through Sisa, wall time).
+  --split 1 runs a workload in that split mode as the headline instead.
 
 Prints ONE JSON line on rank 0 (driver contract) with `roofline` and `cpu_baseline`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -36,23 +49,67 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', choices=['ml1m', 'ml25m'], default='ml1m',
-                    help="ml1m: BASELINE configs[1] (default); ml25m: configs[3] shape (32 shards, d=128) on one GPU")
+                    help="ml1m: BASELINE configs[1] (default); ml25m: configs[3] shape (32 shards, d=128)")
     ap.add_argument('--shards', type=int, default=None)
     ap.add_argument('--d', type=int, default=None)
     ap.add_argument('--batch', type=int, default=30000)
+    ap.add_argument('--split', type=int, default=0,
+                    help='1: ONE job, its shards placed across the ranks (strong scaling); 0: every rank its own job (weak)')
+    ap.add_argument('--splits', default='auto',
+                    help="extra legs at N > 1: comma list of config2,config3,config4 ; 'auto' = all three ; 'none'")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-unlearn', action='store_true', help='skip the learn/unlearn wall-time leg')
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU baseline work')
     ap.add_argument('--roofline-steps', type=int, default=3)
+    ap.add_argument('--extras-timeout', type=float, default=420.0, help='N > 1: seconds allowed for the exchange / split legs')
     ap.add_argument('--backend', default='nccl', help='process-group backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     ap.add_argument('--force-device', type=int, default=None, help='rehearsal only: put every rank on this device')
+    ap.add_argument('--force-dist', action='store_true', help='rehearsal only: create the process group even for one rank, so that '
+                                                               'the RCCL calls of the N > 1 path run on a one-GPU box')
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves, BEFORE this process touches the GPU
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE: N children of this script, one per GPU, with the
+    torch.distributed environment of a single-node launch.  Children are fresh processes (never an
+    exec of a process that initialised HIP); rank 0 inherits stdout and prints the JSON line."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                              env=dict(base, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=None if r == 0 else subprocess.DEVNULL)
+             for r in range(n)]
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:          # one rank failed: the others would wait in a collective for ever
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def interactions_in_ticks(sizes, batch, t0, t1, epochs, dense_bytes=None):
-    """Exact number of interactions the ticks [t0, t1) process over all shards, and the
-    algorithmic bytes of every tick ((16 + 16 d) per interaction + 20 P per dense
-    optimizer step, P counted over the rows actually streamed)."""
+    """Exact number of interactions the ticks [t0, t1) process over the given shards, and the
+    algorithmic bytes of every tick ((16 + 16 d) per interaction + the dense optimizer
+    bytes of the rows actually streamed)."""
     total = 0
     per_tick = np.zeros(max(t1 - t0, 0), dtype=np.int64)
     dense = np.zeros(max(t1 - t0, 0), dtype=np.int64)
@@ -67,180 +124,365 @@ def interactions_in_ticks(sizes, batch, t0, t1, epochs, dense_bytes=None):
     return total, per_tick, dense
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
-    if a.force_device is not None:
-        local = a.force_device
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if a.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-        else:
-            dist.init_process_group(a.backend)
+class Dist:
+    """The process group (or its absence) behind three helpers."""
 
+    def __init__(self, a):
+        self.rank = int(os.environ.get('RANK', 0))
+        self.world = int(os.environ.get('WORLD_SIZE', 1))
+        self.local = int(os.environ.get('LOCAL_RANK', 0)) if a.force_device is None else a.force_device
+        torch.cuda.set_device(self.local)
+        self.pg = None
+        if self.world > 1 or a.force_dist:
+            import torch.distributed as dist
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29655')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
+            if a.backend == 'nccl':
+                dist.init_process_group('nccl', device_id=torch.device('cuda', self.local))
+            else:
+                dist.init_process_group(a.backend)
+            self.pg = dist
+
+    def barrier(self):
+        if self.pg is not None:
+            self.pg.barrier()
+
+    def max(self, x):
+        if self.pg is None:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device='cuda')
+        self.pg.all_reduce(t, op=self.pg.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, x):
+        if self.pg is None:
+            return int(x)
+        t = torch.tensor([x], dtype=torch.int64, device='cuda')
+        self.pg.all_reduce(t, op=self.pg.ReduceOp.SUM)
+        return int(t.item())
+
+
+def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_steps=0, keep_job=False):
+    """Make the workload resident, run W warm-up and K timed bench steps of the rank's shards, return the
+    measurements.  split: ONE job (same data on every rank), shards placed by assign_shards; otherwise
+    every rank generates and trains its own job."""
     from ultrare_amd import engine, rng, synth
-    from ultrare_amd import _native as nv
-
-    # ---- inputs: generated and made resident before anything is timed ----------
-    spec = synth.ML1M if a.workload == 'ml1m' else synth.ML25M
-    a.shards = a.shards or (5 if a.workload == 'ml1m' else 32)
-    a.d = a.d or (32 if a.workload == 'ml1m' else 128)
-    data = synth.make_dataset(**spec, seed=synth.SEED + rank)
-    shard_of, _ = synth.uniform_shards(spec['n_user'], a.shards)
-    parts = synth.split_shards(data['train'], shard_of, a.shards)
-    sizes = [len(p[0]) for p in parts]
-    steps_per_epoch = [(n + a.batch - 1) // a.batch for n in sizes]
-    tps = max(steps_per_epoch)                                     # ticks per bench step
-    n_bench_steps = a.warmup + a.steps + a.roofline_steps
+    from ultrare_amd.method.sisa import assign_shards
+    spec = synth.ML1M if workload == 'ml1m' else synth.ML25M
+    data = synth.make_dataset(**spec, seed=synth.SEED + (0 if split else D.rank))
+    shard_of, groups = synth.uniform_shards(spec['n_user'], n_shards)
+    parts = synth.split_shards(data['train'], shard_of, n_shards)
+    all_sizes = [len(p[0]) for p in parts]
+    owner = assign_shards(all_sizes, D.world) if split else [D.rank] * n_shards
+    mine = [s for s in range(n_shards) if owner[s] == D.rank]
+    sizes = [all_sizes[s] for s in mine]
+    steps_per_epoch = [(n + batch - 1) // batch for n in (all_sizes if split else sizes)]
+    tps = max(steps_per_epoch)                                     # ticks per bench step (job-wide)
+    n_bench_steps = warmup + steps + roofline_steps
     epochs = int(np.ceil(n_bench_steps * tps / min(steps_per_epoch))) + 1
-    torch.manual_seed(42 + rank)
-    inits, perms = [], []
     t_rng = time.perf_counter()
-    for p in parts:
-        inits.append(rng.mf_init(spec['n_user'], spec['n_item'], a.d))
-        perms.append(rng.epoch_perms(rng.epoch_seeds(epochs, True), len(p[0]), threads=min(8, os.cpu_count() or 1)))
+    inits, perms = [], []
+    if not split:
+        torch.manual_seed(42 + D.rank)
+    for s in mine:
+        if split:
+            torch.manual_seed(42 + 1000 * s)                       # own shards only: any fixed init serves a throughput leg
+        inits.append(rng.mf_init(spec['n_user'], spec['n_item'], d))
+        perms.append(rng.epoch_perms(rng.epoch_seeds(epochs, True), all_sizes[s], threads=min(8, os.cpu_count() or 1)))
     t_rng = time.perf_counter() - t_rng
-    shards = [engine.ShardData(*p, spec['n_user'], spec['n_item']) for p in parts]
-    job = engine.TrainJob(shards, inits, perms, a.d, a.batch, epochs, 1e-3, 0.1, 0.9, 0.95)
-    del perms
+    job, shards = None, []
+    if mine:
+        shards = [engine.ShardData(*parts[s], spec['n_user'], spec['n_item']) for s in mine]
+        job = engine.TrainJob(shards, inits, perms, d, batch, epochs, 1e-3, 0.1, 0.9, 0.95)
+    del perms, parts
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    # ---- warmup -----------------------------------------------------------------
-    job.run(a.warmup * tps)
+    if job is not None:
+        job.run(warmup * tps)
     torch.cuda.synchronize()
-    # ---- timed region: exactly K steps --------------------------------------------
-    t0_tick = job.done
-    barrier()
+    t0_tick = job.done if job is not None else 0
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides -------------------
+    D.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     w0 = time.perf_counter()
     ev0.record()
-    job.run(a.steps * tps)
+    if job is not None:
+        job.run(steps * tps)
     ev1.record()
     torch.cuda.synchronize()
     w1 = time.perf_counter()
-    barrier()
-    wall = w1 - w0
+    D.barrier()
+    my_wall = w1 - w0
     dev_ms = ev0.elapsed_time(ev1)
-    n_inter, _, _ = interactions_in_ticks(sizes, a.batch, t0_tick, job.done, epochs)
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-        c = torch.tensor([n_inter], dtype=torch.int64, device='cuda')
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        n_total = int(c.item())
-    else:
-        n_total = n_inter
+    t1_tick = job.done if job is not None else 0
+    n_inter, _, _ = interactions_in_ticks(sizes, batch, t0_tick, t1_tick, epochs)
+    wall = D.max(my_wall)
+    n_total = D.sum(n_inter)
+    out = {'spec': spec, 'data': data, 'groups': groups, 'mine': mine, 'owner': owner, 'sizes': sizes, 'all_sizes': all_sizes,
+           'tps': tps, 'epochs': epochs, 'wall': wall, 'my_wall': my_wall, 'dev_ms': dev_ms, 'n_total': n_total, 'n_inter': n_inter,
+           't_rng': t_rng, 't0_tick': t0_tick, 'n_launch': t1_tick - t0_tick, 'shards': shards, 'job': job,
+           'value': n_total / wall if wall > 0 else 0.0}
+    if not keep_job and job is not None:
+        job.close()
+        out['job'] = None
+        out['shards'] = None
+    return out
 
-    # ---- roofline: the timed region consists of step-kernel launches only (the next epoch's
-    # batch tags ride inside them), so the kernel's average duration is the HIP-event time of the
-    # region / launches, on the stream the launches went to.  A second pass with one event pair
-    # per launch (ure_job_train_profiled) is reported beside it.
-    dp = engine.pad_dim(a.d)
+
+def source_hash():
+    from ultrare_amd import build as lib_build
+    return lib_build.source_hash()
+
+
+def roofline_of(a, leg, d, batch):
+    """Algorithmic bytes per launch / the step kernel's average launch duration (HIP events on the
+    launch stream around the timed region: it holds step-kernel launches only -- the next epoch's batch
+    tags ride inside them), the per-launch-event pass beside it, and the HBM-side traffic of the matching
+    rocprofv3 PMC passes when their source hash equals this tree's."""
+    from ultrare_amd import engine
+    job, shards, spec = leg['job'], leg['shards'], leg['spec']
+    dp = engine.pad_dim(d)
     rows_streamed = [sh.n_active if job.lazy_rows else spec['n_user'] + spec['n_item'] for sh in shards]
-    _, per_tick, dense = interactions_in_ticks(sizes, a.batch, t0_tick, t0_tick + a.steps * tps, epochs,
-                                               dense_bytes=[20 * r * dp for r in rows_streamed])
-    n_launch = a.steps * tps
+    n_launch = leg['n_launch']
+    # SURVEY 8d counts 20 B per dense element (w, m, g read; w, m written); this kernel never materialises
+    # g, so it moves 16 B: both figures are reported, `achieved` uses the survey's
+    _, per_tick, dense20 = interactions_in_ticks(leg['sizes'], batch, leg['t0_tick'], leg['t0_tick'] + n_launch, leg['epochs'],
+                                                 dense_bytes=[20 * r * dp for r in rows_streamed])
     b_sparse = 16 + 16 * dp
-    alg_bytes = float((per_tick * b_sparse + dense).sum()) / n_launch                          # per launch
-    avg_ms = dev_ms / n_launch
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    step_ms, n_step, assign_ms, n_assign = job.run_profiled(a.roofline_steps * tps)
-    # HBM-side bytes per launch come from rocprofv3 PMC passes of this same command (they cannot
-    # be collected from inside the process); the committed summary is quoted with its source
-    traffic, traffic_src = None, None
+    alg20 = float((per_tick * b_sparse + dense20).sum()) / n_launch
+    alg16 = float((per_tick * b_sparse + dense20 * 16 // 20).sum()) / n_launch
+    avg_ms = leg['dev_ms'] / n_launch
+    step_ms, n_step, _, _ = job.run_profiled(a.roofline_steps * leg['tps'])
+    traffic, traffic_src, traffic_note = None, None, None
     import glob
     import re
-    pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', '*pmc_hbm_traffic.json')),
-                 key=lambda f: [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', os.path.relpath(f, ROOT))])   # v9 < v10
-    if pmc and a.workload == 'ml1m' and a.d == 32 and a.shards == 5 and a.batch == 30000:
+    tag = f'{a.workload}_s{len(leg["all_sizes"])}_d{d}_b{batch}'
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', f'*pmc_hbm_traffic*{tag}*.json')) +
+                   (glob.glob(os.path.join(ROOT, 'profiles', 'r*', '*pmc_hbm_traffic.json')) if tag == 'ml1m_s5_d32_b30000' else []),
+                   key=lambda f: [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', os.path.relpath(f, ROOT))])
+    here = source_hash()
+    for f in reversed(cands):
         try:
-            with open(pmc[-1]) as f:
-                k = [v for n, v in json.load(f)['kernels'].items() if 'mf_step_kernel' in n][0]
-            traffic, traffic_src = k['traffic_bytes_per_launch'], os.path.relpath(pmc[-1], ROOT)
+            with open(f) as fh:
+                j = json.load(fh)
+            if j.get('source_hash') != here:
+                traffic_note = f'{os.path.relpath(f, ROOT)} was taken at source hash {j.get("source_hash")}, tree is {here}: not quoted'
+                continue
+            k = [v for n, v in j['kernels'].items() if 'mf_step_kernel' in n][0]
+            traffic, traffic_src, traffic_note = k['traffic_bytes_per_launch'], os.path.relpath(f, ROOT), None
+            break
         except Exception:
-            pass
-    roofline = {'bound': 'hbm', 'kernel': 'mf_step_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
-                'alg_bytes_per_launch': round(alg_bytes), 'avg_launch_us': round(avg_ms * 1e3, 2),
-                'launches_timed': n_launch, 'per_launch_event_us': round(step_ms / max(n_step, 1) * 1e3, 2),
-                'dense_rows_streamed_per_shard': rows_streamed, 'lazy_rows': bool(job.lazy_rows)}
+            continue
+    achieved = alg20 / (avg_ms * 1e-3) / 1e9
+    fabric = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
+    return {'bound': 'hbm', 'kernel': 'mf_step_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+            'traffic': traffic, 'traffic_source': traffic_src, 'traffic_note': traffic_note,
+            'fabric_gbs': round(fabric, 1) if fabric else None, 'fabric_frac': round(fabric / HBM_PEAK_GBS, 4) if fabric else None,
+            'alg_bytes_per_launch': round(alg20), 'alg_bytes_per_launch_16B_dense': round(alg16),
+            'alg_gbs_16B_dense': round(alg16 / (avg_ms * 1e-3) / 1e9, 1),
+            'avg_launch_us': round(avg_ms * 1e3, 2), 'launches_timed': n_launch,
+            'per_launch_event_us': round(step_ms / max(n_step, 1) * 1e3, 2),
+            'dense_rows_streamed_per_shard': rows_streamed, 'lazy_rows': bool(job.lazy_rows), 'source_hash': here,
+            'note': 'frac = algorithmic bytes (SURVEY 8d) / time / 8 TB/s; fabric_frac = PMC bytes that crossed the L2 / time / 8 TB/s '
+                    '(ml-1m tables are cache resident, so fabric_frac is the HBM-side utilisation)'}
 
-    # ---- CPU baseline (rank 0, N = 1): the torch DataLoader port of the reference ---
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        from oracle import torch_port
-        workers = min(24, os.cpu_count() or 1)
-        torch.manual_seed(42)
-        _, seen, spent, _ = torch_port.train_shard(parts[0], spec['n_user'], spec['n_item'], a.d, a.batch, 50,
-                                                   workers=workers, budget_s=a.cpu_budget)
-        pre = torch_port.prebatched_rate(parts[0], spec['n_user'], spec['n_item'], a.d, a.batch, 2)
-        cpu = {'value': round(seen / spent, 1), 'unit': 'interactions/s', 'cores': workers, 'kind': 'port',
-               'sample': f'shard 0 ({sizes[0]} rows), {seen // sizes[0]} epoch(s) = {seen} interactions in {spent:.1f}s; '
-                         f'per-sample Dataset + DataLoader({workers} workers) + nn.Embedding + SGD, '
-                         f'{torch.get_num_threads()} torch threads, host has {os.cpu_count()} cpus',
-               'prebatched_value': round(pre, 1)}
 
-    # ---- second half of the metric (rank 0, N = 1): Sisa.learn, then Sisa.unlearn after a 2 %
-    # random user deletion, 50 epochs, through the operator surface, wall clock with the per-epoch
-    # evaluations, row merge and final test included (outside the timed region above)
-    unlearn = None
-    if rank == 0 and world == 1 and a.workload == 'ml1m' and not a.no_unlearn:
-        job.close()
-        import importlib.util
-        sp = importlib.util.spec_from_file_location('e2e_sisa', os.path.join(ROOT, 'tools', 'e2e_sisa.py'))
-        e2e = importlib.util.module_from_spec(sp)
-        sp.loader.exec_module(e2e)
-        r = e2e.measure(a.shards, a.d, 50, 1, 2.0, data=data)
-        unlearn = {'learn_wall_s': r['learn_s'], 'unlearn_wall_s': r['unlearn_s'], 'epochs': 50,
-                   'deleted_users': r['deleted_users'], 'retrained_shards': r['retrained_shards'],
-                   'unlearn_interactions': r['unlearn_interactions'],
-                   'includes': 'host RNG + layout, 50 epochs of all retrained shards side by side, per-epoch shard/total '
-                               'evaluations, row merge, final test; inputs as in-memory loaders',
-                   'final_test': {'learn': r['log0'], 'unlearn': r['unlearn_log0']}}
-        # BASELINE.json configs[4]: 16 shards (d = the reference's default k = 16), 2 % random deletion
-        r16 = e2e.measure(16, 16, 50, 1, 2.0, data=data)
-        unlearn['config4_16_shards_k16'] = {'learn_wall_s': r16['learn_s'], 'unlearn_wall_s': r16['unlearn_s'],
-                                            'retrained_shards': r16['retrained_shards'], 'deleted_users': r16['deleted_users']}
+def cpu_baseline_of(a, leg, d, batch):
+    """The torch DataLoader port of the reference (oracle/torch_port.py), timed on this host: a thread
+    sweep for the arithmetic, then the reference's structure (per-sample Dataset + DataLoader workers)
+    for a bounded number of epochs, and its end-to-end flavour with the two per-epoch tests."""
+    from oracle import torch_port
+    spec, data = leg['spec'], leg['data']
+    from ultrare_amd import synth
+    shard_of, _ = synth.uniform_shards(spec['n_user'], len(leg['all_sizes']))
+    part0 = synth.split_shards(data['train'], shard_of, len(leg['all_sizes']))[0]
+    test0 = synth.split_shards(data['test'], shard_of, len(leg['all_sizes']))[0]
+    ncpu = os.cpu_count() or 1
+    # ---- arithmetic only (pre-batched tensors): sweep the intra-op thread count, keep the best
+    sweep = {}
+    for t in [x for x in (1, 4, 8, 16, 32, 64) if x <= ncpu]:
+        torch.set_num_threads(t)
+        sweep[t] = round(torch_port.prebatched_rate(part0, spec['n_user'], spec['n_item'], d, batch, 1), 1)
+    best_t = max(sweep, key=sweep.get)
+    torch.set_num_threads(best_t)
+    workers = min(24, max(ncpu - best_t, 1))
+    budget = a.cpu_budget
+    torch.manual_seed(42)
+    _, seen, spent, _ = torch_port.train_shard(part0, spec['n_user'], spec['n_item'], d, batch, 50, workers=workers,
+                                               budget_s=budget * 0.6)
+    torch.manual_seed(42)
+    e2e_seen, e2e_spent = torch_port.train_shard_with_tests(part0, test0, spec['n_user'], spec['n_item'], d, batch, 50,
+                                                            workers=workers, budget_s=budget * 0.4)
+    n0 = len(part0[0])
+    return {'value': round(seen / spent, 1), 'unit': 'interactions/s', 'cores': min(ncpu, workers + best_t), 'kind': 'port',
+            'threads': best_t, 'workers': workers, 'host_cpus': ncpu,
+            'sample': f'shard 0 ({n0} rows), {seen // n0} epoch(s) = {seen} interactions in {spent:.1f}s; '
+                      f'per-sample Dataset + DataLoader({workers} worker processes) + nn.Embedding + SGD with {best_t} torch threads',
+            'prebatched_value': sweep[best_t], 'prebatched_thread_sweep': sweep,
+            'end_to_end_value': round(e2e_seen / e2e_spent, 1),
+            'end_to_end_sample': f'the same plus the per-epoch shard test and total test in Python (scratch.py:72-97), '
+                                 f'{e2e_seen // n0} epoch(s) in {e2e_spent:.1f}s'}
 
-    if rank == 0:
-        arch = ''
-        try:
-            import ctypes
-            buf = ctypes.create_string_buffer(64)
-            nv.lib().ure_device_info(local, None, None, buf, 64)
-            arch = buf.value.decode()
-        except Exception:
-            pass
-        out = {
-            'metric': 'training interactions/sec + unlearn retrain wall-time, ml-1m 5-shard SISA' if a.workload == 'ml1m' else f'training interactions/sec, synthetic ml-25m-scale {a.shards}-shard SISA',
-            'value': round(n_total / wall, 1), 'unit': 'interactions/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': round(wall * 1e3 / a.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{a.workload}-shaped synthetic {spec["n_user"]}x{spec["n_item"]}, {spec["n_train"]} train rows, '
-                                   f'{a.shards}-shard SISA (uniform grouping), d={a.d}, batch={a.batch}, SGD-momentum-L2, '
-                                   f'all shards of a rank side by side',
-                       'shards_per_gpu': a.shards, 'shard_rows': sizes, 'ticks_per_step': tps, 'parallelism': f'shards x{world}',
-                       'arch': arch},
-            'device_ms_timed': round(dev_ms, 3), 'interactions_timed': n_total,
-            'host_rng_prep_s': round(t_rng, 3),
-            'roofline': roofline, 'cpu_baseline': cpu, 'unlearn': unlearn,
-        }
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+
+def unlearn_leg(a, data, shards, d):
+    """Second half of the metric: Sisa.learn, then Sisa.unlearn after a 2 % random user deletion, 50
+    epochs, through the operator surface; wall clock with per-epoch evaluations, row merge, final test."""
+    import importlib.util
+    sp = importlib.util.spec_from_file_location('e2e_sisa', os.path.join(ROOT, 'tools', 'e2e_sisa.py'))
+    e2e = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(e2e)
+    r = e2e.measure(shards, d, 50, 1, 2.0, data=data)
+    out = {'learn_wall_s': r['learn_s'], 'unlearn_wall_s': r['unlearn_s'], 'epochs': 50,
+           'deleted_users': r['deleted_users'], 'retrained_shards': r['retrained_shards'],
+           'unlearn_interactions': r['unlearn_interactions'],
+           'includes': 'host RNG + layout, 50 epochs of all retrained shards side by side, per-epoch shard/total '
+                       'evaluations, row merge, final test; inputs as in-memory loaders',
+           'final_test': {'learn': r['log0'], 'unlearn': r['unlearn_log0']}}
+    return out, e2e
+
+
+def exchange_leg(D, leg, d, reps=5):
+    """The path's one collective on the tables just trained: a global job of 5 x world shards, shard j
+    owned by rank j // 5; every rank contributes its shards' own user rows + item tables."""
+    from ultrare_amd.method.sisa import exchange_tables
+    job, spec = leg['job'], leg['spec']
+    S = len(leg['mine'])
+    ids = list(range(S * D.world))
+    owner = [j // S for j in ids]
+    dev = torch.device('cuda', torch.cuda.current_device())
+    rows = {j: torch.as_tensor(np.asarray(leg['groups'][j % S], dtype=np.int64)).to(dev) for j in ids}
+    models = {D.rank * S + s: tuple(t.contiguous() for t in job.tables(s)) for s in range(S)}
+    times = []
+    for _ in range(reps + 1):
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = exchange_tables(models, ids, owner, D.rank, rows, spec['n_item'], d, dev, D.pg)
+        torch.cuda.synchronize()
+        times.append(D.max(time.perf_counter() - t0))
+    peer = (D.rank + 1) % D.world
+    ok = bool(torch.isfinite(got[peer * S][1]).all().item()) and got[peer * S][0].shape == (len(leg['groups'][0]), d)
+    seg = sum((len(leg['groups'][s]) + spec['n_item']) * d * 4 for s in range(S))
+    return {'collective': 'all_gather_into_tensor (padded all-gather-v of own user rows + item tables)', 'backend': D.pg.get_backend(),
+            'ms': round(float(np.median(times[1:])) * 1e3, 3), 'first_call_ms': round(times[0] * 1e3, 3),
+            'bytes_per_rank': seg, 'bytes_gathered': seg * D.world, 'shards': len(ids), 'received_ok': ok}
+
+
+def split_legs(a, D, which):
+    """BASELINE.json configs[2..4] as ONE job spread over the ranks."""
+    out = {}
+    short = dict(steps=min(a.steps, 5), warmup=1)
+    if 'config2' in which:
+        leg = train_leg(D, 'ml1m', 8, 64, a.batch, a.steps, a.warmup, split=True)
+        out['config2'] = {'workload': 'ml-1m 8-shard SISA, d=64, shards placed over the ranks', 'value': round(leg['value'], 1),
+                          'unit': 'interactions/s', 'scaling': 'strong', 'ms_per_step': round(leg['wall'] * 1e3 / a.steps, 4),
+                          'shards_per_rank': [leg['owner'].count(r) for r in range(D.world)]}
+    if 'config4' in which:
+        from ultrare_amd import synth
+        data = synth.make_dataset(**synth.ML1M)
+        r, _ = unlearn_leg(a, data, 16, 16)
+        out['config4'] = {'workload': 'ml-1m 16-shard learn + unlearn (2 % random deletion), k=16, 50 epochs, through Sisa(parallel) '
+                                      'across the ranks: RNG replay, isolated training, one all-gather, merge, final test',
+                          'learn_wall_s': D.max(r['learn_wall_s']), 'unlearn_wall_s': D.max(r['unlearn_wall_s']),
+                          'retrained_shards': r['retrained_shards'], 'deleted_users': r['deleted_users']}
+    if 'config3' in which:
+        leg = train_leg(D, 'ml25m', 32, 128, a.batch, short['steps'], short['warmup'], split=True)
+        out['config3'] = {'workload': 'synthetic 162k x 60k x 22.5M train rows, 32-shard SISA, d=128, shards placed over the ranks',
+                          'value': round(leg['value'], 1), 'unit': 'interactions/s', 'scaling': 'strong', 'steps': short['steps'],
+                          'ms_per_step': round(leg['wall'] * 1e3 / short['steps'], 4),
+                          'ms_per_launch': round(leg['wall'] * 1e3 / max(short['steps'] * leg['tps'], 1), 4),
+                          'shards_per_rank': [leg['owner'].count(r) for r in range(D.world)]}
+    return out
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    D = Dist(a)
+    rank, world = D.rank, D.world
+    from ultrare_amd import _native as nv
+
+    a.shards = a.shards or (5 if a.workload == 'ml1m' else 32)
+    a.d = a.d or (32 if a.workload == 'ml1m' else 128)
+    split = bool(a.split) and D.pg is not None
+    leg = train_leg(D, a.workload, a.shards, a.d, a.batch, a.steps, a.warmup, split, a.roofline_steps, keep_job=True)
+    spec, job = leg['spec'], leg['job']
+
+    roofline = roofline_of(a, leg, a.d, a.batch) if job is not None and (rank == 0) else None
+    if job is not None and rank != 0:
+        job.run_profiled(a.roofline_steps * leg['tps'])          # every rank does the same work outside the timed region
+
+    arch = ''
+    try:
+        import ctypes
+        buf = ctypes.create_string_buffer(64)
+        nv.lib().ure_device_info(D.local, None, None, buf, 64)
+        arch = buf.value.decode()
+    except Exception:
+        pass
+    mode = (f'ONE job, shards placed over {world} ranks (LPT)' if split else
+            'all shards of a rank side by side' + (f'; every rank its own job (x{world})' if world > 1 else ''))
+    out = {
+        'metric': 'training interactions/sec + unlearn retrain wall-time, ml-1m 5-shard SISA' if a.workload == 'ml1m' else f'training interactions/sec, synthetic ml-25m-scale {a.shards}-shard SISA',
+        'value': round(leg['value'], 1), 'unit': 'interactions/s',
+        'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+        'ms_per_step': round(leg['wall'] * 1e3 / a.steps, 4), 'higher_is_better': True, 'scaling': 'strong' if split else 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{a.workload}-shaped synthetic {spec["n_user"]}x{spec["n_item"]}, {spec["n_train"]} train rows, '
+                               f'{a.shards}-shard SISA (uniform grouping), d={a.d}, batch={a.batch}, SGD-momentum-L2, {mode}',
+                   'shards_per_gpu': len(leg['mine']), 'shard_rows': leg['sizes'], 'ticks_per_step': leg['tps'],
+                   'parallelism': f'shards x{world}', 'backend': a.backend if world > 1 else None, 'arch': arch},
+        'device_ms_timed': round(leg['dev_ms'], 3), 'interactions_timed': leg['n_total'],
+        'host_rng_prep_s': round(leg['t_rng'], 3),
+        'roofline': roofline, 'cpu_baseline': None, 'unlearn': None,
+    }
+    printed = threading.Lock()
+
+    def emit():
+        if rank == 0 and printed.acquire(blocking=False):
+            print(json.dumps(out), flush=True)
+
+    if D.pg is not None:
+        # ---- N > 1 extras: the exchange over RCCL and the north-star splits.  A watchdog prints the
+        # line with what is there and ends the process if a collective never returns.
+        def expire():
+            out.setdefault('north_star_splits', {})['status'] = f'timeout after {a.extras_timeout:.0f}s'
+            emit()
+            os._exit(0 if rank == 0 else 3)
+        dog = threading.Timer(a.extras_timeout, expire)
+        dog.daemon = True
+        dog.start()
+        if not split and job is not None:
+            out['exchange'] = exchange_leg(D, leg, a.d)
+        job and job.close()
+        leg['job'] = leg['shards'] = job = None
+        torch.cuda.empty_cache()
+        which = [] if a.splits == 'none' else (['config2', 'config4', 'config3'] if a.splits == 'auto' else a.splits.split(','))
+        if which:
+            out['north_star_splits'] = split_legs(a, D, which)
+        dog.cancel()
+    else:
+        # ---- N = 1 extras (rank 0 is the only rank): CPU baseline and the unlearn half of the metric
+        if not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline_of(a, leg, a.d, a.batch)
+        if a.workload == 'ml1m' and not a.no_unlearn:
+            job.close()
+            leg['job'] = leg['shards'] = job = None
+            un, e2e = unlearn_leg(a, leg['data'], a.shards, a.d)
+            # BASELINE.json configs[4]: 16 shards (d = the reference's default k = 16), 2 % random deletion
+            r16 = e2e.measure(16, 16, 50, 1, 2.0, data=leg['data'])
+            un['config4_16_shards_k16'] = {'learn_wall_s': r16['learn_s'], 'unlearn_wall_s': r16['unlearn_s'],
+                                           'retrained_shards': r16['retrained_shards'], 'deleted_users': r16['deleted_users']}
+            out['unlearn'] = un
+    emit()
+    if D.pg is not None:
+        D.pg.destroy_process_group()
 
 
 if __name__ == '__main__':

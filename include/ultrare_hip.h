@@ -28,11 +28,15 @@
 extern "C" {
 #endif
 
-#define URE_ABI_VERSION 2
+#define URE_ABI_VERSION 3
 #define URE_MAX_MODELS_PER_CALL 32
 #define URE_SCORE_PARTIALS 2048       /* length of ure_score's sse buffer */
 
 int ure_abi_version(void);
+/* Hash of the sources (ultrare_amd/csrc, this header, compiler flags) the library was built from, as
+ * computed by ultrare_amd/build.py; the host rebuilds a library whose hash is not the tree's, and
+ * profiles/ records it so that a counter file is never quoted against other code. */
+const char *ure_source_hash(void);
 const char *ure_last_error(void);
 /* Number of compute units, wavefront size and gcnArchName of device `dev`. */
 int ure_device_info(int dev, int *n_cu, int *wave_size, char *arch, int arch_len);
@@ -153,12 +157,13 @@ int ure_host_randperm(const int64_t *seeds, int n_perms, int64_t n, int32_t *out
 int ure_host_read_csv(const char *path, int32_t **uid, int32_t **iid, double **rating, int64_t *n_rows, int n_threads);
 void ure_host_free(void *p);
 /* read.py:52-70: shard s receives, in file order, the rows whose user u has
- * shard_of_user[u] == s (-1: deleted user, dropped); rating / max_rating as float32.
+ * shard_of_user[u] == s (-1: deleted user, dropped); rating / max_rating as float32 (out_rating)
+ * and / or as the float64 quotient readRating returns (out_rating64); either may be NULL.
  * counts [n_shards] is always filled; with out_uid == NULL nothing else is written (size query),
  * otherwise the shards are written back to back (shard s starts at sum(counts[:s])). */
 int ure_host_partition(const int32_t *uid, const int32_t *iid, const double *rating, int64_t n, const int32_t *shard_of_user,
                        int32_t n_user, int32_t n_shards, double max_rating, int64_t *counts, int32_t *out_uid,
-                       int32_t *out_iid, float *out_rating);
+                       int32_t *out_iid, float *out_rating, double *out_rating64);
 /* Builds the slot layout of struct ure_shard from a shard's triples: ent_oid / ent_r / ent_src
  * (capacity 2 n + 8 (n_user + n_item) slots, *n_slots receives the used count), sched
  * [n_user + n_item][4], the number of active rows, and optionally u_pos / i_pos [n] (slot of each

@@ -353,6 +353,55 @@ def emd_exact(M):
     return res.x.reshape(n, k)
 
 
+def ot_fixed_point(dist_kn):
+    """fp32 costs [k, n] -> int64 on a common power-of-two scale (exact: every float32 is m * 2^e)."""
+    d = np.ascontiguousarray(dist_kn, dtype=np.float32).astype(np.float64)
+    nz = d[d > 0]
+    if nz.size == 0:
+        return np.zeros(d.shape, dtype=np.int64)
+    _, e = np.frexp(nz)
+    shift = 24 - int(e.min())
+    assert int(e.max()) + shift < 56, 'dynamic range of the costs too wide for an exact int64 certificate'
+    return np.ldexp(d, shift).astype(np.int64)
+
+
+def ot_certificate(dist_kn, plan_nk):
+    """Proof that an integer plan (units of 1/(n k): every point ships k units, every cluster takes n)
+    is an exact optimum of the transportation LP of utils.py:640-644: it is feasible and the residual
+    graph has no negative cycle.  All arithmetic is integer (fixed-point costs), so the verdict has no
+    tolerance.  A cycle through points reduces to a cycle over clusters whose edge a -> b costs
+    min over points i holding units in a of cost[i, b] - cost[i, a].
+    -> dict(feasible, optimal, objective (units), tight_cycles: a zero-cost cycle exists = the optimum
+    is not unique)."""
+    c = ot_fixed_point(dist_kn).T.copy()                  # [n, k]
+    x = np.ascontiguousarray(plan_nk, dtype=np.int64)
+    n, k = x.shape
+    feasible = bool((x >= 0).all() and (x.sum(axis=1) == k).all() and (x.sum(axis=0) == n).all())
+    INF = np.iinfo(np.int64).max // 4
+    w = np.full((k, k), INF, dtype=np.int64)
+    for a in range(k):
+        rows = np.flatnonzero(x[:, a] > 0)
+        if len(rows):
+            w[a] = (c[rows] - c[rows, a:a + 1]).min(axis=0)
+        w[a, a] = INF
+    # Floyd-Warshall on Python ints (k <= a few dozen)
+    D = [[int(v) if v < INF else None for v in row] for row in w]
+    for m in range(k):
+        for a in range(k):
+            if D[a][m] is None:
+                continue
+            for b in range(k):
+                if D[m][b] is None:
+                    continue
+                t = D[a][m] + D[m][b]
+                if D[a][b] is None or t < D[a][b]:
+                    D[a][b] = t
+    diag = [D[a][a] for a in range(k) if D[a][a] is not None]
+    optimal = feasible and all(v >= 0 for v in diag)
+    return {'feasible': feasible, 'optimal': bool(optimal), 'objective': int((x * c).sum()),
+            'tight_cycles': any(v == 0 for v in diag)}
+
+
 def ot_cluster(X, k, max_iters=10, trace=None):
     """utils.py:628-656 with the global numpy RNG for the initial centroids."""
     X = np.ascontiguousarray(X, dtype=np.float32)

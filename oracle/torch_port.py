@@ -100,3 +100,77 @@ def prebatched_rate(data, n_user, n_item, k, batch, epochs=1, lr=1e-3, lam=0.1, 
             opt.step()
     dt = time.perf_counter() - t0
     return n * epochs / dt
+
+
+def _dcg(r):
+    return r[0] + np.sum(r[1:] / np.log2(np.arange(2, len(r) + 1)))
+
+
+def base_test(loader, models, top_k=10):
+    """utils.py:115-187 in the reference's structure: sequential DataLoader, mean of the models'
+    scores, per batch a Python loop over the batch's users with boolean masks and a `uid in list`
+    membership test, then per user two argsorts, HR@10 and the reference's NDCG@10."""
+    loss_fn = nn.MSELoss(reduction='sum')
+    size = len(loader.dataset)
+    test_loss, ndcg, hr = 0, [], []
+    with torch.no_grad():
+        all_user, rating_dict = [], {}
+        for user, item, rating in loader:
+            uni_user = user.unique().tolist()
+            batch_user = user.numpy().astype(np.int32)
+            batch_rating = rating.numpy().astype(np.float32)
+            pred = torch.stack([m(user, item) for m in models]).mean(dim=0)
+            test_loss += loss_fn(pred, rating).item()
+            batch_pred = pred.numpy().astype(np.float32).reshape(-1)
+            for uid in uni_user:
+                cur_rating = batch_rating[batch_user == uid].tolist()
+                cur_pred = batch_pred[batch_user == uid].tolist()
+                if uid in all_user:
+                    rating_dict[uid]['rating'] += cur_rating
+                    rating_dict[uid]['pred'] += cur_pred
+                else:
+                    all_user.append(uid)
+                    rating_dict[uid] = {'rating': cur_rating, 'pred': cur_pred}
+        test_loss = np.sqrt(test_loss / size)
+        for uid in all_user:
+            uid_rating = np.array(rating_dict[uid]['rating'])
+            uid_pred = np.array(rating_dict[uid]['pred'])
+            top_rating = np.argsort(uid_rating, kind='stable')[::-1][:top_k]
+            top_pred = np.argsort(uid_pred, kind='stable')[::-1][:top_k]
+            relevance = uid_rating[top_pred]
+            hr.append(sum(relevance >= (4 / 5)) / top_k)
+            common = np.isin(top_rating, top_pred)
+            relevance = relevance * (relevance >= (4 / 5)) * common
+            r = np.concatenate([relevance, np.zeros(top_k - len(relevance))])
+            ndcg.append(_dcg(r) / _dcg(np.ones(top_k)) if len(relevance) else 0)
+    return test_loss, float(np.mean(ndcg)), float(np.mean(hr))
+
+
+def train_shard_with_tests(data, test, n_user, n_item, k, batch, epochs, lr=1e-3, lam=0.1, momentum=0.9, workers=0,
+                           budget_s=None):
+    """The end-to-end flavour (scratch.py:72-97): every epoch = the training pass + the shard test +
+    the total test (here the same test set twice, as for a one-shard job).  Returns (training
+    interactions processed, seconds) -- the figure the >= 50x target of BASELINE.json is stated on."""
+    loader = DataLoader(_Triples(*data), batch_size=batch, shuffle=True, num_workers=workers)
+    tloader = DataLoader(_Triples(*test), batch_size=batch, shuffle=False, num_workers=workers)
+    model = _Model(n_user, n_item, k)
+    opt = torch.optim.SGD(model.parameters(), lr=lr, weight_decay=lam, momentum=momentum)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=50, gamma=0.95)
+    loss_fn = nn.MSELoss(reduction='sum')
+    seen, spent = 0, 0.0
+    for _ in range(epochs):
+        t0 = time.perf_counter()
+        for u, i, r in loader:
+            loss = loss_fn(model(u, i), r)
+            loss.item()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            seen += len(u)
+        sched.step()
+        base_test(tloader, [model])
+        base_test(tloader, [model])
+        spent += time.perf_counter() - t0
+        if budget_s is not None and spent >= budget_s:
+            break
+    return seen, spent

@@ -16,7 +16,7 @@ Harness conventions:
     default kind is host-specific, SURVEY section 7 "NDCG tie-breaking"); the as-is
     value is stored beside it as information.
 
-usage: python tests/golden/make_golden.py [full] [sisa] [eval] [ot] [ml1m] [kmeans]
+usage: python tests/golden/make_golden.py [full] [sisa] [eval] [ot] [ml1m] [kmeans] [steplr] [sort] [ot_ml1m] [preprocess]
 """
 import contextlib
 import io
@@ -515,8 +515,234 @@ def gen_ml1m():
     np.savez_compressed(os.path.join(HERE, 'ml1m_synth.npz'), **out)
 
 
+# --------------------------------------------------------------------------
+def gen_steplr():
+    """StepLR boundary (scratch.py:69,79-80): the learning rate changes after the 50th scheduler.step(),
+    so epochs 51 and 52 of a 52-epoch run train with lr * 0.95.  Toy set, full MF."""
+    tr_arr, te_arr = read_full()
+    E = 52
+    p = Param(E)
+    tr, te = loaders(tr_arr, te_arr, p.batch)
+    sc = RS.Scratch(p, 'mf')
+    lrs = []
+    _step = torch.optim.lr_scheduler.StepLR.step
+
+    def spy_step(self, *a, **kw):
+        r = _step(self, *a, **kw)
+        lrs.append(float(self.get_last_lr()[0]))
+        return r
+    torch.optim.lr_scheduler.StepLR.step = spy_step
+    t0 = time.time()
+    torch.manual_seed(p.seed)
+    try:
+        with quiet(), stable_sort():
+            model = sc.train(tr, te, [], 0, '')
+    finally:
+        torch.optim.lr_scheduler.StepLR.step = _step
+    out = {'E': E, 'U': model.user_mat.weight.detach().numpy().copy(), 'V': model.item_mat.weight.detach().numpy().copy(),
+           'lr_after_step': np.array(lrs[-E:], dtype=np.float64), 'ref_seconds': time.time() - t0}
+    for key in ('train_loss', 'test_rmse', 'test_ndcg', 'test_hr'):
+        out[key] = np.array(sc.log[key], dtype=np.float64)
+    print(f'steplr E={E}: {out["ref_seconds"]:.1f}s lr tail={lrs[-4:]} loss tail={out["train_loss"][-3:]}', flush=True)
+    np.savez_compressed(os.path.join(HERE, 'steplr_toy.npz'), **out)
+
+
+# --------------------------------------------------------------------------
+def gen_sort():
+    """readRating(..., sort='a') (read.py:40-50, 73-106), the only call the CLI path makes
+    (config.py:80-88).  The reference needs 'ml1m' inside the path (D11), so the toy CSVs are
+    linked into a scratch directory of that name.  Uneven groups (the OT k=5 / k=7 labels of the toy
+    embedding and a hand-made skewed split) make the ordering non-trivial; one case deletes users."""
+    import shutil
+    tmp = tempfile.mkdtemp()
+    d = os.path.join(tmp, 'ml1m')
+    os.makedirs(d)
+    tr_path, te_path = os.path.join(d, 'squ0_train.csv'), os.path.join(d, 'squ0_test.csv')
+    shutil.copy(TOY_TRAIN, tr_path)
+    shutil.copy(TOY_TEST, te_path)
+    ot = np.load(os.path.join(HERE, 'ot_toy.npz'))
+    rs = np.random.RandomState(11)
+    skew = rs.permutation(N_USER)
+    cuts = [0, 700, 760, 1100, 1150, N_USER]
+    cases = {
+        'ot5': [np.flatnonzero(ot['k5_label'] == c).tolist() for c in range(5)],
+        'ot7': [np.flatnonzero(ot['k7_label'] == c).tolist() for c in range(7)],
+        'skew5': [sorted(skew[cuts[i]:cuts[i + 1]].tolist()) for i in range(5)],
+    }
+    np.random.seed(0)
+    del_user = np.random.choice(N_USER, int(2 / 100 * N_USER), replace=False)
+    out = {'del_user': del_user.astype(np.int64)}
+    for name, groups in cases.items():
+        for tag, dels in (('', []), ('_del', del_user.tolist())):
+            with quiet():
+                tr_l, idx = RR.readRating(tr_path, N_USER, 5, dels, [], len(groups), [list(g) for g in groups], 'a')
+                te_l, idx_te = RR.readRating(te_path, N_USER, 5, [], [], len(groups), idx)
+            order = [next(j for j, g in enumerate(groups) if list(g) == list(i)) for i in idx]
+            key = name + tag
+            out[key + '_n_group'] = len(groups)
+            for j, g in enumerate(groups):
+                out[f'{key}_in{j}'] = np.array(g, dtype=np.int64)
+            out[key + '_order'] = np.array(order, dtype=np.int64)
+            out[key + '_ntrain'] = np.array([a.shape[1] for a in tr_l], dtype=np.int64)
+            out[key + '_ntest'] = np.array([a.shape[1] for a in te_l], dtype=np.int64)
+            # checksums of every returned shard array: (uid, iid, rating) in file order
+            out[key + '_train_check'] = np.array([[a[0].sum(), a[1].sum(), a[2].sum(), (a[0] * np.arange(1, a.shape[1] + 1)).sum()] for a in tr_l], dtype=np.float64)
+            out[key + '_test_check'] = np.array([[a[0].sum(), a[1].sum(), a[2].sum(), (a[0] * np.arange(1, a.shape[1] + 1)).sum()] for a in te_l], dtype=np.float64)
+            print(f'sort {key}: order={order} ntrain={out[key + "_ntrain"].tolist()}', flush=True)
+    shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(HERE, 'sort_toy.npz'), **out)
+
+
+# --------------------------------------------------------------------------
+def ot_embedding(n, d, seed):
+    """Seeded stand-in for a trained user matrix at ml-1m size: a mixture of 12 Gaussians in d
+    dimensions (float32).  The generator is numpy's legacy RandomState, stable across versions;
+    tests rebuild X from the seed and check the stored checksum."""
+    rs = np.random.RandomState(seed)
+    centers = rs.standard_normal((12, d)) * 0.8
+    which = rs.randint(0, 12, n)
+    X = centers[which] + rs.standard_normal((n, d)) * 0.6
+    return X.astype(np.float32)
+
+
+def gen_ot_ml1m():
+    """ot_cluster (utils.py:628-656) at BASELINE sizes: n = 6040 users, d = 32, k = 5, 8 (k | n) and
+    16 (6040 / 16 = 377.5: every cluster takes half a point, so split points are exact 8/8 ties in
+    units of 1/(n k); a float LP solver resolves those by rounding noise).  Every round's centroids,
+    labels and split points are stored so that a round can be checked on its own."""
+    n, d, seed = 6040, 32, 20240607
+    X = ot_embedding(n, d, seed)
+    out = {'n': n, 'd': d, 'seed': seed, 'X_sum': np.float64(X.astype(np.float64).sum()),
+           'X_abs': np.float64(np.abs(X.astype(np.float64)).sum()), 'X_head': X[:4].copy()}
+    for k in (5, 8, 16):
+        np.random.seed(0)
+        np.random.choice(n, int(2 / 100 * n), replace=False)          # the CLI path's earlier draw (config.py:47-49)
+        probe = np.random.get_state()
+        cent_idx = np.random.choice(n, size=k, replace=False)
+        np.random.set_state(probe)
+        del EMD_CALLS[:]
+        cents = []
+        _mean = np.ndarray.mean
+        t0 = time.time()
+        with quiet():
+            inertia, label = RU.ot_cluster.__wrapped__(X, k)
+        dt = time.time() - t0
+        tag = f'k{k}'
+        rounds = len(EMD_CALLS)
+        out[tag + '_cent_idx'] = cent_idx.astype(np.int64)
+        out[tag + '_label'] = label.astype(np.int64)
+        out[tag + '_inertia'] = np.float64(inertia)
+        out[tag + '_rounds'] = rounds
+        labels = np.array([np.argmax(c['G'], axis=1) for c in EMD_CALLS], dtype=np.int64)
+        out[tag + '_round_labels'] = labels.astype(np.int8)
+        out[tag + '_round_dist_sum'] = np.array([c['M'].sum() for c in EMD_CALLS], dtype=np.float64)
+        out[tag + '_round_cost'] = np.array([(c['M'] * c['G']).sum() for c in EMD_CALLS], dtype=np.float64)
+        # centroids that produced each round's cost matrix: round 0 from cent_idx, round r from labels r-1
+        cs = [X[cent_idx]]
+        for r in range(rounds - 1):
+            cs.append(np.array([X[labels[r] == i].mean(axis=0) for i in range(k)]))
+        out[tag + '_round_centroids'] = np.array(cs, dtype=np.float32)
+        # split points: rows of the plan whose largest share is not the whole mass
+        splits = []
+        for r, c in enumerate(EMD_CALLS):
+            G = c['G'] * n
+            top = np.sort(G, axis=1)[:, ::-1]
+            for i in np.flatnonzero(top[:, 0] < 1 - 1e-9):
+                two = np.argsort(-G[i], kind='stable')[:2]
+                splits.append((r, int(i), int(two[0]), int(two[1]), float(G[i, two[0]]), float(G[i, two[1]])))
+        out[tag + '_splits'] = np.array(splits, dtype=np.float64).reshape(-1, 6)
+        print(f'ot ml1m k={k}: rounds={rounds} inertia={inertia:.4f} counts={np.bincount(label)} '
+              f'splits/round={len(splits) / rounds:.1f} {dt:.1f}s', flush=True)
+    np.savez_compressed(os.path.join(HERE, 'ot_ml1m.npz'), **out)
+
+
+# --------------------------------------------------------------------------
+def gen_preprocess():
+    """data/ml1m/pro.ipynb cells 0-10 (5-core filter, id squeeze, per-user random 90/10 split) run as
+    written on a small ratings.dat made here.  The notebook's code is read from the reference at
+    generation time and executed in a scratch directory; only its input file and the two CSVs it writes
+    are stored.  Harness shims: DataFrame.append (removed in pandas 2) is mapped to pd.concat, tqdm is
+    silenced, and `random.seed(5)` is called before cell 10 (the notebook never seeds `random`)."""
+    import json
+    import random
+    import pandas as pd
+    rs = np.random.RandomState(3)
+    n_u, n_i = 140, 90
+    rows = []
+    for u in range(1, n_u + 1):
+        cnt = int(rs.choice([2, 3, 6, 9, 14, 25, 40], p=[.06, .06, .2, .25, .2, .15, .08]))
+        items = rs.choice(np.arange(1, n_i + 1), size=min(cnt, n_i), replace=False, p=None)
+        for it in items:
+            rows.append((u, int(it) * 3 + 1, int(rs.randint(1, 6)), 978300000 + int(rs.randint(0, 10 ** 6))))
+    # a few items nobody else rates (dropped by the item filter, which can push users under the bar)
+    for q in range(12):
+        rows.append((int(rs.randint(1, n_u + 1)), 1000 + q, int(rs.randint(1, 6)), 978300000))
+    tmp = tempfile.mkdtemp()
+    dat = os.path.join(tmp, 'ratings.dat')
+    with open(dat, 'w') as f:
+        for r in rows:
+            f.write('::'.join(str(x) for x in r) + '\n')
+    nb = json.load(open(os.path.join(REF, 'data', 'ml1m', 'pro.ipynb')))
+    cells = [''.join(c['source']) for c in nb['cells'] if c['cell_type'] == 'code']
+    had_append = hasattr(pd.DataFrame, 'append')
+    if not had_append:
+        pd.DataFrame.append = lambda self, other, ignore_index=False: pd.concat([self, other], ignore_index=ignore_index)
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    env = {}
+    try:
+        with quiet(), contextlib.redirect_stderr(io.StringIO()):
+            for idx in (0, 1, 3, 4, 7):
+                exec(compile(cells[idx], f'pro.ipynb[{idx}]', 'exec'), env)
+            random.seed(5)
+            exec(compile(cells[9], 'pro.ipynb[10]', 'exec'), env)       # code cell #9 = notebook cell 10
+    finally:
+        os.chdir(cwd)
+        if not had_append:
+            del pd.DataFrame.append
+    tr = np.loadtxt(os.path.join(tmp, 'squ0_train.csv'), delimiter=',')
+    te = np.loadtxt(os.path.join(tmp, 'squ0_test.csv'), delimiter=',')
+    out = {'ratings_dat': np.array(rows, dtype=np.int64), 'train': tr, 'test': te, 'split_seed': 5,
+           'user_dict': np.array(sorted(np.load(os.path.join(tmp, 'user_dict.npy'), allow_pickle=True).item().items()), dtype=np.int64),
+           'item_dict': np.array(sorted(np.load(os.path.join(tmp, 'item_dict.npy'), allow_pickle=True).item().items()), dtype=np.int64)}
+    print(f'preprocess: {len(rows)} rows in, train {tr.shape}, test {te.shape}, users {len(out["user_dict"])}, items {len(out["item_dict"])}', flush=True)
+    np.savez_compressed(os.path.join(HERE, 'preprocess_small.npz'), **out)
+
+
+def gen_ot_25m():
+    """ONE round of ot_cluster (max_iters=1) at configs[3] size: n = 162,000 users, d = 128, k = 32
+    (162000 / 32 = 5062.5: half-point splits as at k = 16).  The LP has 5.2 M variables; HiGHS needs
+    minutes for it.  Stored: labels, split points, the objective; X is rebuilt from the seed."""
+    n, d, k, seed = 162000, 128, 32, 20240608
+    X = ot_embedding(n, d, seed)
+    np.random.seed(0)
+    np.random.choice(n, int(2 / 100 * n), replace=False)
+    probe = np.random.get_state()
+    cent_idx = np.random.choice(n, size=k, replace=False)
+    np.random.set_state(probe)
+    del EMD_CALLS[:]
+    t0 = time.time()
+    with quiet():
+        inertia, label = RU.ot_cluster.__wrapped__(X, k, 1)
+    dt = time.time() - t0
+    c = EMD_CALLS[0]
+    G = c['G'] * n
+    top = np.sort(G, axis=1)[:, ::-1]
+    splits = []
+    for i in np.flatnonzero(top[:, 0] < 1 - 1e-9):
+        two = np.argsort(-G[i], kind='stable')[:2]
+        splits.append((0, int(i), int(two[0]), int(two[1]), float(G[i, two[0]]), float(G[i, two[1]])))
+    out = {'n': n, 'd': d, 'k': k, 'seed': seed, 'X_sum': np.float64(X.astype(np.float64).sum()), 'X_head': X[:4].copy(),
+           'cent_idx': cent_idx.astype(np.int64), 'label': label.astype(np.int8), 'inertia': np.float64(inertia),
+           'dist_sum': np.float64(c['M'].sum()), 'cost': np.float64((c['M'] * c['G']).sum()),
+           'splits': np.array(splits, dtype=np.float64).reshape(-1, 6), 'ref_seconds': dt}
+    print(f'ot 25m: inertia={inertia:.4f} cost={out["cost"]:.6f} splits={len(splits)} {dt:.1f}s', flush=True)
+    np.savez_compressed(os.path.join(HERE, 'ot_25m.npz'), **out)
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['full', 'sisa', 'eval', 'ot']
     torch.set_num_threads(1)
     for w in what:
-        {'full': gen_full, 'sisa': gen_sisa, 'eval': gen_eval, 'ot': gen_ot, 'ml1m': gen_ml1m, 'kmeans': gen_kmeans}[w]()
+        {'full': gen_full, 'sisa': gen_sisa, 'eval': gen_eval, 'ot': gen_ot, 'ml1m': gen_ml1m, 'kmeans': gen_kmeans,
+         'steplr': gen_steplr, 'sort': gen_sort, 'ot_ml1m': gen_ot_ml1m, 'preprocess': gen_preprocess, 'ot_25m': gen_ot_25m}[w]()

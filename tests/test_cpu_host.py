@@ -228,10 +228,10 @@ def test_native_ingest_matches_numpy(tmp_path):
     counts = np.zeros(4, dtype=np.int64)
     L = nv.lib()
     nv.check(L.ure_host_partition(u.ctypes.data, i.ctypes.data, r.ctypes.data, len(u), shard_of.ctypes.data, N_USER, 4, 5.0,
-                                  counts.ctypes.data, None, None, None), 'count')
+                                  counts.ctypes.data, None, None, None, None), 'count')
     ouid, oiid, orat = (np.empty(counts.sum(), np.int32), np.empty(counts.sum(), np.int32), np.empty(counts.sum(), np.float32))
     nv.check(L.ure_host_partition(u.ctypes.data, i.ctypes.data, r.ctypes.data, len(u), shard_of.ctypes.data, N_USER, 4, 5.0,
-                                  counts.ctypes.data, ouid.ctypes.data, oiid.ctypes.data, orat.ctypes.data), 'partition')
+                                  counts.ctypes.data, ouid.ctypes.data, oiid.ctypes.data, orat.ctypes.data, None), 'partition')
     want = O.partition(ou, oi, orr, idx, dels)
     o = 0
     for s_ in range(4):
@@ -375,11 +375,15 @@ loaders = [loadData(RatingData(np.vstack([rs.randint(0, 20, n), rs.randint(0, 10
 ids = [0, 1, 2]
 owner = assign_shards(sizes, 2)
 torch.manual_seed(42)
-prep = prepare_owned(ids, owner, rank, loaders, 20, 10, 4, 2, on_device=False)
+foreign = {}
+prep = prepare_owned(ids, owner, rank, loaders, 20, 10, 4, 2, on_device=False, foreign_u0=foreign)
 after = torch.empty((), dtype=torch.int64).random_().item()          # stream position after the call
 models = {i: (prep[i][1][0].clone() + 0, prep[i][1][1].clone() + 0) for i in prep}
-got = exchange_tables(models, ids, owner, rank, 20, 10, 4, torch.device('cpu'), dist)
-np.savez(sys.argv[2] + f'/rank{rank}.npz', owner=owner, after=after,
+rows = {0: torch.arange(0, 7), 1: torch.tensor([7, 9, 8, 14, 13, 12, 11, 10]), 2: torch.arange(15, 20)}   # ragged groups
+got = exchange_tables(models, ids, owner, rank, rows, 10, 4, torch.device('cpu'), dist)
+np.savez(sys.argv[2] + f'/rank{rank}.npz', owner=owner, after=after, foreign=sorted(foreign),
+         **{f'F{i}': foreign[i].numpy() for i in foreign},
+         **{f'R{i}': rows[i].numpy() for i in ids},
          **{f'U{i}': got[i][0].numpy() for i in ids}, **{f'V{i}': got[i][1].numpy() for i in ids},
          **{f'perm{i}': prep[i][2].numpy() for i in prep})
 dist.destroy_process_group()
@@ -388,8 +392,8 @@ dist.destroy_process_group()
 
 def test_two_rank_protocol_over_gloo(tmp_path):
     """world_size 2 on CPU: every rank replays the whole RNG stream, keeps its own
-    shards, and after the exchange holds every shard's tables -- identical to what a
-    single process draws sequentially."""
+    shards, and after the one all-gather holds every shard's OWN user rows and item table --
+    identical to what a single process draws sequentially (sisa.py:52-58 reads nothing else)."""
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29631', WORLD_SIZE='2')
@@ -409,58 +413,38 @@ def test_two_rank_protocol_over_gloo(tmp_path):
     for r in (r0, r1):
         assert int(r['after']) == after
         for i in range(3):
-            assert np.array_equal(r[f'U{i}'], want[i][0]) and np.array_equal(r[f'V{i}'], want[i][1])
+            assert np.array_equal(r[f'U{i}'], want[i][0][r[f'R{i}']]) and np.array_equal(r[f'V{i}'], want[i][1])
+        mine = [i for i in range(3) if int(r['owner'][i]) == (0 if r is r0 else 1)]
+        assert sorted(r['foreign'].tolist()) == sorted(set(range(3)) - set(mine))       # U0 of the shards it does not own
+        for i in r['foreign'].tolist():
+            assert np.array_equal(r[f'F{i}'], want[i][0])
     for i in range(3):
         src = r0 if int(r0['owner'][i]) == 0 else r1
         assert np.array_equal(src[f'perm{i}'], want[i][2])
 
 
-def test_preprocess_restates_the_notebook(tmp_path):
-    """data/ml1m/pro.ipynb as a function: 5-core filter, id squeeze in first-appearance order,
-    per-user int(0.9 * n) split, checked against a direct pandas restatement of the cells."""
-    import pandas as pd
-    import random
+def test_preprocess_properties_on_unsorted_input(tmp_path):
+    """ultrare_amd/preprocess.py on a file whose users are NOT grouped: 5-core property, squeezed ids,
+    int(0.9 n) rows per user in train, file order kept in both splits.  (The pin against the
+    notebook's own cells is tests/test_parity_pins.py::test_preprocess_matches_the_notebook_run.)"""
     from ultrare_amd.preprocess import preprocess
     rs = np.random.RandomState(0)
     n = 6000
     u = rs.zipf(1.3, n) % 300 + 1
     i = rs.zipf(1.2, n) % 400 + 1
-    df = pd.DataFrame({'uid': u, 'iid': i}).drop_duplicates()
-    df['rating'] = rs.randint(1, 6, len(df))
-    df['ts'] = 0
+    pairs = np.unique(np.stack([u, i], 1), axis=0)
+    pairs = pairs[rs.permutation(len(pairs))]
     dat = tmp_path / 'ratings.dat'
-    dat.write_text(''.join(f'{a}::{b}::{c}::{d}\n' for a, b, c, d in df.values.tolist()))
+    dat.write_text(''.join(f'{a}::{b}::{rs.randint(1, 6)}::0\n' for a, b in pairs.tolist()))
     info = preprocess(str(dat), str(tmp_path / 'out'), seed=5)
-    tr = pd.read_csv(tmp_path / 'out' / 'squ0_train.csv', header=None)
-    te = pd.read_csv(tmp_path / 'out' / 'squ0_test.csv', header=None)
-    # the notebook, cell by cell, in pandas
-    new = df.copy()
-    while True:
-        nf = 0
-        cnt = new.groupby('iid').size()
-        bad = cnt[cnt < 5].index
-        nf += len(bad)
-        new = new[~new.iid.isin(bad)]
-        cnt = new.groupby('uid').size()
-        bad = cnt[cnt < 5].index
-        nf += len(bad)
-        new = new[~new.uid.isin(bad)]
-        if nf == 0:
-            break
-    new = new.reset_index(drop=True)
-    new.uid -= 1
-    new.uid = new.uid.map({o: k for k, o in enumerate(new.uid.unique())})
-    new.iid = new.iid.map({o: k for k, o in enumerate(new.iid.unique())})
-    new = new.sort_values(by=['uid', 'iid']).reset_index(drop=True)
-    rng = random.Random(5)
-    tri = []
-    for uu in range(len(new.uid.unique())):
-        idx = new[new.uid == uu].index.to_list()
-        tri.extend(rng.sample(idx, int(len(idx) * 0.9)))
-    want_tr = new.iloc[np.sort(np.array(tri)), :]
-    want_te = new.drop(index=want_tr.index)
-    assert info['n_train'] == len(want_tr) == len(tr) and info['n_test'] == len(want_te) == len(te)
-    assert np.array_equal(tr[[0, 1]].values, want_tr[['uid', 'iid']].values)
-    assert np.array_equal(te[[0, 1]].values, want_te[['uid', 'iid']].values)
-    assert np.array_equal(tr[2].values, want_tr['rating'].values.astype(np.float16).astype(float))
-    assert info['n_user'] == len(new.uid.unique()) and info['n_item'] == len(new.iid.unique())
+    tr = np.loadtxt(tmp_path / 'out' / 'squ0_train.csv', delimiter=',')
+    te = np.loadtxt(tmp_path / 'out' / 'squ0_test.csv', delimiter=',')
+    assert info['n_train'] == len(tr) and info['n_test'] == len(te)
+    allr = np.vstack([tr, te])
+    cu, ci = np.bincount(allr[:, 0].astype(int)), np.bincount(allr[:, 1].astype(int))
+    assert cu.min() >= 5 and ci.min() >= 5 and len(cu) == info['n_user'] and len(ci) == info['n_item']
+    assert np.array_equal(np.bincount(tr[:, 0].astype(int), minlength=len(cu)), (cu * 0.9).astype(int))
+    assert len(np.unique(allr[:, :2], axis=0)) == len(allr)
+    # first-appearance squeeze: user ids appear in increasing order of first occurrence over train + test merged in file order
+    ud = np.load(tmp_path / 'out' / 'user_dict.npy', allow_pickle=True).item()
+    assert sorted(ud.values()) == list(range(info['n_user']))

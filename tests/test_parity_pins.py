@@ -1,0 +1,263 @@
+"""Round-2 pins, CPU side: the oracle and the host-side product code against goldens that
+tests/golden/make_golden.py produced by running the REAL reference in the build container.
+
+  steplr_toy.npz        Scratch.train E = 52: the StepLR boundary (scratch.py:69,79-80)
+  sort_toy.npz          readRating(..., sort='a') on uneven groups, with and without deleted users
+                        (read.py:40-50, 73-106; the only call the CLI path makes, config.py:80-88)
+  ot_ml1m.npz           ot_cluster at n = 6040, d = 32, k = 5 / 8 / 16 (utils.py:628-656)
+  ot_25m.npz            one round at n = 162,000, d = 128, k = 32 (present when generated)
+  preprocess_small.npz  data/ml1m/pro.ipynb cells 0-10 executed as written on a small ratings.dat
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+TRAIN, TEST = os.path.join(G, 'toy', '0_train.csv'), os.path.join(G, 'toy', '0_test.csv')
+N_USER, N_ITEM = 1508, 2071
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+# ------------------------------------------------------------------------------------ StepLR
+def test_oracle_crosses_the_steplr_boundary():
+    g = np.load(os.path.join(G, 'steplr_toy.npz'))
+    E = int(g['E'])
+    assert E == 52
+    # the reference's scheduler: lr after scheduler.step() number 50 is 0.95e-3 -> epochs 51, 52 train with it
+    np.testing.assert_allclose(g['lr_after_step'][[48, 49, 50, 51]], [1e-3, 0.95e-3, 0.95e-3, 0.95e-3], rtol=1e-12)
+    tr, te = O.load_csv(TRAIN), O.load_csv(TEST)
+    full = [list(range(N_USER))]
+    train, test = O.partition(*tr, full)[0], O.partition(*te, full)[0]
+    h = O.Hyper(k=16, batch=3000, epochs=E)
+    torch.manual_seed(h.seed)
+    U, V, log = O.scratch_train(h, N_USER, N_ITEM, train, test)
+    assert rel(U, g['U']) < 2e-6 and rel(V, g['V']) < 2e-6
+    np.testing.assert_allclose(log['train_loss'], g['train_loss'], rtol=2e-6)
+    np.testing.assert_allclose(log['test_rmse'], g['test_rmse'], rtol=2e-6)
+    np.testing.assert_allclose(log['test_ndcg'], g['test_ndcg'], rtol=1e-4)
+    # a run that ignored the boundary (lr = 1e-3 throughout) is measurably different: the pin has teeth
+    h2 = O.Hyper(k=16, batch=3000, epochs=E)
+    h2.lr_decay = 1.0
+    torch.manual_seed(h2.seed)
+    U2, _, log2 = O.scratch_train(h2, N_USER, N_ITEM, train, test, with_eval=False)
+    assert rel(U2, g['U']) > 1e-5 and abs(log2['train_loss'][-1] - g['train_loss'][-1]) > 1e-7
+
+
+# ------------------------------------------------------------------------------------ sort='a'
+def _sort_cases():
+    g = np.load(os.path.join(G, 'sort_toy.npz'))
+    for name in ('ot5', 'ot7', 'skew5'):
+        for tag in ('', '_del'):
+            key = name + tag
+            groups = [g[f'{key}_in{j}'].tolist() for j in range(int(g[key + '_n_group']))]
+            yield key, g, groups, (g['del_user'].tolist() if tag else [])
+
+
+def _check(arrs):
+    return np.array([[a[0].sum(), a[1].sum(), a[2].sum(), (a[0] * np.arange(1, a.shape[1] + 1)).sum()] for a in arrs], dtype=np.float64)
+
+
+def test_oracle_order_by_count_and_partition_match_reference_sort():
+    tr, te = O.load_csv(TRAIN), O.load_csv(TEST)
+    for key, g, groups, dels in _sort_cases():
+        idx = O.order_by_count(tr[0], groups)
+        assert [groups.index(x) for x in idx] == g[key + '_order'].tolist(), key
+        parts = O.partition(*tr, idx, dels)
+        assert [len(p[0]) for p in parts] == g[key + '_ntrain'].tolist(), key
+        assert [len(p[0]) for p in O.partition(*te, idx)] == g[key + '_ntest'].tolist(), key
+
+
+def test_product_read_rating_sort_a_matches_reference():
+    """The product's readRating (native CSV reader + ure_host_partition) on the exact call of
+    config.py:80-96: train with sort='a' (+ deleted users), test with the returned index."""
+    from ultrare_amd.read import readRating
+    for key, g, groups, dels in _sort_cases():
+        tr_l, idx = readRating(TRAIN, N_USER, 5, dels, [], len(groups), [list(x) for x in groups], 'a')
+        te_l, idx_te = readRating(TEST, N_USER, 5, [], [], len(groups), idx)
+        order = [next(j for j, x in enumerate(groups) if list(x) == list(i)) for i in idx]
+        assert order == g[key + '_order'].tolist(), key
+        assert [list(x) for x in idx_te] == [list(x) for x in idx]
+        assert [a.shape[1] for a in tr_l] == g[key + '_ntrain'].tolist(), key
+        assert [a.shape[1] for a in te_l] == g[key + '_ntest'].tolist(), key
+        assert all(a.dtype == np.float64 and a.shape[0] == 3 for a in tr_l)
+        np.testing.assert_array_equal(_check(tr_l), g[key + '_train_check'], err_msg=key)     # bit-equal sums: same rows, same order, same r / 5
+        np.testing.assert_array_equal(_check(te_l), g[key + '_test_check'], err_msg=key)
+
+
+def test_product_read_rating_general_form_equals_native_form():
+    """A user listed in two groups forces the boolean-pass form (np.in1d semantics: the user's rows go
+    to both shards); on disjoint groups both forms return the same arrays."""
+    from ultrare_amd import read
+    groups = [list(range(0, 500)), list(range(500, 1508))]
+    fast, _ = read.readRating(TRAIN, N_USER, 5, [3, 700], [], 2, groups)
+    slow, _ = read.readRating(TRAIN, N_USER, 5, [3, 700], [[0, 0]][:0] or [], 2, [groups[0] + [499], groups[1]])   # duplicate id -> general form
+    for a, b in zip(fast, slow):
+        np.testing.assert_array_equal(a, b)
+    both, _ = read.readRating(TRAIN, N_USER, 5, [], [], 2, [groups[0] + [600], groups[1]])
+    assert both[0].shape[1] > fast[0].shape[1] and (both[0][0] == 600).any() and (both[1][0] == 600).any()
+
+
+# ------------------------------------------------------------------------------------ OT at BASELINE sizes
+def ot_embedding(n, d, seed):
+    """make_golden.py::ot_embedding (numpy legacy generator: stable across versions)."""
+    rs = np.random.RandomState(seed)
+    centers = rs.standard_normal((12, d)) * 0.8
+    which = rs.randint(0, 12, n)
+    X = centers[which] + rs.standard_normal((n, d)) * 0.6
+    return X.astype(np.float32)
+
+
+@pytest.fixture(scope='module')
+def ot_ml1m():
+    g = np.load(os.path.join(G, 'ot_ml1m.npz'))
+    X = ot_embedding(int(g['n']), int(g['d']), int(g['seed']))
+    assert float(X.astype(np.float64).sum()) == float(g['X_sum']) and np.array_equal(X[:4], g['X_head'])
+    return g, X
+
+
+def _tied_points(g, tag, r):
+    sp = g[tag + '_splits']
+    sp = sp[sp[:, 0] == r]
+    return {int(row[1]): (int(row[2]), int(row[3]), row[4], row[5]) for row in sp}
+
+
+@pytest.mark.parametrize('k', [5, 8, 16])
+def test_product_solver_round_by_round_at_ml1m_size(ot_ml1m, k):
+    """Every round of the reference's ot_cluster run: cost matrix from the oracle (bit-exact numpy
+    order) of that round's centroids, the PRODUCT's exact solver (ure_ot_assign, host code), labels
+    compared with the reference's (HiGHS-backed) labels.  k | n: all labels equal.  k = 16: up to
+    k - 1 points are split exactly 8/8 between two clusters (6040 = 377.5 * 16) and a float LP solver
+    picks by rounding noise; there the label must be one of the two clusters, everything else equal.
+    Each plan carries an integer optimality certificate."""
+    from ultrare_amd import _native as nv
+    g, X = ot_ml1m
+    tag = f'k{k}'
+    n = len(X)
+    cents, labels = g[tag + '_round_centroids'], g[tag + '_round_labels'].astype(np.int64)
+    assert np.array_equal(cents[0], X[g[tag + '_cent_idx']])
+    for r in range(int(g[tag + '_rounds'])):
+        dist = O.ot_cost(X, cents[r])
+        assert float(dist.astype(np.float64).sum()) == float(g[tag + '_round_dist_sum'][r])        # the reference's cost matrix, bit for bit
+        label, plan, obj = nv.ot_assign(dist)
+        cert = O.ot_certificate(dist, plan)
+        assert cert['feasible'] and cert['optimal'], (k, r)
+        np.testing.assert_allclose(obj, g[tag + '_round_cost'][r], rtol=1e-9)
+        tied = _tied_points(g, tag, r)
+        diff = np.flatnonzero(label != labels[r])
+        if n % k == 0:
+            assert len(tied) == 0 and len(diff) == 0, (k, r, diff[:8])
+        else:
+            assert len(tied) <= k - 1
+            for i in diff:
+                assert int(i) in tied and label[i] in tied[int(i)][:2], (k, r, int(i))
+            for i, (a, b, sa, sb) in tied.items():                 # the product's rule on an exact tie: lowest cluster index
+                if abs(sa - sb) < 1e-9 and plan[i, a] == plan[i, b]:
+                    assert label[i] == min(a, b)
+        if r + 1 < len(cents):                                     # utils.py:648 with the REFERENCE's labels -> next round's centroids
+            np.testing.assert_array_equal(O.centroids(X, labels[r], k), cents[r + 1])
+
+
+@pytest.mark.parametrize('k', [5, 8])
+def test_oracle_ot_cluster_end_to_end_at_ml1m_size(ot_ml1m, k):
+    """The oracle's ot_cluster with the product's exact solver in place of HiGHS (k | n: the optimum
+    is unique, so the solver does not matter) reproduces the reference's final labels and inertia."""
+    from ultrare_amd import _native as nv
+    g, X = ot_ml1m
+    tag = f'k{k}'
+    n = len(X)
+    np.random.seed(0)
+    np.random.choice(n, int(2 / 100 * n), replace=False)
+    centroid = X[np.random.choice(n, size=k, replace=False)]
+    for r in range(10):
+        dist = O.ot_cost(X, centroid)
+        inertia = np.min(dist, axis=0).sum()
+        label, _, _ = nv.ot_assign(dist)
+        new_c = O.centroids(X, label, k)
+        if np.allclose(centroid, new_c):
+            break
+        centroid = new_c
+    assert r + 1 == int(g[tag + '_rounds'])
+    assert np.array_equal(label, g[tag + '_label']) and float(inertia) == float(g[tag + '_inertia'])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(G, 'ot_25m.npz')), reason='ot_25m.npz not generated')
+def test_product_solver_at_25m_size_vs_reference_round():
+    from ultrare_amd import _native as nv
+    g = np.load(os.path.join(G, 'ot_25m.npz'))
+    n, d, k = int(g['n']), int(g['d']), int(g['k'])
+    X = ot_embedding(n, d, int(g['seed']))
+    assert float(X.astype(np.float64).sum()) == float(g['X_sum'])
+    dist = O.ot_cost(X, X[g['cent_idx']])
+    assert float(dist.astype(np.float64).sum()) == float(g['dist_sum'])
+    label, plan, obj = nv.ot_assign(dist)
+    cert = O.ot_certificate(dist, plan)
+    assert cert['feasible'] and cert['optimal']
+    np.testing.assert_allclose(obj, float(g['cost']), rtol=1e-9)
+    tied = {int(r[1]): (int(r[2]), int(r[3])) for r in g['splits']}
+    diff = np.flatnonzero(label != g['label'].astype(np.int64))
+    assert len(tied) <= k - 1
+    for i in diff:
+        assert int(i) in tied and label[i] in tied[int(i)]
+
+
+def test_certificate_rejects_a_worse_plan():
+    from ultrare_amd import _native as nv
+    rs = np.random.RandomState(5)
+    dist = rs.rand(6, 300).astype(np.float32)
+    label, plan, _ = nv.ot_assign(dist)
+    assert O.ot_certificate(dist, plan)['optimal']
+    i, j = np.flatnonzero(label == 0)[0], np.flatnonzero(label == 1)[0]
+    worse = plan.copy()
+    worse[i], worse[j] = plan[j].copy(), plan[i].copy()
+    c = O.ot_certificate(dist, worse)
+    assert c['feasible'] and not c['optimal']
+    bad = plan.copy()
+    bad[0, 0] += 1
+    assert not O.ot_certificate(dist, bad)['feasible']
+
+
+# ------------------------------------------------------------------------------------ preprocessing
+def test_preprocess_matches_the_notebook_run(tmp_path):
+    """ultrare_amd/preprocess.py against the outputs of pro.ipynb's own cells (5-core filter, id squeeze
+    in first-appearance order, per-user random.sample 90/10 split with random.seed(5), float16 ratings)."""
+    from ultrare_amd.preprocess import preprocess
+    g = np.load(os.path.join(G, 'preprocess_small.npz'))
+    dat = tmp_path / 'ratings.dat'
+    dat.write_text(''.join('::'.join(str(int(x)) for x in row) + '\n' for row in g['ratings_dat']))
+    out = preprocess(str(dat), str(tmp_path), seed=int(g['split_seed']))
+    tr = np.loadtxt(tmp_path / 'squ0_train.csv', delimiter=',')
+    te = np.loadtxt(tmp_path / 'squ0_test.csv', delimiter=',')
+    np.testing.assert_array_equal(tr, g['train'])
+    np.testing.assert_array_equal(te, g['test'])
+    assert out['n_train'] == len(tr) and out['n_test'] == len(te)
+    for name in ('user_dict', 'item_dict'):
+        d = np.load(tmp_path / (name + '.npy'), allow_pickle=True).item()
+        assert sorted((int(a), int(b)) for a, b in d.items()) == [tuple(x) for x in g[name].tolist()]
+
+
+# ------------------------------------------------------------------------------------ CPU baseline port
+def test_torch_port_base_test_matches_reference_vectors():
+    """oracle/torch_port.py::base_test (the per-epoch tests of the end-to-end CPU baseline) reproduces
+    the reference's baseTest on its unit vectors."""
+    from torch.utils.data import DataLoader
+    from oracle import torch_port as T
+    g = np.load(os.path.join(G, 'eval_vectors.npz'))
+
+    class Table:
+        def __init__(self, tab):
+            self.tab = tab
+
+        def __call__(self, user, item):
+            return torch.tensor([self.tab[(int(a), int(b))] for a, b in zip(user, item)], dtype=torch.float32)
+    for c in range(int(g['n_cases'])):
+        u, i, r, sc = g[f'c{c}_u'], g[f'c{c}_i'], g[f'c{c}_r'], g[f'c{c}_scores']
+        models = [Table({(int(a), int(b)): float(s) for a, b, s in zip(u, i, sc[m])}) for m in range(sc.shape[0])]
+        ld = DataLoader(T._Triples(u, i, r), batch_size=int(g[f'c{c}_batch']), shuffle=False)
+        np.testing.assert_allclose(T.base_test(ld, models), g[f'c{c}_expect'], rtol=1e-9)

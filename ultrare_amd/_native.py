@@ -11,7 +11,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libultrare_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_MODELS_PER_CALL = 32
 
 _vp = ctypes.c_void_p
@@ -40,6 +40,7 @@ class NativeError(RuntimeError):
 
 _PROTOTYPES = {
     'ure_abi_version': (ctypes.c_int, []),
+    'ure_source_hash': (ctypes.c_char_p, []),
     'ure_last_error': (ctypes.c_char_p, []),
     'ure_device_info': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                        ctypes.c_char_p, ctypes.c_int]),
@@ -55,7 +56,7 @@ _PROTOTYPES = {
     'ure_host_read_csv': (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                          ctypes.POINTER(_i64), ctypes.c_int]),
     'ure_host_free': (None, [_vp]),
-    'ure_host_partition': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, ctypes.c_double, _vp, _vp, _vp, _vp]),
+    'ure_host_partition': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, ctypes.c_double, _vp, _vp, _vp, _vp, _vp]),
     'ure_host_build_layout': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp,
                                              ctypes.POINTER(_i64), ctypes.POINTER(_i32), _vp, _vp]),
     'ure_host_build_units': (ctypes.c_int, [_vp, _i32, _i32, _vp, _i64, ctypes.POINTER(_i64)]),
@@ -96,6 +97,12 @@ def lib():
             fn.argtypes = args
         if L.ure_abi_version() != ABI_VERSION:
             raise NativeError(f'ABI mismatch: library {L.ure_abi_version()} != binding {ABI_VERSION}')
+        # the library must be the build of THIS tree's sources (they travel together): a stale .so is an error,
+        # not something to run silently.  URE_ALLOW_STALE_LIB=1 is for experiment builds (tools/) only.
+        from . import build as _build
+        have, want = L.ure_source_hash().decode().replace('URE_SRC_HASH=', ''), _build.source_hash()
+        if have != want and os.environ.get('URE_ALLOW_STALE_LIB', '0') != '1' and LIB_PATH == _build.LIB:
+            raise NativeError(f'{LIB_PATH} was built from other sources (hash {have}, tree {want}): run `python -m ultrare_amd.build`')
         _lib = L
     return _lib
 
@@ -152,6 +159,24 @@ def read_csv(path, threads=0):
             if p:
                 lib().ure_host_free(p)
     return u, i, r
+
+
+def partition(uid, iid, rating, shard_of_user, n_shards, max_rating):
+    """ure_host_partition: one pass over the rows -> per shard (uid int32, iid int32, rating / max_rating
+    float64), file order kept; shard_of_user[u] = -1 drops user u (deleted, or in no group)."""
+    uid = np.ascontiguousarray(uid, dtype=np.int32)
+    iid = np.ascontiguousarray(iid, dtype=np.int32)
+    rating = np.ascontiguousarray(rating, dtype=np.float64)
+    shard_of_user = np.ascontiguousarray(shard_of_user, dtype=np.int32)
+    counts = np.zeros(n_shards, dtype=np.int64)
+    args = (uid.ctypes.data, iid.ctypes.data, rating.ctypes.data, len(uid), shard_of_user.ctypes.data, len(shard_of_user),
+            n_shards, float(max_rating), counts.ctypes.data)
+    check(lib().ure_host_partition(*args, None, None, None, None), 'ure_host_partition')
+    tot = int(counts.sum())
+    ou, oi, orr = np.empty(tot, np.int32), np.empty(tot, np.int32), np.empty(tot, np.float64)
+    check(lib().ure_host_partition(*args, ou.ctypes.data, oi.ctypes.data, None, orr.ctypes.data), 'ure_host_partition')
+    off = np.concatenate([[0], np.cumsum(counts)])
+    return [(ou[off[s]:off[s + 1]], oi[off[s]:off[s + 1]], orr[off[s]:off[s + 1]]) for s in range(n_shards)]
 
 
 def build_layout(uid, iid, rating, n_user, n_item, want_pos=False):

@@ -22,12 +22,34 @@ FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-mun
          '-ffp-contract=off', '-Wall', '-Wno-unused-result', '-pthread', '-mllvm', '-amdgpu-kernarg-preload-count=8']
 
 
+def source_hash(extra=()):
+    """sha256 (16 hex digits) over every file of csrc/, the public header and the compiler flags: the
+    identity of the code a library, a profile or a counter file belongs to."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.startswith('.')) + [os.path.join(ROOT, 'include', 'ultrare_hip.h')]
+    for path in files:
+        h.update(os.path.basename(path).encode() + b'\0')
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(list(FLAGS) + list(extra)).encode())
+    return h.hexdigest()[:16]
+
+
+def built_hash(lib=None):
+    """The hash a built library reports (ure_source_hash), read without loading it into this process
+    through ctypes' global namespace: a throw-away handle is enough, the symbol is plain C."""
+    lib = lib or LIB
+    if not os.path.exists(lib):
+        return None
+    with open(lib, 'rb') as f:
+        blob = f.read()
+    i = blob.find(b'URE_SRC_HASH=')
+    return blob[i + 13:i + 29].decode() if i >= 0 else None
+
+
 def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, 'include', 'ultrare_hip.h')]
-    return any(os.path.getmtime(p) > t for p in deps)
+    return built_hash() != source_hash()
 
 
 def build(force=False, verbose=False, timeline=None, defines=(), out=None):
@@ -39,7 +61,8 @@ def build(force=False, verbose=False, timeline=None, defines=(), out=None):
     if not os.path.exists(hipcc):
         raise RuntimeError('hipcc not found: libultrare_hip.so cannot be built')
     out = timeline or out or LIB
-    cmd = [hipcc] + FLAGS + (['-DURE_TIMELINE'] if timeline else []) + ['-D' + d for d in defines] + ['-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-o', out] + \
+    extra = (['-DURE_TIMELINE'] if timeline else []) + ['-D' + d for d in defines]
+    cmd = [hipcc] + FLAGS + extra + [f'-DURE_SOURCE_HASH="URE_SRC_HASH={source_hash(extra)}"'] + ['-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-o', out] + \
           [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd), flush=True)

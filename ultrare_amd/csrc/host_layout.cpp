@@ -152,7 +152,7 @@ void ure_host_free(void *p) { std::free(p); }
 
 int ure_host_partition(const int32_t *uid, const int32_t *iid, const double *rating, int64_t n, const int32_t *shard_of_user,
                        int32_t n_user, int32_t n_shards, double max_rating, int64_t *counts, int32_t *out_uid, int32_t *out_iid,
-                       float *out_rating)
+                       float *out_rating, double *out_rating64)
 {
     if (!uid || !iid || !rating || !shard_of_user || !counts || n < 0 || n_user <= 0 || n_shards <= 0)
         return ure::fail(-1, "ure_host_partition: bad arguments");
@@ -173,7 +173,9 @@ int ure_host_partition(const int32_t *uid, const int32_t *iid, const double *rat
         const int64_t o = cur[s]++;
         out_uid[o] = uid[j];
         out_iid[o] = iid[j];
-        out_rating[o] = (float)(rating[j] / max_rating);      // read.py:66 then read.py:113,124 (float64 division, one cast)
+        const double q = rating[j] / max_rating;              // read.py:66 (float64 division)
+        if (out_rating) out_rating[o] = (float)q;             // read.py:113,124: one cast to float32
+        if (out_rating64) out_rating64[o] = q;
     }
     return 0;
 }

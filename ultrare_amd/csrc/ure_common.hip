@@ -26,6 +26,11 @@ extern "C" {
 
 int ure_abi_version(void) { return URE_ABI_VERSION; }
 
+#ifndef URE_SOURCE_HASH
+#define URE_SOURCE_HASH "unknown"
+#endif
+const char *ure_source_hash(void) { return URE_SOURCE_HASH; }
+
 const char *ure_last_error(void) { return ure::err_buf(); }
 
 int ure_device_info(int dev, int *n_cu, int *wave_size, char *arch, int arch_len)

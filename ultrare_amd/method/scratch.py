@@ -20,7 +20,8 @@ from .utils import MF, padded_tables, seed_all
 
 PERM_THREADS = int(os.environ.get('URE_PERM_THREADS', str(min(16, os.cpu_count() or 1))))
 # end-of-epoch snapshots kept on the device for the per-epoch test series (per shard job)
-SNAPSHOT_LIMIT_BYTES = int(float(os.environ.get('URE_SNAPSHOT_LIMIT_GB', '8')) * 2 ** 30)
+def snapshot_limit():
+    return int(float(os.environ.get('URE_SNAPSHOT_LIMIT_GB', '8')) * 2 ** 30)
 
 
 def _is_empty(x):
@@ -103,7 +104,7 @@ class Scratch(object):
         # in four launches each (ure_eval_series); otherwise each epoch synchronises to print
         queued = verbose == 0
         snap_bytes = self.epochs * (self.n_user + self.n_item) * engine.pad_dim(self.k) * 4
-        series = queued and snap_bytes <= SNAPSHOT_LIMIT_BYTES
+        series = queued and snap_bytes <= snapshot_limit()
         job = engine.TrainJob([shard], [init], [perms], self.k, batch, self.epochs, self.lr, self.lam, self.momentum,
                               self.lr_decay, snapshots=series)
         rng.release(perms)                                  # uploaded: the host buffer goes back to the pool

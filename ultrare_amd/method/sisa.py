@@ -23,7 +23,7 @@ from torch import nn
 
 from .. import engine
 from ..read import as_loader
-from .scratch import Scratch, prepare_shard, SNAPSHOT_LIMIT_BYTES
+from .scratch import Scratch, prepare_shard, snapshot_limit
 from .utils import MF, baseTest, padded_tables, seed_all
 
 
@@ -45,11 +45,13 @@ def assign_shards(sizes, world):
     return owner
 
 
-def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_device=True):
+def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_device=True, foreign_u0=None):
     """Host part of a parallel call.  Every rank replays the WHOLE RNG stream in shard
     order (the draws are data independent: 4 fills + 4 seeds per epoch per shard,
     SURVEY.md 3.4) and keeps the init / permutations of its own shards only, so shard
-    i starts from exactly the state it would have in a sequential single-process run."""
+    i starts from exactly the state it would have in a sequential single-process run.
+    foreign_u0: dict that receives U0 of the shards other ranks own (the full pre-merge user
+    table of such a shard is its exchanged own rows + the closed form of U0 elsewhere)."""
     from .. import rng
     prepared = {}
     for pos, i in enumerate(ids):
@@ -63,7 +65,9 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
                 prepared[i] = (None, (init.user_mat.weight.detach(), init.item_mat.weight.detach()),
                                rng.epoch_perms(seeds, n))
         else:
-            rng.mf_init(n_user, n_item, k)
+            U0, _ = rng.mf_init(n_user, n_item, k)
+            if foreign_u0 is not None:
+                foreign_u0[i] = U0
             rng.epoch_seeds(epochs, True)
     for i, (shard, init, perms) in list(prepared.items()):      # permutations expanded in the background: collect
         if hasattr(perms, 'result'):
@@ -71,22 +75,59 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
     return prepared
 
 
-def exchange_tables(models, ids, owner, rank, n_user, n_item, k, device, dist):
-    """After isolated training every rank receives every shard's (U, V) from its
-    owner: one broadcast per table over RCCL/xGMI (payloads of a few MB, latency
-    bound).  This is the path's only communication (sisa.py:52-58 needs all U_i,
-    utils.py:140-145 all V_i)."""
-    out = {}
+def exchange_plan(ids, owner, group_sizes, n_item, k, world):
+    """Layout of the path's one collective.  A rank's segment holds, for each shard it owns (in `ids`
+    order), that shard's OWN user rows [len(group_index[i]), k] followed by its item table
+    [n_item, k]; segments are padded to the longest (all-gather-v as one all_gather_into_tensor).
+    -> ({shard: (rank, offset in floats)}, floats per segment)."""
+    fill = [0] * world
+    where = {}
+    for pos, i in enumerate(ids):
+        r = owner[pos]
+        where[i] = (r, fill[r])
+        fill[r] += (group_sizes[pos] + n_item) * k
+    return where, max(max(fill), 1)
+
+
+def exchange_tables(models, ids, owner, rank, rows, n_item, k, device, dist):
+    """After isolated training: ONE all-gather over RCCL/xGMI.  Every rank contributes, per shard it
+    owns, the rows of U_i that belong to the shard's own users (sisa.py:55-56 reads nothing else of
+    U_i) and V_i (utils.py:140-145 needs every model's item table); payloads are padded to the
+    longest segment.  `rows[i]` = device int64 tensor of group_index[i].
+    -> {shard: (U rows of its own users [len(rows[i]), k], V [n_item, k])}, device tensors."""
+    world = dist.get_world_size()
+    sizes = [int(rows[i].numel()) for i in ids]
+    where, seg = exchange_plan(ids, owner, sizes, n_item, k, world)
+    send = torch.zeros(seg, dtype=torch.float32, device=device)
     for pos, i in enumerate(ids):
         if owner[pos] == rank:
             U, V = models[i]
-        else:
-            U = torch.empty(n_user, k, dtype=torch.float32, device=device)
-            V = torch.empty(n_item, k, dtype=torch.float32, device=device)
-        dist.broadcast(U, src=owner[pos])
-        dist.broadcast(V, src=owner[pos])
-        out[i] = (U, V)
+            o = where[i][1]
+            nu = sizes[pos] * k
+            send[o:o + nu] = U.index_select(0, rows[i]).reshape(-1)
+            send[o + nu:o + nu + n_item * k] = V.reshape(-1)
+    recv = torch.empty(world * seg, dtype=torch.float32, device=device)
+    if dist.get_backend() == 'nccl':
+        dist.all_gather_into_tensor(recv, send)
+    else:       # rehearsal transports (gloo): staged through the host
+        host = torch.empty(world * seg, dtype=torch.float32)
+        dist.all_gather_into_tensor(host, send.cpu())
+        recv.copy_(host)
+    out = {}
+    for pos, i in enumerate(ids):
+        r, o = where[i]
+        base = r * seg + o
+        nu = sizes[pos] * k
+        out[i] = (recv[base:base + nu].view(sizes[pos], k), recv[base + nu:base + nu + n_item * k].view(n_item, k))
     return out
+
+
+def untouched_scale(lr, lr_decay, epochs, steps, lam, momentum, lr_step=50):
+    """a_T of a row that only decays (no interaction in its shard) after the whole training:
+    w_T = float32(a_T) * w_0 -- the same closed form ure_job_materialize applies on the owner."""
+    lr_host = np.array([lr * (lr_decay ** (t // lr_step)) for t in range(epochs)], dtype=np.float32)
+    a = engine.closed_form_scalars(lr_host, steps, float(np.float32(lam)), float(np.float32(momentum)))
+    return np.float32(a[-1]) if len(a) else np.float32(1.0)
 
 
 class Sisa(Scratch):
@@ -131,12 +172,19 @@ class Sisa(Scratch):
         rank = dist.get_rank() if dist else 0
         sizes = [len(as_loader(train_dlist[i]).dataset) for i in ids]
         owner = assign_shards(sizes, world)
-        prepared = prepare_owned(ids, owner, rank, train_dlist, self.n_user, self.n_item, self.k, self.epochs)
+        # full pre-merge user tables of other ranks' shards are needed for the reference's per-epoch logs
+        # (scratch.py:83-86 averages the earlier models as they are) and for user_mat{id}.npy on rank 0
+        want_full = bool(dist) and (self.epoch_logs or (rank == 0 and len(save_dir) > 0))
+        foreign_u0 = {} if want_full else None
+        prepared = prepare_owned(ids, owner, rank, train_dlist, self.n_user, self.n_item, self.k, self.epochs,
+                                 foreign_u0=foreign_u0)
         mine = [i for pos, i in enumerate(ids) if owner[pos] == rank]
         snap_bytes = len(mine) * self.epochs * (self.n_user + self.n_item) * engine.pad_dim(self.k) * 4
-        keep_logs = self.epoch_logs and snap_bytes <= SNAPSHOT_LIMIT_BYTES
-        if self.epoch_logs and not keep_logs and verbose:
-            print(f'per-epoch test logs skipped: {snap_bytes / 2**30:.1f} GiB of snapshots exceeds the limit')
+        keep_logs = self.epoch_logs and snap_bytes <= snapshot_limit()
+        if self.epoch_logs and not keep_logs:
+            import warnings
+            warnings.warn(f'per-epoch test logs of this call are NaN: {snap_bytes / 2**30:.1f} GiB of end-of-epoch snapshots '
+                          f'exceed URE_SNAPSHOT_LIMIT_GB ({snapshot_limit() / 2**30:.3g}); train_loss and log0 are complete')
         models, job, losses = {}, None, {}
         if mine:
             batch = as_loader(train_dlist[mine[0]]).batch_size
@@ -151,8 +199,24 @@ class Sisa(Scratch):
                 U, V = job.tables(pos)
                 models[i] = (U.clone().contiguous(), V.clone().contiguous())
                 losses[i] = [float(x) for x in np.sqrt(job.epoch_sse(pos) / prepared[i][0].N)]
-        if dist:   # the only exchange of the path: every rank ends up with every shard's tables
-            models = exchange_tables(models, ids, owner, rank, self.n_user, self.n_item, self.k, engine._device(), dist)
+        if dist:
+            # the only exchange of the path (sisa.py:52-58): own user rows + item table of every shard, one all-gather
+            dev = engine._device()
+            rows = {i: self._rows(i).to(dev) for i in ids}
+            got = exchange_tables(models, ids, owner, rank, rows, self.n_item, self.k, dev, dist)
+            batch = as_loader(train_dlist[ids[0]]).batch_size
+            for pos, i in enumerate(ids):
+                if owner[pos] == rank:
+                    continue
+                Ur, V = got[i]
+                if want_full:      # rows of other shards' users never train in shard i: closed form of U0 (engine lazy rows)
+                    steps = (sizes[pos] + batch - 1) // batch
+                    a = untouched_scale(self.lr, self.lr_decay, self.epochs, steps, self.lam, self.momentum)
+                    U = foreign_u0[i].to(dev) * float(a)
+                else:              # only the shard's own rows are ever read again (merge + final test)
+                    U = torch.zeros(self.n_user, self.k, dtype=torch.float32, device=dev)
+                U.index_copy_(0, rows[i], Ur)
+                models[i] = (U, V.clone())
         out = {i: MF.from_tables(*models[i]) for i in ids}
 
         # ---- logs, shard after shard in the reference's order (one dict for all shards)
@@ -182,6 +246,10 @@ class Sisa(Scratch):
                     entry[key] = [float(x) for x in res[:, 0, c]]
                 for c, key in enumerate(('total_rmse', 'total_ndcg', 'total_hr')):
                     entry[key] = [float(x) for x in res[:, 1, c]]
+            else:
+                nan = [float('nan')] * self.epochs
+                for key in ('test_rmse', 'test_ndcg', 'test_hr', 'total_rmse', 'total_ndcg', 'total_hr'):
+                    entry[key] = list(nan)
             logs[i] = entry
         if job is not None:
             job.close()

@@ -4,12 +4,13 @@ Restates the reference's preprocessing notebook (data/ml1m/pro.ipynb) as a funct
   cell 0-1   read `uid::iid::rating::timestamp`
   cell 4     iterative 5-core filter: drop items with < low ratings, then users with < low
              ratings, until nothing is dropped
-  cell 7     `uid -= 1`, then squeeze user and item ids to 0..n-1 in order of first appearance;
-             sort by (uid, iid)
+  cell 7     `uid -= 1`, then squeeze user and item ids to 0..n-1 in order of first appearance
+             (the sorted copy it writes, ratings.csv, is not read again)
   cell 10    per user, in id order: n_train = int(total * 0.9) rows drawn with
              `random.sample` (Python's generator; the notebook never seeds it, so a run is
              reproducible only if the caller passes a seed), the rest is the test split; both
-             splits keep the sorted row order; ratings written as float16 values
+             splits keep the FILE order of the rows (ml-1m's ratings.dat is grouped by user);
+             ratings written as float16 values
 
     python -m ultrare_amd.preprocess ratings.dat out_dir [--seed 0]
 """
@@ -59,13 +60,14 @@ def preprocess(ratings_dat, out_dir, low=5, train_ratio=0.9, seed=None):
     uid, iid, rating = uid[keep] - 1, iid[keep], rating[keep]
     uid, user_dict = squeeze(uid)
     iid, item_dict = squeeze(iid)
-    order = np.lexsort((iid, uid))
-    uid, iid, rating = uid[order], iid[order], rating[order]
+    # cell 10 works on the frame in FILE order (cell 7 sorts only the copy it writes to ratings.csv): a user's
+    # candidate list is its row numbers ascending, and both splits keep the file order of the rows
     rng = random.Random(seed) if seed is not None else random
-    start = np.searchsorted(uid, np.arange(int(uid.max()) + 2))
+    by_user = np.argsort(uid, kind='stable')
+    start = np.searchsorted(uid[by_user], np.arange(int(uid.max()) + 2))
     is_train = np.zeros(len(uid), dtype=bool)
     for u in range(int(uid.max()) + 1):
-        idx = list(range(int(start[u]), int(start[u + 1])))
+        idx = by_user[int(start[u]):int(start[u + 1])].tolist()
         is_train[rng.sample(idx, int(len(idx) * train_ratio))] = True
     os.makedirs(out_dir, exist_ok=True)
     val = rating.astype(np.float16)

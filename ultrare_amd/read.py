@@ -58,11 +58,27 @@ def readRating(dir, n_user, max_rating=5, del_user=[], del_rating=[], n_group=1,
         sorted_index = sort_group(order='a', group_index=group_index, var='count', ratings0=uid)   # read.py:45: always ascending
         group_index = [group_index[i] for i in sorted_index]
 
-    deleted = np.zeros(max(n_user, int(uid.max()) + 1 if len(uid) else 0), dtype=bool)
+    n_ids = max(n_user, int(uid.max()) + 1 if len(uid) else 0)
+    shard_of = np.full(n_ids, -1, dtype=np.int32)
+    overlapping = False
+    for s, g in enumerate(group_index[:n_group]):
+        g = np.asarray(g, dtype=np.int64)
+        overlapping = overlapping or bool((shard_of[g] >= 0).any()) or len(np.unique(g)) != len(g)
+        shard_of[g] = s
+    if not overlapping and len(del_rating) == 0:
+        # one native pass over the rows (ure_host_partition): shard = group of the row's user, deleted users dropped
+        if len(del_user):
+            shard_of[np.asarray(list(del_user), dtype=np.int64)] = -1
+        from . import _native as nv
+        rating_lists = [np.vstack([u.astype(np.float64), i.astype(np.float64), r])
+                        for u, i, r in nv.partition(uid, iid, raw, shard_of, n_group, max_rating)]
+        return rating_lists, group_index
+
+    # general form of read.py:52-70 (a user listed in two groups, or single ratings deleted): boolean passes
+    deleted = np.zeros(n_ids, dtype=bool)
     if len(del_user):
         deleted[np.asarray(list(del_user), dtype=np.int64)] = True
-    # del_rating (single-rating deletion, config.py:36) is always [] on the published
-    # path; rows listed there are dropped as well for completeness
+    # del_rating (single-rating deletion, config.py:36) is always [] on the published path
     drop = np.zeros(len(uid), dtype=bool)
     for pair in np.asarray(del_rating).reshape(-1, 2) if len(del_rating) else ():
         drop |= (uid == int(pair[0])) & (iid == int(pair[1]))
