@@ -112,6 +112,16 @@ typedef struct ure_shard {
     int32_t batch;          /* B (config.py:26)                                     */
     int32_t epochs;
     float   lam, mu;        /* weight decay, momentum (config.py:20,29)             */
+    /* Touch mode (needs lazy_rows, at most 64 steps per epoch, and the same lr / lam / mu schedule for
+     * every shard of the job): a step visits only the rows it trains; rows are kept valid for their NEXT
+     * own step and advanced over the steps in between by the optimizer's closed form (csrc/mf_touch.h).
+     * For jobs whose tables do not fit the caches (BASELINE.json configs[3]).  The tables can then be
+     * read (ure_job_materialize, snapshots) at the shard's epoch boundaries only.               */
+    int32_t touch_mode;
+    /* touch mode: the first n_multi rows of the schedule are longer than one scan pass (8 * lanes slots)
+     * and `units` covers exactly those; the rows [n_multi, n_active) fit in one pass and are worked off
+     * from a per-step compaction of the rows that have interactions in the step.                  */
+    int32_t n_multi;
 } ure_shard_t;
 
 typedef struct ure_job ure_job_t;   /* a set of shards trained side by side */

@@ -6,6 +6,7 @@ import ctypes
 import os
 import re
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -448,3 +449,45 @@ def test_preprocess_properties_on_unsorted_input(tmp_path):
     # first-appearance squeeze: user ids appear in increasing order of first occurrence over train + test merged in file order
     ud = np.load(tmp_path / 'out' / 'user_dict.npy', allow_pickle=True).item()
     assert sorted(ud.values()) == list(range(info['n_user']))
+
+
+# ---------------------------------------------------------------- bench.py host logic (no GPU here)
+def test_bench_spawn_propagates_rank_failure_without_hanging():
+    """`python bench.py --gpus 2` with no launcher starts two rank processes itself.  In this container
+    there is no GPU, so every rank stops with the 'needs an MI355X' message: the parent must come back
+    promptly with a non-zero code (and must not have touched the GPU itself)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is visible: covered by tests/test_gpu_multirank.py')
+    assert p.returncode != 0 and time.time() - t0 < 120
+    assert b'needs an MI355X' in p.stderr and p.stderr.count(b'needs an MI355X') == 2      # both ranks were started
+
+
+def test_exchange_plan_is_a_padded_all_gather_v():
+    from ultrare_amd.method.sisa import exchange_plan
+    ids, owner, sizes = [0, 1, 2, 3, 4], [0, 1, 0, 2, 1], [7, 8, 5, 3, 9]
+    where, seg = exchange_plan(ids, owner, sizes, n_item=10, k=4, world=4)
+    fill = {r: sum((sizes[p] + 10) * 4 for p in range(5) if owner[p] == r) for r in range(4)}
+    assert seg == max(fill.values()) and fill[3] == 0
+    for r in range(4):                                   # a rank's shards tile its segment back to back, in ids order
+        off = 0
+        for p, i in enumerate(ids):
+            if owner[p] == r:
+                assert where[i] == (r, off)
+                off += (sizes[p] + 10) * 4
+
+
+def test_bench_counts_interactions_exactly():
+    import importlib.util
+    sp = importlib.util.spec_from_file_location('bench', os.path.join(ROOT, 'bench.py'))
+    b = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(b)
+    sizes, B, E = [70, 25, 100], 30, 3
+    tot, per_tick, dense = b.interactions_in_ticks(sizes, B, 0, 12, E, dense_bytes=[1, 10, 100])
+    # shard 0: 3 steps/epoch (30, 30, 10); shard 1: 1 step (25), done after tick 3; shard 2: 4 steps (30, 30, 30, 10)
+    assert tot == 3 * 70 + 3 * 25 + 3 * 100
+    assert per_tick[:4].tolist() == [30 + 25 + 30, 30 + 25 + 30, 10 + 25 + 30, 30 + 0 + 10]
+    assert dense[:4].tolist() == [111, 111, 111, 101] and dense[9:].tolist() == [100, 100, 100]

@@ -91,3 +91,42 @@ def test_two_ranks_share_one_gpu(tmp_path):
     # only rank 0 writes artifacts (scratch.py:131-144)
     assert os.path.exists(tmp_path / 'rank0' / 'user_mat4.npy') and os.path.exists(tmp_path / 'rank0' / 'log0.npy')
     assert not os.path.exists(tmp_path / 'rank1' / 'user_mat4.npy')
+
+
+def _bench(args, timeout=900):
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, stdout=subprocess.PIPE, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, lines                 # the driver contract: ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher: the script starts both ranks (here over gloo, both on
+    the one visible GPU), rank 0 prints the one JSON line with n_gpus == 2, the exchange leg ran the
+    all-gather, and the configs[2] split placed ONE job's 8 shards over both ranks."""
+    out = _bench(['--gpus', '2', '--backend', 'gloo', '--force-device', '0', '--steps', '2', '--warmup', '1',
+                  '--roofline-steps', '1', '--splits', 'config2'])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0
+    assert out['interactions_timed'] > 2 * 2 * 5 * 100000          # both ranks' shards were counted
+    ex = out['exchange']
+    assert ex['received_ok'] and ex['shards'] == 10 and ex['bytes_gathered'] == 2 * ex['bytes_per_rank']
+    c2 = out['north_star_splits']['config2']
+    assert c2['scaling'] == 'strong' and c2['shards_per_rank'] == [4, 4] and c2['value'] > 0
+    assert out['roofline']['frac'] > 0 and out['roofline']['source_hash']
+
+
+def test_bench_rccl_calls_on_one_rank():
+    """The RCCL half of the N > 1 path on a one-GPU box: a one-rank nccl process group runs the same
+    init / barrier / all_reduce / all_gather_into_tensor calls the 8-GPU run makes."""
+    out = _bench(['--gpus', '1', '--force-dist', '--steps', '2', '--warmup', '1', '--roofline-steps', '1', '--splits', 'config2'])
+    assert out['n_gpus'] == 1 and out['exchange']['backend'] == 'nccl' and out['exchange']['received_ok']
+    assert out['north_star_splits']['config2']['shards_per_rank'] == [8]
+
+
+def test_bench_split_mode_headline():
+    out = _bench(['--gpus', '2', '--backend', 'gloo', '--force-device', '0', '--steps', '2', '--warmup', '1', '--roofline-steps', '1',
+                  '--split', '1', '--shards', '8', '--d', '64', '--splits', 'none'])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['config']['shards_per_gpu'] == 4

@@ -1,0 +1,294 @@
+"""Round-2 GPU parity pins: the branches and sizes the round-1 suite did not reach.
+
+  * Scratch.train at E = 52 against the reference's own run (StepLR boundary, scratch.py:69,79-80)
+  * the CLI's default verbose=1 branch, verbose=2, the over-limit snapshot branch and the
+    given_model branch of Scratch.train -- all must equal the verbose=0 results and the goldens
+  * the parallel Sisa path when the end-of-epoch snapshots exceed the limit (NaN series, full log0)
+  * lazy rows on / off (dense optimizer exactly as the reference steps it), across the StepLR boundary
+    and with a mid-training materialize()
+  * four d = 128 shards of configs[3] size side by side against the C oracle
+  * ot_cluster at n = 6040 (k = 5, 8 end to end; k = 16 round by round) against the reference's run
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+TRAIN, TEST = os.path.join(G, 'toy', '0_train.csv'), os.path.join(G, 'toy', '0_test.csv')
+N_USER, N_ITEM = 1508, 2071
+RTOL = 1e-4
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+class Param:
+    def __init__(self, epochs, k=16, batch=3000, parallel=False):
+        self.k, self.lam, self.seed, self.batch = k, 0.1, 42, batch
+        self.lr, self.lr_decay, self.momentum, self.epochs = 0.001, 0.95, 0.9, epochs
+        self.n_user, self.n_item, self.parallel = N_USER, N_ITEM, parallel
+
+
+def _full_loaders():
+    from ultrare_amd.read import RatingData, loadData, readRating
+    tr, idx = readRating(TRAIN, N_USER, 5, [], [], 1, [])
+    te, _ = readRating(TEST, N_USER, 5, [], [], 1, idx)
+    return loadData(RatingData(tr[0]), 3000, 24), loadData(RatingData(te[0]), 3000, 24, False)
+
+
+def test_scratch_train_crosses_the_steplr_boundary():
+    from ultrare_amd.method.scratch import Scratch
+    g = np.load(os.path.join(G, 'steplr_toy.npz'))
+    train, test = _full_loaders()
+    sc = Scratch(Param(int(g['E'])), 'mf')
+    torch.manual_seed(42)
+    model = sc.train(train, test, [], 0, '')
+    assert rel(model.user_mat.weight, g['U']) < RTOL and rel(model.item_mat.weight, g['V']) < RTOL
+    for key in ('train_loss', 'test_rmse', 'test_ndcg', 'test_hr'):
+        np.testing.assert_allclose(sc.log[key], g[key], rtol=RTOL, err_msg=key)
+    # epochs 51 and 52 ran with lr * 0.95: one more epoch at the old rate would move the loss differently
+    assert abs((g['train_loss'][51] - g['train_loss'][50]) - (sc.log['train_loss'][51] - sc.log['train_loss'][50])) < 1e-7
+
+
+@pytest.mark.parametrize('mode', ['verbose1', 'verbose2', 'over_limit'])
+def test_scratch_train_branches_equal_the_queued_run(mode, capsys, monkeypatch):
+    """main.py defaults to --verbose 1: Scratch.train then synchronises and prints every epoch.  That
+    branch, verbose=2 and the verbose=0 branch whose snapshots exceed URE_SNAPSHOT_LIMIT_GB (per-epoch
+    evaluations queued instead of the series) must produce the tables and logs of the default
+    verbose=0 run, which the goldens pin."""
+    from ultrare_amd.method.scratch import Scratch
+    g = np.load(os.path.join(G, 'full_mf_toy.npz'))
+    E = 3
+    train, test = _full_loaders()
+    if mode == 'over_limit':
+        monkeypatch.setenv('URE_SNAPSHOT_LIMIT_GB', '1e-6')
+    sc = Scratch(Param(E), 'mf')
+    torch.manual_seed(42)
+    model = sc.train(train, test, [], {'verbose1': 1, 'verbose2': 2, 'over_limit': 0}[mode], '')
+    out = capsys.readouterr().out
+    assert rel(model.user_mat.weight, g[f'E{E}_U']) < RTOL and rel(model.item_mat.weight, g[f'E{E}_V']) < RTOL
+    for key in ('train_loss', 'test_rmse', 'test_ndcg', 'test_hr'):
+        assert len(sc.log[key]) == E
+        np.testing.assert_allclose(sc.log[key], g[f'E{E}_{key}'], rtol=RTOL, err_msg=key)
+    assert len(sc.log['time']) == E and sc.log['total_rmse'] == []          # runFull has no total test (scratch.py:92-95)
+    if mode == 'verbose1':
+        assert out.count('Epoch: [') == E and 'train RMSE' in out and 'total RMSE' not in out     # scratch.py:101-117
+    if mode == 'verbose2':
+        assert out.count('Test - RMSE') == E and out.count('Time:') == E
+
+
+def test_scratch_train_given_model_continues_from_it():
+    """scratch.py:57-61: with `given_model` the tables start from that model (no init draws for the
+    weights); two epochs from the golden's E=1 model -- same stream position as the reference would be
+    at -- equal a direct run of the oracle from those tables."""
+    from ultrare_amd import rng
+    from ultrare_amd.method.scratch import Scratch
+    from ultrare_amd.method.utils import MF
+    g = np.load(os.path.join(G, 'full_mf_toy.npz'))
+    train, test = _full_loaders()
+    start = MF.from_tables(torch.from_numpy(g['E1_U']).cuda(), torch.from_numpy(g['E1_V']).cuda())
+    sc = Scratch(Param(2), 'mf')
+    torch.manual_seed(7)
+    model = sc.train(train, test, [], 0, '', 0, start)
+    # oracle: the same draws (3 seeds per epoch, no init fills), same start tables
+    torch.manual_seed(7)
+    seeds = rng.epoch_seeds(2, False)
+    tr = O.partition(*O.load_csv(TRAIN), [list(range(N_USER))])[0]
+    st = O.MFState(g['E1_U'].copy(), g['E1_V'].copy())
+    losses = [O.train_epoch(st, tr, rng.epoch_perm(s, len(tr[0])).numpy(), 3000, 1e-3, 0.1, 0.9)[0] for s in seeds]
+    assert rel(model.user_mat.weight, st.U) < 1e-5 and rel(model.item_mat.weight, st.V) < 1e-5
+    np.testing.assert_allclose(sc.log['train_loss'], losses, rtol=1e-5)
+
+
+def _sisa_inputs(S, del_user=()):
+    from ultrare_amd.read import RatingData, loadData, readRating
+    tr, idx = readRating(TRAIN, N_USER, 5, list(del_user), [], S, [])
+    te, _ = readRating(TEST, N_USER, 5, [], [], S, idx)
+    return (idx, [loadData(RatingData(a), 3000, 24) for a in tr], [loadData(RatingData(a), 3000, 24, False) for a in te],
+            loadData(RatingData(np.hstack(te)), 3000, 24, False))
+
+
+def test_parallel_sisa_over_the_snapshot_limit(monkeypatch, tmp_path):
+    """above URE_SNAPSHOT_LIMIT_GB the parallel path cannot rebuild the per-epoch test
+    series.  It must say so unconditionally, keep every series at `epochs` entries per shard (NaN),
+    and still deliver the models, train_loss and log0 of the goldens."""
+    from ultrare_amd.method.sisa import Sisa
+    g = np.load(os.path.join(G, 'sisa_toy.npz'))
+    S, E = 4, 3
+    idx, trd, ted, tot = _sisa_inputs(S)
+    monkeypatch.setenv('URE_SNAPSHOT_LIMIT_GB', '1e-6')
+    sisa = Sisa(Param(E, parallel=True), 'mf', S, idx)
+    torch.manual_seed(42)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        ml = sisa.learn(trd, ted, tot, 0, str(tmp_path))
+    assert any('per-epoch test logs' in str(x.message) for x in w)
+    for i in range(S):
+        assert rel(ml[i].item_mat.weight, g[f'S4_learn_V{i}']) < RTOL
+    assert rel(ml[0].user_mat.weight, g['S4_learn_Umerged']) < RTOL
+    np.testing.assert_allclose(sisa.log['train_loss'], g['S4_learn_log_train_loss'], rtol=RTOL)
+    np.testing.assert_allclose([sisa.log0['total_rmse'], sisa.log0['total_ndcg'], sisa.log0['total_hr']], g['S4_learn_log0'], rtol=RTOL)
+    for key in ('test_rmse', 'test_ndcg', 'test_hr', 'total_rmse', 'total_ndcg', 'total_hr', 'time'):
+        assert len(sisa.log[key]) == S * E, key                              # same length as train_loss: the log stays rectangular
+    assert np.isnan(sisa.log['total_rmse']).all()
+
+
+# ------------------------------------------------------------------------------------ lazy rows on / off
+@pytest.mark.parametrize('lazy', [False, True])
+def test_dense_and_lazy_rows_agree_with_the_oracle(lazy):
+    """URE_LAZY_ROWS=0 streams the rows a shard never touches through the optimizer every step, exactly
+    as the reference's dense SGD does; the default advances them in closed form.  Both against the C
+    oracle over 53 epochs (the StepLR boundary at 50) with a materialize() in the middle of training,
+    on a shard that leaves 2/3 of the user rows untouched."""
+    from ultrare_amd import engine, rng
+    raw = O.load_csv(TRAIN)
+    part = O.partition(*raw, O.uniform_groups(N_USER, 3))[1]
+    k, B, E = 16, 1500, 53
+    torch.manual_seed(3)
+    init = rng.mf_init(N_USER, N_ITEM, k)
+    perms = rng.epoch_perms(rng.epoch_seeds(E, True), len(part[0]))
+    job = engine.TrainJob([engine.ShardData(*part, N_USER, N_ITEM)], [init], [perms], k, B, E, 1e-3, 0.1, 0.9, 0.95, lazy_rows=lazy)
+    assert job.lazy_rows == lazy
+    st = O.MFState(init[0].numpy().copy(), init[1].numpy().copy())
+    job.run_epochs(20)
+    for t in range(20):
+        O.train_epoch(st, part, perms[t].numpy(), B, 1e-3, 0.1, 0.9)
+    U, V = job.tables(0)                                            # materialises the lazily advanced rows mid-training
+    assert rel(U, st.U) < 2e-5 and rel(V, st.V) < 2e-5
+    job.run()
+    for t in range(20, E):
+        O.train_epoch(st, part, perms[t].numpy(), B, 1e-3 * 0.95 ** (t // 50), 0.1, 0.9)
+    U, V = job.tables(0)
+    bound = 2e-5 if lazy else 1e-5
+    assert rel(U, st.U) < bound and rel(V, st.V) < bound
+    untouched = np.setdiff1d(np.arange(N_USER), np.unique(part[0]))
+    assert len(untouched) > 900
+    # the untouched rows: dense = the oracle's fp32 steps to the last bit or two; lazy = closed form, ~1e-6 away
+    err = np.abs(U.cpu().numpy()[untouched] - st.U[untouched]).max() / np.abs(st.U[untouched]).max()
+    assert err < (5e-6 if lazy else 1e-6), err
+
+
+def test_dense_and_lazy_rows_agree_with_each_other():
+    from ultrare_amd import engine, rng
+    raw = O.load_csv(TRAIN)
+    parts = O.partition(*raw, O.uniform_groups(N_USER, 2))
+    k, B, E = 32, 3000, 4
+    out = {}
+    for lazy in (False, True):
+        torch.manual_seed(5)
+        inits = [rng.mf_init(N_USER, N_ITEM, k) for _ in parts]
+        perms = [rng.epoch_perms(rng.epoch_seeds(E, True), len(p[0])) for p in parts]
+        job = engine.TrainJob([engine.ShardData(*p, N_USER, N_ITEM) for p in parts], inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95,
+                              lazy_rows=lazy)
+        job.run()
+        out[lazy] = [tuple(t.cpu().numpy() for t in job.tables(s)) for s in range(2)]
+    for s in range(2):
+        assert rel(out[True][s][0], out[False][s][0]) < 2e-6 and rel(out[True][s][1], out[False][s][1]) < 2e-6
+        touched = np.unique(parts[s][0])
+        assert np.array_equal(out[True][s][0][touched], out[False][s][0][touched])       # rows with interactions: bit-identical
+
+
+# ------------------------------------------------------------------------------------ configs[3]: d = 128 shards side by side
+def test_four_d128_shards_side_by_side_vs_oracle():
+    """configs[3] per-shard size (5,063 users, 60,000 items, ~703k ratings, d = 128, 24 steps/epoch), FOUR
+    such shards in one job -- the V4 = 2 / 16-lanes-per-row instantiation with the sliced XCD mapping --
+    every shard against the C oracle after one epoch, and equal to the same shard trained alone."""
+    from ultrare_amd import engine, rng, synth
+    n_user, n_item, k, B, S = 162000, 60000, 128, 30000, 4
+    parts = []
+    for s in range(S):
+        d = synth.make_dataset(5063, n_item, 703125, 78125, seed=21 + s)
+        ids = np.sort(np.random.RandomState(50 + s).choice(n_user, 5063, replace=False))
+        u, i, r = d['train']
+        parts.append((ids[u].astype(np.int32), i.astype(np.int32), (r / 5).astype(np.float32)))
+    torch.manual_seed(42)
+    inits, perms = [], []
+    for p in parts:
+        inits.append(rng.mf_init(n_user, n_item, k))
+        perms.append(rng.epoch_perms(rng.epoch_seeds(1, True), len(p[0])))
+    shards = [engine.ShardData(*p, n_user, n_item) for p in parts]
+    job = engine.TrainJob(shards, inits, perms, k, B, 1, 1e-3, 0.1, 0.9, 0.95)
+    job.run()
+    torch.cuda.synchronize()
+    alone = engine.TrainJob([shards[2]], [inits[2]], [perms[2]], k, B, 1, 1e-3, 0.1, 0.9, 0.95)
+    alone.run()
+    assert torch.equal(alone.tables(0)[0], job.tables(2)[0]) and torch.equal(alone.tables(0)[1], job.tables(2)[1])
+    alone.close()
+    for s in range(S):
+        st = O.MFState(inits[s][0].numpy().copy(), inits[s][1].numpy().copy())
+        loss = O.train_epoch(st, parts[s], perms[s][0].numpy(), B, 1e-3, 0.1, 0.9)[0]
+        U, V = job.tables(s)
+        assert rel(U, st.U) < 1e-5 and rel(V, st.V) < 1e-5, s
+        np.testing.assert_allclose(np.sqrt(job.epoch_sse(s)[0] / len(parts[s][0])), loss, rtol=1e-5)
+    job.close()
+
+
+# ------------------------------------------------------------------------------------ OT at BASELINE sizes
+def ot_embedding(n, d, seed):
+    rs = np.random.RandomState(seed)
+    centers = rs.standard_normal((12, d)) * 0.8
+    which = rs.randint(0, 12, n)
+    X = centers[which] + rs.standard_normal((n, d)) * 0.6
+    return X.astype(np.float32)
+
+
+@pytest.fixture(scope='module')
+def ot_ml1m():
+    g = np.load(os.path.join(G, 'ot_ml1m.npz'))
+    X = ot_embedding(int(g['n']), int(g['d']), int(g['seed']))
+    assert float(X.astype(np.float64).sum()) == float(g['X_sum'])
+    return g, X
+
+
+@pytest.mark.parametrize('k', [5, 8])
+def test_ot_cluster_at_ml1m_size_matches_reference(ot_ml1m, k):
+    """method/utils.py::ot_cluster (HIP cost + centroid kernels, exact host LP) on the reference's own call
+    sequence (config.py:47-49 draws first): final labels and inertia bit-equal to the reference's run."""
+    from ultrare_amd.method.utils import ot_cluster
+    g, X = ot_ml1m
+    n = len(X)
+    np.random.seed(0)
+    np.random.choice(n, int(2 / 100 * n), replace=False)
+    inertia, label = ot_cluster(X, k)
+    assert np.array_equal(label, g[f'k{k}_label'])
+    assert float(inertia) == float(g[f'k{k}_inertia'])
+    assert np.bincount(label).tolist() == [n // k] * k
+
+
+def test_ot_rounds_k16_fractional_case(ot_ml1m):
+    """k = 16 does not divide 6040: every round up to 15 points are split exactly half / half and the
+    reference's float LP resolves those by rounding noise, so rounds are checked one by one from the
+    reference's centroids: device cost matrix bit-equal, labels equal except at the recorded split points
+    (where the label is one of the two clusters), device centroids of the reference's labels bit-equal."""
+    from ultrare_amd import _native as nv
+    g, X = ot_ml1m
+    k, n, d = 16, len(X), X.shape[1]
+    L, st = nv.lib(), nv.stream_handle()
+    Xd = torch.from_numpy(X).cuda()
+    dist_d = torch.empty(k, n, dtype=torch.float32, device='cuda')
+    cent_d = torch.empty(k, d, dtype=torch.float32, device='cuda')
+    counts_d = torch.empty(k, dtype=torch.int32, device='cuda')
+    cents, labels, splits = g['k16_round_centroids'], g['k16_round_labels'].astype(np.int64), g['k16_splits']
+    for r in range(int(g['k16_rounds'])):
+        cd = torch.from_numpy(cents[r]).cuda()
+        nv.check(L.ure_ot_cost(nv.ptr(Xd), nv.ptr(cd), n, k, d, nv.ptr(dist_d), st), 'ure_ot_cost')
+        dist = dist_d.cpu().numpy()
+        assert np.array_equal(dist, O.ot_cost(X, cents[r]))
+        assert float(dist.astype(np.float64).sum()) == float(g['k16_round_dist_sum'][r])
+        label, plan, _ = nv.ot_assign(dist)
+        tied = {int(row[1]): (int(row[2]), int(row[3])) for row in splits[splits[:, 0] == r]}
+        for i in np.flatnonzero(label != labels[r]):
+            assert int(i) in tied and label[i] in tied[int(i)], (r, int(i))
+        if r + 1 < len(cents):
+            lab_d = torch.from_numpy(labels[r].astype(np.int32)).cuda()
+            nv.check(L.ure_ot_centroids(nv.ptr(Xd), nv.ptr(lab_d), n, k, d, nv.ptr(cent_d), nv.ptr(counts_d), st), 'ure_ot_centroids')
+            assert np.array_equal(cent_d.cpu().numpy(), cents[r + 1])

@@ -1,0 +1,165 @@
+"""Touch mode of the step kernel (csrc/mf_touch.h): a step visits only the rows it trains; the rows in
+between are advanced by the optimizer's closed form when they are next trained.  Same results as the
+reference's dense optimizer (scratch.py:64-69) within the 1e-4 bar of BASELINE.json -- checked against
+the C oracle, against the default kernel, across epoch and StepLR boundaries, with snapshots, and at
+configs[3] shard size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+TRAIN = os.path.join(G, 'toy', '0_train.csv')
+N_USER, N_ITEM = 1508, 2071
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def _setup(S, k, B, E, seed=42):
+    from ultrare_amd import engine, rng
+    raw = O.load_csv(TRAIN)
+    parts = O.partition(*raw, O.uniform_groups(N_USER, S))
+    torch.manual_seed(seed)
+    inits = [rng.mf_init(N_USER, N_ITEM, k) for _ in parts]
+    perms = [rng.epoch_perms(rng.epoch_seeds(E, True), len(p[0])) for p in parts]
+    shards = [engine.ShardData(*p, N_USER, N_ITEM) for p in parts]
+    return parts, inits, perms, shards
+
+
+@pytest.mark.parametrize('S,k,B,E', [(1, 16, 3000, 3), (3, 32, 700, 5), (2, 64, 1500, 53), (2, 128, 500, 2), (3, 8, 450, 2)])
+def test_touch_mode_vs_oracle(S, k, B, E):
+    """Shards side by side in touch mode against the C oracle's dense optimizer: users with few ratings and
+    most items are trained in a fraction of the steps only (B = 450: 21 steps per epoch), so nearly every
+    update is followed by a closed-form advance; E = 53 crosses the StepLR boundary at epoch 50."""
+    from ultrare_amd import engine
+    parts, inits, perms, shards = _setup(S, k, B, E)
+    job = engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=True)
+    assert job.touch
+    job.run()
+    for s, p in enumerate(parts):
+        st = O.MFState(inits[s][0].numpy().copy(), inits[s][1].numpy().copy())
+        losses = [O.train_epoch(st, p, perms[s][t].numpy(), B, 1e-3 * 0.95 ** (t // 50), 0.1, 0.9)[0] for t in range(E)]
+        U, V = job.tables(s)
+        assert rel(U, st.U) < 2e-5 and rel(V, st.V) < 2e-5, (s, rel(U, st.U), rel(V, st.V))
+        np.testing.assert_allclose(np.sqrt(job.epoch_sse(s) / len(p[0])), losses, rtol=2e-5)
+    job.close()
+
+
+def test_touch_mode_vs_default_kernel_epoch_by_epoch():
+    """The same job in both modes, tables read at every epoch boundary (materialize + continue): the two
+    kernels stay within float32 rounding of each other; rows trained in every step differ least."""
+    from ultrare_amd import engine
+    k, B, E = 32, 1200, 4
+    parts, inits, perms, shards = _setup(1, k, B, E, seed=3)
+    jobs = [engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=t) for t in (False, True)]
+    assert [j.touch for j in jobs] == [False, True]
+    for e in range(E):
+        for j in jobs:
+            j.run_epochs(1)
+        (U0, V0), (U1, V1) = jobs[0].tables(0), jobs[1].tables(0)
+        assert rel(U1, U0) < 5e-6 and rel(V1, V0) < 5e-6, e
+    for j in jobs:
+        j.close()
+
+
+def test_touch_mode_reads_only_at_epoch_boundaries():
+    from ultrare_amd import _native as nv
+    from ultrare_amd import engine
+    parts, inits, perms, shards = _setup(1, 16, 3000, 2)
+    job = engine.TrainJob(shards, inits, perms, 16, 3000, 2, 1e-3, 0.1, 0.9, 0.95, touch=True)
+    job.run(3)                                   # 10 steps per epoch: inside epoch 0
+    with pytest.raises(nv.NativeError, match='epoch boundaries'):
+        job.tables(0)
+    job.run(7)
+    job.tables(0)                                # the boundary: fine, and training goes on from it
+    job.run()
+    job.tables(0)
+    job.close()
+
+
+def test_touch_mode_snapshots_equal_tables_at_epoch_ends():
+    from ultrare_amd import engine
+    k, B, E = 16, 2000, 3
+    parts, inits, perms, shards = _setup(2, k, B, E, seed=8)
+    job = engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=True, snapshots=True)
+    job.run()
+    # the two shards have different step counts, so their epoch boundaries fall on different ticks: the last
+    # snapshot of each equals its final tables ...
+    for s in range(2):
+        snapU, snapV = job.snapshots_of(s)
+        U, V = job.padded_tables(s)
+        assert torch.equal(snapU[E - 1], U) and torch.equal(snapV[E - 1], V)
+    # ... and every snapshot equals the tables of the same shard trained alone, read epoch by epoch
+    for s in range(2):
+        one = engine.TrainJob([shards[s]], [inits[s]], [perms[s]], k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=True)
+        for e in range(E):
+            one.run_epochs(1)
+            U, V = one.padded_tables(0)
+            assert torch.equal(job.snapshots_of(s)[0][e], U) and torch.equal(job.snapshots_of(s)[1][e], V), (s, e)
+        one.close()
+    job.close()
+
+
+def test_touch_mode_is_bitwise_reproducible():
+    from ultrare_amd import engine
+    out = []
+    for _ in range(2):
+        parts, inits, perms, shards = _setup(2, 32, 900, 3, seed=1)
+        job = engine.TrainJob(shards, inits, perms, 32, 900, 3, 1e-3, 0.1, 0.9, 0.95, touch=True)
+        job.run()
+        out.append([tuple(t.clone() for t in job.tables(s)) for s in range(2)])
+        job.close()
+    for s in range(2):
+        assert torch.equal(out[0][s][0], out[1][s][0]) and torch.equal(out[0][s][1], out[1][s][1])
+
+
+def test_touch_mode_refusals():
+    """More than 64 steps per epoch, or without lazy rows: the engine falls back to the default kernel; the C ABI
+    refuses a descriptor that asks for touch mode there."""
+    from ultrare_amd import engine
+    parts, inits, perms, shards = _setup(1, 16, 300, 1)           # 95 steps per epoch
+    job = engine.TrainJob(shards, inits, perms, 16, 300, 1, 1e-3, 0.1, 0.9, 0.95, touch=True)
+    assert not job.touch
+    job.run()
+    job.close()
+    job = engine.TrainJob(shards, inits, perms, 16, 300, 1, 1e-3, 0.1, 0.9, 0.95, touch=True, lazy_rows=False)
+    assert not job.touch
+    job.close()
+
+
+def test_touch_mode_d128_shards_at_configs3_size_vs_oracle():
+    """configs[3] per-shard size (5,063 users x 60,000 items, ~703 k ratings, d = 128, 24 steps per epoch): two
+    shards side by side in touch mode -- the mode bench.py's ml25m workload selects by itself -- against the C
+    oracle after two epochs (the second starts from rows in both buffers)."""
+    from ultrare_amd import engine, rng, synth
+    n_user, n_item, k, B, S, E = 162000, 60000, 128, 30000, 2, 2
+    parts = []
+    for s in range(S):
+        d = synth.make_dataset(5063, n_item, 703125, 78125, seed=31 + s)
+        ids = np.sort(np.random.RandomState(60 + s).choice(n_user, 5063, replace=False))
+        u, i, r = d['train']
+        parts.append((ids[u].astype(np.int32), i.astype(np.int32), (r / 5).astype(np.float32)))
+    torch.manual_seed(42)
+    inits, perms = [], []
+    for p in parts:
+        inits.append(rng.mf_init(n_user, n_item, k))
+        perms.append(rng.epoch_perms(rng.epoch_seeds(E, True), len(p[0])))
+    shards = [engine.ShardData(*p, n_user, n_item) for p in parts]
+    job = engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=True)
+    assert job.touch
+    job.run()
+    for s in range(S):
+        st = O.MFState(inits[s][0].numpy().copy(), inits[s][1].numpy().copy())
+        losses = [O.train_epoch(st, parts[s], perms[s][t].numpy(), B, 1e-3, 0.1, 0.9)[0] for t in range(E)]
+        U, V = job.tables(s)
+        assert rel(U, st.U) < 2e-5 and rel(V, st.V) < 2e-5, s
+        np.testing.assert_allclose(np.sqrt(job.epoch_sse(s) / len(parts[s][0])), losses, rtol=2e-5)
+    job.close()

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libultrare_hip.so')
+LIB_PATH = os.environ.get('URE_LIB') or os.path.join(_PKG, 'libultrare_hip.so')      # URE_LIB: experiment builds (tools/) only
 ABI_VERSION = 3
 MAX_MODELS_PER_CALL = 32
 
@@ -31,6 +31,7 @@ class UreShard(ctypes.Structure):
         ('N', _i32), ('n_user', _i32), ('n_item', _i32), ('d', _i32),
         ('batch', _i32), ('epochs', _i32),
         ('lam', ctypes.c_float), ('mu', ctypes.c_float),
+        ('touch_mode', _i32), ('n_multi', _i32),
     ]
 
 

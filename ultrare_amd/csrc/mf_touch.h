@@ -1,0 +1,455 @@
+// mf_touch.h -- "touch mode" of the step kernel: the HBM-bound regime (BASELINE.json configs[3]:
+// 32 shards x 113.7 MB of tables per GPU), where most rows of a shard have NO interaction in a given
+// optimizer step and the dense optimizer of the reference (scratch.py:64-69: weight decay + momentum
+// touch every row every step) would stream them through HBM just to let them decay.
+//
+// Between two gradient events a row's (w, m) evolves by the optimizer's own linear recurrence
+//     m' = mu m + lam w ;  w' = w - lr m'      <=>   (w, m)' = A (w, m),  A = [[1 - lr lam, -lr mu], [lam, mu]]
+// so j steps without a gradient are one 2x2 map A^j (evaluated in double on the host, one table per
+// epoch's learning rate: StepLR changes it between epochs only).  Touch mode keeps every row in
+// NEXT-TOUCH FORM: the stored (w, m) are valid for the step at which the row has its next interaction
+// (or the end of the epoch).  Then
+//   * a step visits only the rows it trains: a 64-bit mask per row and epoch says in which steps of
+//     the epoch the row has interactions (steps per epoch <= 64 -- 24..27 at configs[3]);
+//   * whoever gathers a row reads w only, with no time stamp and no catching up: a row is gathered in
+//     exactly the steps in which it is trained itself (interaction (u, i) of step s makes u gather i
+//     and i gather u in step s), and for those steps its stored w is current by construction;
+//   * after its update the owner advances the row by the table entry of the gap to its next step.
+// A row's w alternates between the two table buffers with each of its OWN steps (its k-th step of the
+// epoch reads buffer k & 1 and writes the other).  Which buffer a GATHERED row is in at step s -- the
+// parity of its steps before s -- is put into bit 15 of the slot's batch tag once per epoch, so a gather
+// costs no extra memory level.
+//
+// Work: rows longer than one scan pass (8 * LPR slots) keep the work units of mf_step (ure_host_build_units
+// over the first n_multi rows of the schedule).  The others -- most item rows, the light users; 96 % of the
+// rows, trained in 13..60 % of the steps -- are CANDIDATES: a workgroup looks at 256 of them with one lane
+// each (mask in schedule order, coalesced), compacts the rows trained in this step into LDS, and its
+// lane groups work the compacted list off.  (One lane group per row with an early exit was measured first:
+// 125 k workgroups per launch whose fixed cost -- two dependent loads and an exit -- set the launch time,
+// 0.94 ms against 1.03 ms for the dense kernel; profiles/r02/NOTES.md.)
+//
+// At an epoch start three launches (A) clear the epoch's mask buffer, (B) build the row masks from the
+// epoch's batch tags, (C) copy them into work order, put the buffer bits into the tags, and bring every
+// row from "valid at the epoch boundary" to "valid at its first step", into buffer 0.
+//
+// Included by mf_train.hip after its constants (kQueue, kSegPerLane, lanes_per_row) and helpers.
+#pragma once
+#include "tag_prep.h"
+
+namespace ure {
+
+constexpr int kTouchMaxSteps = 64;          // steps per epoch a 64-bit row mask can describe
+constexpr int kTouchTab = kTouchMaxSteps + 1;
+constexpr unsigned kTagStep = 0x7FFFu;      // touch mode: bits 0..14 of a tag = the step, bit 15 = buffer of the gathered row
+
+__device__ __forceinline__ unsigned long long mask_below(int s) { return s >= 64 ? ~0ull : ((1ull << s) - 1ull); }
+__device__ __forceinline__ int mask_rank_parity(unsigned long long mk, int s) { return __popcll(mk & mask_below(s)) & 1; }
+
+// (w, m) <- P (w, m), P = {p11, p12, p21, p22}
+template <int V4>
+__device__ __forceinline__ void row_advance(RowVec<V4> &w, RowVec<V4> &m, const float4 P)
+{
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        float4 a = w.q[i], b = m.q[i], nw, nm;
+        nw.x = fmaf(P.x, a.x, __fmul_rn(P.y, b.x)); nw.y = fmaf(P.x, a.y, __fmul_rn(P.y, b.y));
+        nw.z = fmaf(P.x, a.z, __fmul_rn(P.y, b.z)); nw.w = fmaf(P.x, a.w, __fmul_rn(P.y, b.w));
+        nm.x = fmaf(P.z, a.x, __fmul_rn(P.w, b.x)); nm.y = fmaf(P.z, a.y, __fmul_rn(P.w, b.y));
+        nm.z = fmaf(P.z, a.z, __fmul_rn(P.w, b.z)); nm.w = fmaf(P.z, a.w, __fmul_rn(P.w, b.w));
+        w.q[i] = nw;
+        m.q[i] = nm;
+    }
+}
+
+// Workgroups of a shard's row-structured passes (mask building, tag bits): [0, nbU) take the work units of
+// the multi-pass rows, [nbU, nbU + nbG) take 256 / LPR single-pass rows each, one lane group per row.
+// -> the lane group's piece {row id or -1, first slot, end slot, unit index or -1}; *sched_idx = the row's
+// place among the single-pass rows (or -1).
+template <int LPR>
+__device__ __forceinline__ int4 touch_piece(const ure_shard_t &S, int wg, int *sched_idx)
+{
+    constexpr int UPB = kBlock / LPR;
+    const int nbU = S.n_units / UPB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int local = wave * (kWave / LPR) + lane / LPR;
+    *sched_idx = -1;
+    if (wg < nbU) {
+        const int4 du = ldg_i4(S.units + 4 * ((size_t)wg * UPB + local));
+        return make_int4(du.x, du.y, du.z, wg * UPB + local);
+    }
+    const int rel = (wg - nbU) * UPB + local;
+    if (rel >= S.n_active - S.n_multi) return make_int4(-1, 0, 0, -1);
+    *sched_idx = rel;
+    const int4 sc = ldg_i4(S.sched + 4 * (size_t)(S.n_multi + rel));
+    return make_int4(sc.x, sc.y, sc.z, -1);
+}
+template <int LPR>
+__host__ __device__ inline int touch_piece_blocks(int n_units, int n_active, int n_multi)
+{
+    constexpr int UPB = kBlock / LPR;
+    return n_units / UPB + (n_active - n_multi + UPB - 1) / UPB;
+}
+
+// ---- epoch start, launch B: the step mask of every row from the epoch's (fresh) batch tags -------------
+template <int LPR>
+__device__ __forceinline__ void touch_build_masks(const ure_shard_t &S, const shard_aux &A, int epoch, int wg)
+{
+    constexpr int CAP = kSegPerLane * LPR;
+    int si;
+    const int4 pc = touch_piece<LPR>(S, wg, &si);
+    if (pc.x < 0) return;
+    const int sub = threadIdx.x & (LPR - 1);
+    const uint16_t *__restrict__ ent_tag = S.ent_tag + (size_t)(epoch & 1) * S.n_slots;
+    unsigned long long mk = 0;
+    for (int p0 = pc.y + sub * kSegPerLane; p0 < pc.z; p0 += CAP) {
+        const uint4 t4 = ldg_u4(ent_tag + p0);
+        const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned tg = (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            if (tg < (unsigned)kTouchMaxSteps) mk |= 1ull << tg;
+        }
+    }
+    if (mk) atomicOr(A.mask[epoch & 1] + pc.x, mk);
+}
+
+// ---- epoch start, launch C, part 1: bit 15 of every slot's tag = the buffer the slot's OTHER row is in at the
+// slot's step (parity of that row's steps before it), and the masks copied into work order
+template <int LPR>
+__device__ __forceinline__ void touch_mark_tags(const ure_shard_t &S, const shard_aux &A, int epoch, int wg)
+{
+    constexpr int CAP = kSegPerLane * LPR;
+    int si;
+    const int4 pc = touch_piece<LPR>(S, wg, &si);
+    if (pc.x < 0) return;
+    const int sub = threadIdx.x & (LPR - 1);
+    const unsigned long long *__restrict__ masks = A.mask[epoch & 1];
+    if (sub == 0) {
+        const unsigned long long mine = ldg(masks + pc.x);
+        if (pc.w >= 0) stg(A.unit_mask + pc.w, mine);            // work unit -> its row's mask
+        else stg(A.sched_mask + si, mine);                       // single-pass row, in schedule order
+    }
+    uint16_t *__restrict__ ent_tag = S.ent_tag + (size_t)(epoch & 1) * S.n_slots;
+    const int other_base = pc.x < S.n_user ? S.n_user : 0;
+    for (int p0 = pc.y + sub * kSegPerLane; p0 < pc.z; p0 += CAP) {
+        const uint4 t4 = ldg_u4(ent_tag + p0);
+        const int4 o0 = ldg_i4(S.ent_oid + p0), o1 = ldg_i4(S.ent_oid + p0 + 4);
+        const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+        const int ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+        unsigned out[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned tg = (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            out[k] = tg;
+            if (tg < (unsigned)kTouchMaxSteps) out[k] = tg | ((unsigned)mask_rank_parity(ldg(masks + other_base + ov[k]), (int)tg) << 15);
+        }
+        stg_u4(ent_tag + p0, make_uint4(out[0] | (out[1] << 16), out[2] | (out[3] << 16), out[4] | (out[5] << 16), out[6] | (out[7] << 16)));
+    }
+}
+
+// ---- epoch start, launch C, part 2: every active row from "valid at the epoch boundary" (buffer = parity of
+// its number of steps in the epoch that ended) to "valid at its first step of this epoch", in buffer 0.
+// One lane per float4 of a row.
+__device__ __forceinline__ void touch_advance_rows(const ure_shard_t &S, const shard_aux &A, int epoch, int blk, int n_blk)
+{
+    const int d4 = S.d / 4;
+    const int64_t total = (int64_t)S.n_active * d4;
+    const unsigned long long *__restrict__ m_new = A.mask[epoch & 1];
+    const unsigned long long *__restrict__ m_old = A.mask[(epoch & 1) ^ 1];
+    const float4 *__restrict__ tab = A.ptab + (size_t)epoch * kTouchTab;
+    for (int64_t t = (int64_t)blk * kBlock + threadIdx.x; t < total; t += (int64_t)n_blk * kBlock) {
+        const int idx = (int)(t / d4), c4 = (int)(t % d4);
+        const int row_id = ldg(S.sched + 4 * (size_t)idx);
+        const unsigned long long mo = ldg(m_old + row_id), mn = ldg(m_new + row_id);
+        const int from = __popcll(mo) & 1;
+        const int j = mn ? __ffsll((long long)mn) - 1 : A.steps;          // steps that pass before the row's first own step
+        const bool is_user = row_id < S.n_user;
+        const size_t o = (size_t)(is_user ? row_id : row_id - S.n_user) * S.d + (size_t)c4 * 4;
+        float *wsrc = (is_user ? S.U[from] : S.V[from]) + o, *wdst = (is_user ? S.U[0] : S.V[0]) + o;
+        float *mom = (is_user ? S.mU : S.mV) + o;
+        if (from != 0 || j != 0) {
+            RowVec<1> w, m;
+            w.q[0] = ldg_f4(wsrc);
+            m.q[0] = ldg_f4(mom);
+            if (j != 0) row_advance<1>(w, m, tab[j]);
+            stg_f4(wdst, w.q[0]);
+            if (j != 0) stg_f4(mom, m.q[0]);
+        }
+    }
+}
+
+// epoch start, launch A: the mask buffer of this epoch's parity still holds the masks of two epochs ago
+__device__ __forceinline__ void touch_clear_masks(const ure_shard_t &S, const shard_aux &A, int epoch, int blk, int n_blk)
+{
+    unsigned long long *__restrict__ mk = A.mask[epoch & 1];
+    const int n_rows = S.n_user + S.n_item;
+    for (int r = blk * kBlock + threadIdx.x; r < n_rows; r += n_blk * kBlock) stg(mk + r, 0ull);
+}
+
+// ---- one row (or one work unit of a multi-pass row) of a step in touch mode: the scan, compaction and gather
+// loop of mf_step (mf_train.hip); what differs is marked [touch].  du = {row id, first slot, end slot, leader |
+// count << 16 | multi << 30}, mk = the row's step mask, hit = the row is trained in step s (lane-group uniform).
+template <int LPR, int V4>
+__device__ __forceinline__ void touch_process(const ure_shard_t &S, const shard_aux &A, const int4 du, const unsigned long long mk, const bool hit,
+                                              const int local, const int epoch, const int s, const int steps, const float lr, int *qo, float *qr,
+                                              float (*q_r)[kQueue], float4 (*part_acc)[V4][LPR])
+{
+    constexpr int D = LPR * V4 * 4;
+    using Row = RowVec<V4>;
+    constexpr int G = kWave / LPR;
+    constexpr int CAP = kSegPerLane * LPR;
+    constexpr int kGB = LPR <= 8 ? URE_KGB_NARROW : URE_KGB_WIDE;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (LPR - 1), grp = lane / LPR;
+    const float lam = S.lam, mu = S.mu;
+    const int32_t *__restrict__ ent_oid = S.ent_oid;
+    const float *__restrict__ ent_r = S.ent_r;
+    const uint16_t *__restrict__ ent_tag = S.ent_tag + (size_t)(epoch & 1) * S.n_slots;
+    const int leader = du.w & 0xFFFF, count = (du.w >> 16) & 0x3FFF;
+    const bool multi = (du.w >> 30) & 1;
+    const bool owner = hit && local == leader;
+    const bool is_user = du.x < S.n_user;
+    const int row = is_user ? du.x : du.x - S.n_user;
+    const size_t row_off = (size_t)(hit ? row : 0) * D;
+    // [touch] the row's k-th step of the epoch reads buffer k & 1 (next-touch form: w is valid for THIS step)
+    const int buf = mask_rank_parity(mk, s);
+    Row w = row_zero<V4>(), acc = w, m4 = w;
+    float *mom = (is_user ? S.mU : S.mV) + row_off;
+    if (hit) w = row_load<LPR, V4>((is_user ? S.U[buf] : S.V[buf]) + row_off, sub);
+    if (owner) m4 = row_load<LPR, V4>(mom, sub);       // requested with the row: no memory level of its own at the end
+    float sse = 0.f;
+    float *const *other_tab = is_user ? S.V : S.U;
+    const float *__restrict__ other0 = other_tab[0];
+    const float *__restrict__ other1 = other_tab[1];
+    int *gq = qo + grp * CAP;
+    float *gr = qr + grp * CAP;
+    const int beg = du.y, end = hit ? du.z : du.y;
+    for (int seg = beg;; seg += CAP) {
+        if (!__any(seg < end)) break;
+        const int p0 = seg + sub * kSegPerLane;
+        const bool valid = p0 < end;
+        uint4 t4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        int4 o0 = make_int4(0, 0, 0, 0), o1 = o0;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        if (valid) {
+            t4 = ldg_u4(ent_tag + p0);
+            o0 = ldg_i4(ent_oid + p0);
+            o1 = ldg_i4(ent_oid + p0 + 4);
+            r0 = ldg_f4(ent_r + p0);
+            r1 = ldg_f4(ent_r + p0 + 4);
+        }
+        const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+        int ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+        const float rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        unsigned mb = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned tg = (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            mb |= ((tg & kTagStep) == (unsigned)s ? 1u : 0u) << k;
+            ov[k] |= (int)((tg >> 15) << 31);            // [touch] the gathered row's buffer rides in the id's top bit
+        }
+        const int c = __popc(mb);
+        const int inc = group_scan<LPR>(c, sub);
+        const int qn = (int)group_sum<LPR>((float)c);
+        int mpos = inc - c, upos = qn + sub * kSegPerLane - mpos;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool h = (mb >> k) & 1u;
+            const int pos = ((h ? mpos : upos) + grp) & (CAP - 1);
+            gq[pos] = ov[k];
+            gr[pos] = rv[k];
+            mpos += h ? 1 : 0;
+            upos += h ? 0 : 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int t0 = 0; __any(t0 < qn); t0 += kGB) {
+            int o[kGB];
+            float r[kGB];
+            bool act[kGB];
+            Row v[kGB];
+#pragma unroll
+            for (int k = 0; k < kGB; ++k) {
+                const int qi = (min(t0 + k, CAP - 1) + grp) & (CAP - 1);
+                act[k] = t0 + k < qn;
+                o[k] = act[k] ? gq[qi] : 0;
+                r[k] = gr[qi];
+            }
+#pragma unroll
+            for (int k = 0; k < kGB; ++k)
+                v[k] = row_load<LPR, V4>((o[k] < 0 ? other1 : other0) + (size_t)(o[k] & 0x7FFFFFFF) * D, sub);
+#pragma unroll
+            for (int k = 0; k < kGB; ++k) {
+                const float p = group_sum<LPR>(row_dot<V4>(w, v[k]));
+                const float e = p - r[k];
+                const float ge = act[k] ? 2.0f * e : 0.0f;
+                if (act[k]) sse = fmaf(e, e, sse);
+                row_axpy<V4>(acc, ge, v[k]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (multi) {
+        if (hit && count > 1) {
+#pragma unroll
+            for (int i = 0; i < V4; ++i) part_acc[local][i][sub] = acc.q[i];
+            if (sub == 0) qr[grp * CAP] = sse;
+        }
+        __syncthreads();
+        if (owner && count > 1) {
+#pragma unroll
+            for (int i = 0; i < V4; ++i) {
+                float4 a4 = part_acc[leader][i][sub];
+                for (int k = 1; k < count; ++k) {
+                    const float4 t = part_acc[leader + k][i][sub];
+                    a4.x += t.x; a4.y += t.y; a4.z += t.z; a4.w += t.w;
+                }
+                acc.q[i] = a4;
+            }
+            sse = 0.f;
+            for (int k = 0; k < count; ++k) sse += q_r[(leader + k) / G][((leader + k) % G) * CAP];
+        }
+    }
+    if (owner) {
+        Row gr2, nr;
+#pragma unroll
+        for (int i = 0; i < V4; ++i) {                   // torch.optim.SGD: g += lam w ; buf = mu buf + g ; w -= lr buf
+            const float4 ww = w.q[i], mm = m4.q[i], aa = acc.q[i];
+            float4 g, wn;
+            g.x = fmaf(lam, ww.x, aa.x); g.y = fmaf(lam, ww.y, aa.y); g.z = fmaf(lam, ww.z, aa.z); g.w = fmaf(lam, ww.w, aa.w);
+            g.x = __fadd_rn(__fmul_rn(mu, mm.x), g.x); g.y = __fadd_rn(__fmul_rn(mu, mm.y), g.y);
+            g.z = __fadd_rn(__fmul_rn(mu, mm.z), g.z); g.w = __fadd_rn(__fmul_rn(mu, mm.w), g.w);
+            wn.x = fmaf(-lr, g.x, ww.x); wn.y = fmaf(-lr, g.y, ww.y); wn.z = fmaf(-lr, g.z, ww.z); wn.w = fmaf(-lr, g.w, ww.w);
+            gr2.q[i] = g;
+            nr.q[i] = wn;
+        }
+        // [touch] bring the row to its next own step of the epoch (or to the epoch's end): the steps in between
+        // apply weight decay and momentum only, one 2x2 map for all of them
+        const unsigned long long rest = s + 1 < 64 ? mk >> (s + 1) : 0ull;
+        const int gap = rest ? __ffsll((long long)rest) - 1 : steps - 1 - s;
+        if (gap > 0) row_advance<V4>(nr, gr2, A.ptab[(size_t)epoch * kTouchTab + gap]);
+        row_store<LPR, V4>(mom, sub, gr2);
+        row_store<LPR, V4>((is_user ? S.U[buf ^ 1] : S.V[buf ^ 1]) + row_off, sub, nr);
+        if (is_user && sub == 0 && sse != 0.f) {
+            float *slot = S.sse + (size_t)epoch * S.n_user + row;
+            stg(slot, ldg(slot) + sse);
+        }
+    }
+}
+
+// ---- one optimizer step in touch mode.  Workgroups of a shard: [0, nbU) work units of the multi-pass rows |
+// [nbU, nbU + nbC) candidates, 256 single-pass rows each | the tag riders of the next epoch.
+template <int LPR, int V4>
+__device__ __forceinline__ void mf_touch_step(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, int shard_fast)
+{
+    constexpr int G = kWave / LPR;
+    constexpr int UPB = kBlock / LPR;
+    constexpr int kQueueBytes = kWavesPerBlock * kQueue * 8;
+    static_assert(kTagLds <= kQueueBytes, "tag phases must fit in the queue space");
+    __shared__ __attribute__((aligned(16))) char lds_raw[kQueueBytes];
+    __shared__ float4 part_acc[UPB][V4][LPR];
+    __shared__ int4 cand_row[kBlock];                   // the candidates trained in this step: {row id, first slot, end slot, -}
+    __shared__ unsigned long long cand_mask[kBlock];
+    __shared__ int cand_count[kWavesPerBlock];
+    int (*q_oid)[kQueue] = reinterpret_cast<int (*)[kQueue]>(lds_raw);
+    float (*q_r)[kQueue] = reinterpret_cast<float (*)[kQueue]>(lds_raw + kWavesPerBlock * kQueue * 4);
+
+    int shard_idx = (int)(shard_fast ? blockIdx.x : blockIdx.y);
+    int wg = (int)(shard_fast ? blockIdx.y : blockIdx.x);
+    if (shard_fast >> 1) {        // sliced mapping, see mf_step
+        const unsigned n_sh = (unsigned)shard_fast >> 8;
+        const unsigned x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        const unsigned jq = j / n_sh, jr = j - jq * n_sh;
+        const unsigned slice = n_sh * x + jr;
+        shard_idx = (int)(slice >> 3);
+        wg = (int)(jq * 8 + (slice & 7u));
+    }
+    const ure_shard_t &S = shards[shard_idx];
+    const shard_aux &A = aux[shard_idx];
+    const int steps = A.steps;
+    if (tick >= (int64_t)steps * S.epochs) return;
+    const int epoch = (int)epoch_of(A, tick);
+    const int s = (int)(tick - (int64_t)epoch * steps);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane / LPR;
+    const float lr = ldg(S.lr + epoch);
+    int *qo = q_oid[wave];
+    float *qr = q_r[wave];
+    const int local = wave * G + grp;
+
+    const int nbU = S.n_units / UPB;
+    const int n_single = S.n_active - S.n_multi;
+    const int nbC = (n_single + kBlock - 1) / kBlock;
+    if (wg < nbU) {
+        // ---- multi-pass rows: the unit's mask sits next to its descriptor (no dependent load)
+        const size_t u = (size_t)wg * UPB + local;
+        const int4 du = ldg_i4(S.units + 4 * u);
+        const unsigned long long mk = ldg(A.unit_mask + u);
+        const bool hit = du.x >= 0 && ((mk >> s) & 1ull);
+        const bool multi = (du.w >> 30) & 1;
+        if (!multi && !__any(hit)) return;
+        touch_process<LPR, V4>(S, A, du, mk, hit, local, epoch, s, steps, lr, qo, qr, q_r, part_acc);
+        return;
+    }
+    if (wg < nbU + nbC) {
+        // ---- candidates: one lane per row finds out whether the row is trained in this step ...
+        const int rel = (wg - nbU) * kBlock + (int)threadIdx.x;
+        const unsigned long long mk = rel < n_single ? ldg(A.sched_mask + rel) : 0ull;
+        const bool hit = (mk >> s) & 1ull;
+        const unsigned long long vote = __ballot(hit);
+        if (lane == 0) cand_count[wave] = __popcll(vote);
+        int4 sc = make_int4(-1, 0, 0, 0);
+        if (hit) sc = ldg_i4(S.sched + 4 * (size_t)(S.n_multi + rel));
+        __syncthreads();
+        int base = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < kWavesPerBlock; ++k) {
+            const int c = cand_count[k];
+            base += k < wave ? c : 0;
+            total += c;
+        }
+        if (hit) {
+            const int pos = base + __popcll(vote & ((1ull << lane) - 1ull));
+            cand_row[pos] = sc;
+            cand_mask[pos] = mk;
+        }
+        __syncthreads();
+        // ... and the lane groups work the compacted list off, one row each per round
+        for (int e0 = wave * G; e0 < total; e0 += UPB) {      // wave-uniform bound: a wave's groups take e0 .. e0 + G - 1
+            const int e = e0 + grp;
+            const bool have = e < total;
+            int4 du = make_int4(-1, 0, 0, 0);
+            unsigned long long rm = 0ull;
+            if (have) { du = cand_row[e]; rm = cand_mask[e]; }
+            du.w = local | (1 << 16);                          // its own leader, one unit, no partial sums to combine
+            touch_process<LPR, V4>(S, A, du, rm, have, local, epoch, s, steps, lr, qo, qr, q_r, part_acc);
+        }
+        return;
+    }
+    // ---- the tag riders of the next epoch, as in mf_step
+    const TagRide ride = tag_ride(A, s, epoch + 1 < S.epochs);
+    const int rb = wg - nbU - nbC;
+    if (rb >= ride.count) return;
+    if (ride.phase == 0) tag_partition(S, epoch + 1, ride.first + rb, lds_raw);
+    else if (ride.phase == 1) tag_collect(S, ride.first + rb, lds_raw);
+    else tag_derive(S, epoch + 1, ride.first + rb, A.derive_blocks);
+}
+
+// ---- reading the tables at an epoch boundary of the shard: the active rows' current w sits in the buffer
+// given by the parity of their step count in the epoch that ended; copy it where the caller reads (`cur`)
+__device__ __forceinline__ void touch_collect_rows(const ure_shard_t &S, const shard_aux &A, int last_epoch, int cur, int blk, int n_blk)
+{
+    const int d4 = S.d / 4;
+    const int64_t total = (int64_t)S.n_active * d4;
+    const unsigned long long *__restrict__ mk = A.mask[last_epoch & 1];
+    for (int64_t t = (int64_t)blk * kBlock + threadIdx.x; t < total; t += (int64_t)n_blk * kBlock) {
+        const int idx = (int)(t / d4), c4 = (int)(t % d4);
+        const int row_id = ldg(S.sched + 4 * (size_t)idx);
+        const int from = last_epoch < 0 ? 0 : (__popcll(ldg(mk + row_id)) & 1);
+        if (from == cur) continue;
+        const bool is_user = row_id < S.n_user;
+        const size_t o = (size_t)(is_user ? row_id : row_id - S.n_user) * S.d + (size_t)c4 * 4;
+        stg_f4((is_user ? S.U[cur] : S.V[cur]) + o, ldg_f4((is_user ? S.U[from] : S.V[from]) + o));
+    }
+}
+
+}  // namespace ure

@@ -363,14 +363,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(V4 == 1 
 // End-of-epoch snapshot of a shard's tables into snapU/snapV[epoch] (optional; used to rebuild the
 // reference's per-epoch test logs after shards were trained side by side, scratch.py:83-97).
 // Rows the step kernel skips (lazy_rows) are written in closed form with the epoch's scalar.
-__global__ __launch_bounds__(kBlock) void snapshot_kernel(const ure_shard_t *__restrict__ shards, int64_t ticks_done)
+__global__ __launch_bounds__(kBlock) void snapshot_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t ticks_done)
 {
     const ure_shard_t &S = shards[blockIdx.y];
+    const unsigned long long *__restrict__ row_mask = nullptr;
     if (!S.snapU || !S.snapV) return;
     const int steps = shard_steps(S);
     if (ticks_done > (int64_t)steps * S.epochs || ticks_done % steps != 0) return;   // only at an epoch end of this shard
     const int epoch = (int)(ticks_done / steps) - 1;
     const int cur = (int)(ticks_done & 1);
+    if (S.touch_mode) row_mask = aux[blockIdx.y].mask[epoch & 1];      // touch mode: a row's w sits in the buffer of its step-count parity
     const float a = S.lazy_rows ? ldg(S.snap_a + epoch) : 0.f;
     const int d4 = S.d / 4;
     const int n_rows = S.n_user + S.n_item;
@@ -387,7 +389,8 @@ __global__ __launch_bounds__(kBlock) void snapshot_kernel(const ure_shard_t *__r
             const float4 w0 = ldg_f4((is_user ? S.U0 : S.V0) + o);
             v = make_float4(a * w0.x, a * w0.y, a * w0.z, a * w0.w);
         } else {
-            v = ldg_f4((is_user ? S.U[cur] : S.V[cur]) + o);
+            const int from = row_mask ? (__popcll(ldg(row_mask + row_id)) & 1) : cur;
+            v = ldg_f4((is_user ? S.U[from] : S.V[from]) + o);
         }
         stg_f4((is_user ? su : sv) + o, v);
     }
@@ -420,6 +423,72 @@ __global__ __launch_bounds__(kBlock) void materialize_rows_kernel(const ure_shar
     }
 }
 
+}  // namespace ure
+#include "mf_touch.h"
+namespace ure {
+
+template <int LPR, int V4>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void mf_touch_step_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, int shard_fast)
+{
+    mf_touch_step<LPR, V4>(shards, aux, tick, shard_fast);
+}
+
+// Epoch start of a shard in touch mode: phase 0 clears the epoch's mask buffer, 1 builds the row masks from
+// the batch tags, 2 advances every active row to its first step (mf_touch.h).  One launch per phase.
+__device__ __forceinline__ int touch_epoch_start(const ure_shard_t &S, const shard_aux &A, int64_t tick)
+{
+    if (tick >= (int64_t)A.steps * S.epochs || tick % A.steps != 0) return -1;
+    return (int)(tick / A.steps);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void touch_prep_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, int phase,
+                                                            int piece_blocks)
+{
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    const int epoch = touch_epoch_start(S, A, tick);
+    if (epoch < 0) return;
+    if (phase == 0) touch_clear_masks(S, A, epoch, (int)blockIdx.x, (int)gridDim.x);
+    else if (phase == 1) touch_build_masks<LPR>(S, A, epoch, (int)blockIdx.x);
+    else if ((int)blockIdx.x < piece_blocks) touch_mark_tags<LPR>(S, A, epoch, (int)blockIdx.x);
+    else touch_advance_rows(S, A, epoch, (int)blockIdx.x - piece_blocks, (int)gridDim.x - piece_blocks);
+}
+
+// Tables read at `ticks_done`: a shard must stand at one of its epoch boundaries (or have finished).
+__global__ __launch_bounds__(kBlock) void touch_collect_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t ticks_done)
+{
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    const int64_t T = min(ticks_done, (int64_t)A.steps * S.epochs);
+    if (T % A.steps != 0) return;                      // refused on the host (ure_job_materialize)
+    touch_collect_rows(S, A, (int)(T / A.steps) - 1, (int)(T & 1), (int)blockIdx.x, (int)gridDim.x);
+}
+
+static bool touch_prep_needed(const ure_job *job, int64_t tick)
+{
+    if (!job->touch) return false;
+    for (size_t k = 0; k < job->host.size(); ++k) {
+        const int64_t steps = job->aux_host[k].steps;
+        if (tick < steps * job->host[k].epochs && tick % steps == 0) return true;
+    }
+    return false;
+}
+
+// the three launches of an epoch start in touch mode (after the epoch's batch tags are complete)
+template <int LPR>
+static void launch_touch_prep(const ure_job *job, int64_t tick, hipStream_t st)
+{
+    const unsigned n_sh = (unsigned)job->host.size();
+    const unsigned rows_b = (unsigned)std::max<int64_t>(1, std::min<int64_t>((job->max_rows + kBlock - 1) / kBlock, 1024));
+    int pieces = 1;
+    for (const ure_shard_t &S : job->host) pieces = std::max(pieces, touch_piece_blocks<LPR>(S.n_units, S.n_active, S.n_multi));
+    const unsigned adv_b = (unsigned)std::max<int64_t>(1, std::min<int64_t>((job->max_active4 + kBlock - 1) / kBlock, 8192));
+    hipLaunchKernelGGL((touch_prep_kernel<LPR>), dim3(rows_b, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, 0, pieces);
+    hipLaunchKernelGGL((touch_prep_kernel<LPR>), dim3((unsigned)pieces, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, 1, pieces);
+    hipLaunchKernelGGL((touch_prep_kernel<LPR>), dim3((unsigned)pieces + adv_b, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, 2, pieces);
+}
+
 template <int LPR, int V4>
 static void launch_step(const ure_job *job, int64_t tick, hipStream_t st)
 {
@@ -439,6 +508,10 @@ static void launch_step(const ure_job *job, int64_t tick, hipStream_t st)
     if (job->shard_sliced && n_sh < (1u << 16) && (uint64_t)((blocks + 7) / 8) * 8 * n_sh < (1ull << 31)) {
         shard_fast = 2 | (int)(n_sh << 8);
         grid = dim3((unsigned)((blocks + 7) / 8) * 8 * n_sh);
+    }
+    if (job->touch) {
+        hipLaunchKernelGGL((mf_touch_step_kernel<LPR, V4>), grid, dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, shard_fast);
+        return;
     }
     hipLaunchKernelGGL((mf_step_kernel<LPR, V4>), grid, dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, shard_fast);
 }
@@ -472,7 +545,9 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         if (steps > 65534) { delete job; return fail(-1, "ure_job_create: shard %d needs %lld steps/epoch (> 65534)", k, (long long)steps); }
         job->ticks = std::max(job->ticks, steps * S.epochs);
         const int per_block = kBlock / lanes_per_row(S.d);
-        const int blocks = S.n_units / per_block + (S.lazy_rows ? 0 : (n_rows - S.n_active + per_block - 1) / per_block);
+        if (S.touch_mode && (S.n_multi < 0 || S.n_multi > S.n_active)) { delete job; return fail(-1, "ure_job_create: shard %d: n_multi outside [0, n_active]", k); }
+        const int blocks = S.touch_mode ? S.n_units / per_block + (S.n_active - S.n_multi + kBlock - 1) / kBlock      // units + candidate workgroups
+                                        : S.n_units / per_block + (S.lazy_rows ? 0 : (n_rows - S.n_active + per_block - 1) / per_block);
         job->row_blocks.push_back(blocks);
         job->max_n = std::max(job->max_n, S.N);
         job->max_slots = std::max(job->max_slots, S.n_slots);
@@ -494,10 +569,68 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             job->snap_blocks = std::max<unsigned>(job->snap_blocks, (unsigned)std::min<int64_t>(((int64_t)(S.n_user + S.n_item) * (S.d / 4) + kBlock - 1) / kBlock, 2048));
         }
     }
+    for (int k = 0; k < n_shards; ++k) job->aux_host.push_back(make_shard_aux(shards[k]));
+    // ---- touch mode: all shards of the job or none; masks and closed-form tables are library-owned
+    for (int k = 0; k < n_shards; ++k) job->touch = job->touch || shards[k].touch_mode != 0;
+    if (job->touch) {
+        for (int k = 0; k < n_shards; ++k) {
+            const ure_shard_t &S = shards[k];
+            const char *why = !S.touch_mode ? "every shard of a job must ask for it" :
+                              !S.lazy_rows ? "it needs lazy_rows" :
+                              job->aux_host[k].steps > kTouchMaxSteps ? "more than 64 steps per epoch" :
+                              (S.epochs != shards[0].epochs || S.lam != shards[0].lam || S.mu != shards[0].mu ||
+                               job->lr_host[k] != job->lr_host[0]) ? "the shards' optimizer schedules differ" : nullptr;
+            if (why) { delete job; return fail(-1, "ure_job_create: touch mode refused for shard %d: %s", k, why); }
+            job->max_units = std::max(job->max_units, S.n_units);
+            job->max_active4 = std::max<int64_t>(job->max_active4, (int64_t)S.n_active * (S.d / 4));
+            job->max_rows = std::max(job->max_rows, S.n_user + S.n_item);
+        }
+    }
     hipError_t e = hipMalloc(&job->dev, sizeof(ure_shard_t) * n_shards);
     if (e == hipSuccess) e = hipMemcpy(job->dev, job->host.data(), sizeof(ure_shard_t) * n_shards, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&job->dev_ab, sizeof(double) * 2 * n_shards);
-    for (int k = 0; k < n_shards; ++k) job->aux_host.push_back(make_shard_aux(shards[k]));
+    if (job->touch && e == hipSuccess) {
+        // A_e^j for j = 0..64 at every epoch's learning rate, in double: (w, m)' = A (w, m),
+        // m' = mu m + lam w, w' = w - lr m'
+        const int E = shards[0].epochs;
+        std::vector<float> tab((size_t)E * kTouchTab * 4);
+        const double lam = (double)shards[0].lam, mu = (double)shards[0].mu;
+        for (int ep = 0; ep < E; ++ep) {
+            const double lr = (double)job->lr_host[0][(size_t)ep];
+            const double a11 = 1.0 - lr * lam, a12 = -lr * mu, a21 = lam, a22 = mu;
+            double p11 = 1.0, p12 = 0.0, p21 = 0.0, p22 = 1.0;
+            for (int j = 0; j < kTouchTab; ++j) {
+                float *o = &tab[((size_t)ep * kTouchTab + j) * 4];
+                o[0] = (float)p11; o[1] = (float)p12; o[2] = (float)p21; o[3] = (float)p22;
+                const double q11 = a11 * p11 + a12 * p21, q12 = a11 * p12 + a12 * p22;
+                const double q21 = a21 * p11 + a22 * p21, q22 = a21 * p12 + a22 * p22;
+                p11 = q11; p12 = q12; p21 = q21; p22 = q22;
+            }
+        }
+        void *ptab = nullptr;
+        e = hipMalloc(&ptab, tab.size() * sizeof(float));
+        if (e == hipSuccess) { job->touch_mem.push_back(ptab); e = hipMemcpy(ptab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice); }
+        for (int k = 0; k < n_shards && e == hipSuccess; ++k) {
+            const size_t bytes = (size_t)(shards[k].n_user + shards[k].n_item) * sizeof(unsigned long long);
+            void *mk = nullptr;
+            e = hipMalloc(&mk, 2 * bytes);
+            if (e != hipSuccess) break;
+            job->touch_mem.push_back(mk);
+            e = hipMemset(mk, 0, 2 * bytes);
+            job->aux_host[k].mask[0] = static_cast<unsigned long long *>(mk);
+            job->aux_host[k].mask[1] = static_cast<unsigned long long *>(mk) + (shards[k].n_user + shards[k].n_item);
+            job->aux_host[k].ptab = static_cast<const float4 *>(ptab);
+            // the masks once more in work order: per work unit (multi-pass rows) and per single-pass row of the schedule
+            const size_t n_um = (size_t)std::max(shards[k].n_units, 1), n_sm = (size_t)std::max(shards[k].n_active - shards[k].n_multi, 1);
+            void *wm = nullptr;
+            e = hipMalloc(&wm, (n_um + n_sm) * sizeof(unsigned long long));
+            if (e != hipSuccess) break;
+            job->touch_mem.push_back(wm);
+            e = hipMemset(wm, 0, (n_um + n_sm) * sizeof(unsigned long long));
+            job->aux_host[k].unit_mask = static_cast<unsigned long long *>(wm);
+            job->aux_host[k].sched_mask = static_cast<unsigned long long *>(wm) + n_um;
+        }
+    }
     if (e == hipSuccess) e = hipMalloc(&job->dev_aux, sizeof(shard_aux) * n_shards);
     if (e == hipSuccess) e = hipMemcpy(job->dev_aux, job->aux_host.data(), sizeof(shard_aux) * n_shards, hipMemcpyHostToDevice);
     if (e != hipSuccess) { const int rc = fail((int)e, "ure_job_create: %s", hipGetErrorString(e)); ure_job_destroy(reinterpret_cast<ure_job_t *>(job)); return rc; }
@@ -512,6 +645,7 @@ int ure_job_destroy(ure_job_t *j)
     if (job->dev) (void)hipFree(job->dev);
     if (job->dev_ab) (void)hipFree(job->dev_ab);
     if (job->dev_aux) (void)hipFree(job->dev_aux);
+    for (void *p : job->touch_mem) (void)hipFree(p);
     delete job;
     return 0;
 }
@@ -549,6 +683,18 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
             launch_tag_prep(job, t, st);
             if (int rc = mark(assign_ev)) return rc;
         }
+        if (touch_prep_needed(job, t)) {
+            if (int rc = mark(assign_ev)) return rc;
+            switch (lanes_per_row(job->d)) {
+                case 1: launch_touch_prep<1>(job, t, st); break;
+                case 2: launch_touch_prep<2>(job, t, st); break;
+                case 4: launch_touch_prep<4>(job, t, st); break;
+                case 8: launch_touch_prep<8>(job, t, st); break;
+                case 16: launch_touch_prep<16>(job, t, st); break;
+                default: launch_touch_prep<32>(job, t, st); break;
+            }
+            if (int rc = mark(assign_ev)) return rc;
+        }
         if (int rc = mark(step_ev)) return rc;
         switch (job->d) {
             case 4: launch_step<1, 1>(job, t, st); break;
@@ -568,7 +714,7 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
                 if (S.snapU && t + 1 <= steps * S.epochs && (t + 1) % steps == 0) { epoch_end = true; break; }
             }
             if (epoch_end)
-                hipLaunchKernelGGL(snapshot_kernel, dim3(job->snap_blocks, (unsigned)job->host.size()), dim3(kBlock), 0, st, job->dev, t + 1);
+                hipLaunchKernelGGL(snapshot_kernel, dim3(job->snap_blocks, (unsigned)job->host.size()), dim3(kBlock), 0, st, job->dev, job->dev_aux, t + 1);
         }
     }
     URE_HIP(hipGetLastError());
@@ -579,9 +725,20 @@ int ure_job_materialize(ure_job_t *j, int64_t ticks_done, void *stream)
 {
     auto *job = reinterpret_cast<ure::ure_job *>(j);
     URE_ARG(job && ticks_done >= 0);
-    if (job->max_lazy == 0 || ticks_done == 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t n = job->host.size();
+    if (job->touch) {
+        // rows are kept valid for their NEXT own step: the tables as of `ticks_done` exist only where a shard stands
+        // at one of its epoch boundaries (all its rows are then valid for that boundary)
+        for (size_t k = 0; k < n; ++k) {
+            const int64_t steps = job->aux_host[k].steps;
+            const int64_t T = std::min(ticks_done, steps * job->host[k].epochs);
+            if (T % steps != 0) return fail(-1, "ure_job_materialize: touch mode: shard %d is inside an epoch at tick %lld (tables are readable at its epoch boundaries only)", (int)k, (long long)ticks_done);
+        }
+        const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((job->max_active4 + kBlock - 1) / kBlock, 8192));
+        hipLaunchKernelGGL(touch_collect_kernel, dim3(blocks, (unsigned)n), dim3(kBlock), 0, st, job->dev, job->dev_aux, ticks_done);
+    }
+    if (job->max_lazy == 0 || ticks_done == 0) { URE_HIP(hipGetLastError()); return 0; }
     job->ab_host.assign(2 * n, 0.0);
     for (size_t k = 0; k < n; ++k) {
         const ure_shard_t &S = job->host[k];

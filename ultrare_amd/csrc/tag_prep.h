@@ -182,6 +182,11 @@ struct shard_aux {
     int32_t ride_c;         // the same for phase C
     int32_t ranges;         // tag_ranges(N)
     int32_t derive_blocks;  // tag_derive_blocks(n_slots)
+    // touch mode (mf_touch.h); library-owned device memory, NULL otherwise
+    unsigned long long *mask[2];   // [n_user + n_item] steps of the epoch in which the row is trained, by epoch parity
+    const float4 *ptab;            // [epochs][65] A_e^j = {p11, p12, p21, p22}: j optimizer steps without a gradient at epoch e's lr
+    unsigned long long *unit_mask; // [n_units] the current epoch's mask of each work unit's row
+    unsigned long long *sched_mask;// [n_active - n_multi] the same for the single-pass rows, in schedule order
 };
 
 inline shard_aux make_shard_aux(const ure_shard_t &S)

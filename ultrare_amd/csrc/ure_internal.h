@@ -61,6 +61,11 @@ struct ure_job {
     bool snapshots = false;
     unsigned snap_blocks = 1;
     int64_t max_lazy = 0;                              // float4 slices of lazily advanced rows, max over shards
+    bool touch = false;                                // touch mode (mf_touch.h): all shards of the job or none
+    std::vector<void *> touch_mem;                     // library-owned device memory of touch mode (masks, tables)
+    int max_units = 0;                                 // work units of the largest shard
+    int64_t max_active4 = 0;                           // float4 slices of active rows, max over shards
+    int max_rows = 0;
 };
 
 // tag_prep.hip: standalone per-epoch tag preparation (the step kernel carries the common case)

@@ -25,6 +25,8 @@ from . import _native as nv
 SCORE_PARTIALS = 2048     # URE_SCORE_PARTIALS of the C ABI
 SERIES_SCRATCH_BYTES = 256 << 20     # prediction scratch of one ure_eval_series call
 LAZY_ROWS = os.environ.get('URE_LAZY_ROWS', '1') != '0'
+TOUCH_MAX_STEPS = 64                 # kTouchMaxSteps of csrc/mf_touch.h
+TOUCH_MIN_TABLE_BYTES = 256 << 20    # auto rule: the job's live rows (w, m, second buffer) exceed the Infinity Cache
 
 
 def pad_dim(d):
@@ -81,12 +83,25 @@ class ShardData:
         self._sched_host = sched
         self._units = {}
 
-    def units(self, d):
-        """The work units of the step kernel for table width d (device int32 [n_units, 4])."""
-        if d not in self._units:
-            u = nv.build_units(self._sched_host, self.n_active, d)
-            self._units[d] = torch.from_numpy(np.ascontiguousarray(u)).to(self.device)
-        return self._units[d]
+    def units(self, d, touch=False):
+        """The work units of the step kernel for table width d (device int32 [n_units, 4]).  touch: only the rows
+        longer than one scan pass get units (-> (units, n_multi)); the others are worked off per step from a
+        compaction of the rows that are trained in it (csrc/mf_touch.h)."""
+        key = (d, bool(touch))
+        if key not in self._units:
+            n_rows = self.n_active
+            if touch:
+                lanes = d // 4 if d <= 32 else d // 8
+                seg = self._sched_host[:self.n_active, 2] - self._sched_host[:self.n_active, 1]
+                n_rows = int(np.count_nonzero(seg > 8 * lanes))
+                assert n_rows == 0 or (seg[:n_rows] > 8 * lanes).all()          # the schedule is heaviest first
+            u = nv.build_units(self._sched_host, n_rows, d)
+            if len(u) == 0:
+                u = np.zeros((1, 4), dtype=np.int32)[:0]
+            dev_u = torch.from_numpy(np.ascontiguousarray(u if len(u) else np.full((1, 4), -1, np.int32))).to(self.device)
+            self._units[key] = (dev_u, len(u), n_rows)
+        dev_u, n_units, n_rows = self._units[key]
+        return (dev_u, n_units, n_rows) if touch else dev_u
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in
@@ -115,7 +130,8 @@ class TrainJob:
     perms  : list of int32 [epochs, N_s] arrays (numpy or torch; CPU or device)
     """
 
-    def __init__(self, shards, inits, perms, k, batch, epochs, lr, lam, momentum, lr_decay=1.0, lr_step=50, lazy_rows=None, snapshots=False):
+    def __init__(self, shards, inits, perms, k, batch, epochs, lr, lam, momentum, lr_decay=1.0, lr_step=50, lazy_rows=None, snapshots=False,
+                 touch=None):
         assert len(shards) == len(inits) == len(perms) and len(shards) > 0
         self.shards, self.k, self.d = shards, int(k), pad_dim(int(k))
         self.batch, self.epochs = int(batch), int(epochs)
@@ -128,6 +144,14 @@ class TrainJob:
         # (URE_LAZY_ROWS=0 streams them every step, exactly as the reference's dense optimizer does)
         self.lazy_rows = LAZY_ROWS if lazy_rows is None else bool(lazy_rows)
         self._fresh = 0          # ticks for which the lazily advanced rows are up to date
+        # touch mode (csrc/mf_touch.h): a step visits only the rows it trains, the others are advanced in closed form when
+        # they are next trained.  Pays when the tables do not fit the caches (configs[3]); URE_TOUCH=0/1 overrides the rule.
+        steps_all = [(sh.N + self.batch - 1) // self.batch for sh in shards]
+        if touch is None:
+            env = os.environ.get('URE_TOUCH', 'auto')
+            live = sum(sh.n_active for sh in shards) * self.d * 12
+            touch = (env == '1') or (env == 'auto' and live > TOUCH_MIN_TABLE_BYTES)
+        self.touch = bool(touch) and self.lazy_rows and max(steps_all) <= TOUCH_MAX_STEPS
         self.snapshots = bool(snapshots)
         self.lr = torch.from_numpy(lr_host).to(dev)
         self.state = []
@@ -153,8 +177,13 @@ class TrainJob:
             D = descs[s]
             for name in ('ent_oid', 'ent_r', 'ent_tag', 'ent_src', 'file_tag', 'inv_stage', 'inv_off', 'sched'):
                 setattr(D, name, nv.ptr(getattr(sh, name)))
-            units = sh.units(self.d)
-            D.units, D.n_units, D.n_active, D.n_slots = nv.ptr(units), units.shape[0], sh.n_active, sh.n_slots
+            if self.touch:
+                units, n_units, n_multi = sh.units(self.d, touch=True)
+                D.n_multi = n_multi
+            else:
+                units = sh.units(self.d)
+                n_units = units.shape[0]
+            D.units, D.n_units, D.n_active, D.n_slots = nv.ptr(units), n_units, sh.n_active, sh.n_slots
             D.U[0], D.U[1] = nv.ptr(U[0]), nv.ptr(U[1])
             D.V[0], D.V[1] = nv.ptr(V[0]), nv.ptr(V[1])
             D.mU, D.mV = nv.ptr(mU), nv.ptr(mV)
@@ -162,6 +191,7 @@ class TrainJob:
             D.N, D.n_user, D.n_item, D.d = sh.N, sh.n_user, sh.n_item, self.d
             D.batch, D.epochs = self.batch, self.epochs
             D.lam, D.mu = float(lam), float(momentum)
+            D.touch_mode = int(self.touch)
             if self.snapshots:
                 snapU = torch.empty(self.epochs, sh.n_user, self.d, dtype=torch.float32, device=dev)
                 snapV = torch.empty(self.epochs, sh.n_item, self.d, dtype=torch.float32, device=dev)
