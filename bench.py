@@ -233,7 +233,7 @@ def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_st
 
 def source_hash():
     from ultrare_amd import build as lib_build
-    return lib_build.source_hash()
+    return lib_build.step_kernel_hash()
 
 
 def roofline_of(a, leg, d, batch):
@@ -245,17 +245,20 @@ def roofline_of(a, leg, d, batch):
     job, shards, spec = leg['job'], leg['shards'], leg['spec']
     dp = engine.pad_dim(d)
     rows_streamed = [sh.n_active if job.lazy_rows else spec['n_user'] + spec['n_item'] for sh in shards]
+    if job.touch:      # touch mode: only the rows a step trains are read and rewritten (measured on the epoch's row masks)
+        rows_streamed = [round(x, 1) for x in job.touch_rows_per_step()]
     n_launch = leg['n_launch']
     # SURVEY 8d counts 20 B per dense element (w, m, g read; w, m written); this kernel never materialises
     # g, so it moves 16 B: both figures are reported, `achieved` uses the survey's
     _, per_tick, dense20 = interactions_in_ticks(leg['sizes'], batch, leg['t0_tick'], leg['t0_tick'] + n_launch, leg['epochs'],
-                                                 dense_bytes=[20 * r * dp for r in rows_streamed])
+                                                 dense_bytes=[int(20 * r * dp) for r in rows_streamed])
     b_sparse = 16 + 16 * dp
     alg20 = float((per_tick * b_sparse + dense20).sum()) / n_launch
     alg16 = float((per_tick * b_sparse + dense20 * 16 // 20).sum()) / n_launch
     avg_ms = leg['dev_ms'] / n_launch
     step_ms, n_step, _, _ = job.run_profiled(a.roofline_steps * leg['tps'])
     traffic, traffic_src, traffic_note = None, None, None
+    kernel_name = 'mf_touch_step_kernel' if job.touch else 'mf_step_kernel'
     import glob
     import re
     tag = f'{a.workload}_s{len(leg["all_sizes"])}_d{d}_b{batch}'
@@ -270,14 +273,14 @@ def roofline_of(a, leg, d, batch):
             if j.get('source_hash') != here:
                 traffic_note = f'{os.path.relpath(f, ROOT)} was taken at source hash {j.get("source_hash")}, tree is {here}: not quoted'
                 continue
-            k = [v for n, v in j['kernels'].items() if 'mf_step_kernel' in n][0]
+            k = [v for n, v in j['kernels'].items() if kernel_name + '<' in n][0]
             traffic, traffic_src, traffic_note = k['traffic_bytes_per_launch'], os.path.relpath(f, ROOT), None
             break
         except Exception:
             continue
     achieved = alg20 / (avg_ms * 1e-3) / 1e9
     fabric = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
-    return {'bound': 'hbm', 'kernel': 'mf_step_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+    return {'bound': 'hbm', 'kernel': kernel_name, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
             'traffic': traffic, 'traffic_source': traffic_src, 'traffic_note': traffic_note,
             'fabric_gbs': round(fabric, 1) if fabric else None, 'fabric_frac': round(fabric / HBM_PEAK_GBS, 4) if fabric else None,
@@ -285,7 +288,8 @@ def roofline_of(a, leg, d, batch):
             'alg_gbs_16B_dense': round(alg16 / (avg_ms * 1e-3) / 1e9, 1),
             'avg_launch_us': round(avg_ms * 1e3, 2), 'launches_timed': n_launch,
             'per_launch_event_us': round(step_ms / max(n_step, 1) * 1e3, 2),
-            'dense_rows_streamed_per_shard': rows_streamed, 'lazy_rows': bool(job.lazy_rows), 'source_hash': here,
+            'dense_rows_streamed_per_shard': rows_streamed if len(rows_streamed) <= 8 else {'shards': len(rows_streamed), 'mean': round(float(np.mean(rows_streamed)), 1)},
+            'lazy_rows': bool(job.lazy_rows), 'touch_mode': bool(job.touch), 'source_hash': here,
             'note': 'frac = algorithmic bytes (SURVEY 8d) / time / 8 TB/s; fabric_frac = PMC bytes that crossed the L2 / time / 8 TB/s '
                     '(ml-1m tables are cache resident, so fabric_frac is the HBM-side utilisation)'}
 

@@ -147,6 +147,10 @@ int ure_job_train(ure_job_t *job, int64_t tick0, int64_t tick1, void *stream);
  * every shard, for `ticks_done` = the number of ticks trained so far.  Call before reading
  * the tables; training may continue afterwards.  No-op for shards with lazy_rows == 0. */
 int ure_job_materialize(ure_job_t *job, int64_t ticks_done, void *stream);
+/* Touch mode accounting (synchronises): rows_per_epoch[s] = the number of (row, step) pairs of shard s's current
+ * epoch in which a row is trained -- the rows the step kernel actually reads and rewrites, summed over the epoch's
+ * steps (from the epoch's row masks); -1 for a job that is not in touch mode.                                   */
+int ure_job_touch_rows(ure_job_t *job, int64_t *rows_per_epoch);
 /* Measurement aid (bench.py's roofline leg): the same ticks, each kernel launch
  * bracketed by a pair of HIP events on `stream`; synchronises the stream and returns
  * the summed durations and launch counts of the step kernel and of the per-epoch

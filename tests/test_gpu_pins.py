@@ -216,10 +216,11 @@ def test_four_d128_shards_side_by_side_vs_oracle():
         inits.append(rng.mf_init(n_user, n_item, k))
         perms.append(rng.epoch_perms(rng.epoch_seeds(1, True), len(p[0])))
     shards = [engine.ShardData(*p, n_user, n_item) for p in parts]
-    job = engine.TrainJob(shards, inits, perms, k, B, 1, 1e-3, 0.1, 0.9, 0.95)
+    job = engine.TrainJob(shards, inits, perms, k, B, 1, 1e-3, 0.1, 0.9, 0.95, touch=False)     # the default kernel (touch mode: test_gpu_touch.py)
+    assert not job.touch
     job.run()
     torch.cuda.synchronize()
-    alone = engine.TrainJob([shards[2]], [inits[2]], [perms[2]], k, B, 1, 1e-3, 0.1, 0.9, 0.95)
+    alone = engine.TrainJob([shards[2]], [inits[2]], [perms[2]], k, B, 1, 1e-3, 0.1, 0.9, 0.95, touch=False)
     alone.run()
     assert torch.equal(alone.tables(0)[0], job.tables(2)[0]) and torch.equal(alone.tables(0)[1], job.tables(2)[1])
     alone.close()

@@ -51,6 +51,7 @@ _PROTOTYPES = {
     'ure_job_ticks': (_i64, [_vp]),
     'ure_job_train': (ctypes.c_int, [_vp, _i64, _i64, _vp]),
     'ure_job_materialize': (ctypes.c_int, [_vp, _i64, _vp]),
+    'ure_job_touch_rows': (ctypes.c_int, [_vp, _vp]),
     'ure_job_train_profiled': (ctypes.c_int, [_vp, _i64, _i64, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
                                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64)]),
     'ure_host_randperm': (ctypes.c_int, [_vp, ctypes.c_int, _i64, _vp, ctypes.c_int]),

@@ -36,6 +36,22 @@ def source_hash(extra=()):
     return h.hexdigest()[:16]
 
 
+STEP_KERNEL_FILES = ['mf_train.hip', 'mf_touch.h', 'tag_prep.h', 'tag_prep.hip', 'ure_internal.h']
+
+
+def step_kernel_hash():
+    """Hash of the sources the training step kernels are compiled from (+ the public header and the flags): what a
+    PMC counter file of those kernels is tied to (bench.py quotes `roofline.traffic` only on a match)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, f) for f in STEP_KERNEL_FILES] + [os.path.join(ROOT, 'include', 'ultrare_hip.h')]:
+        h.update(os.path.basename(path).encode() + b'\0')
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def built_hash(lib=None):
     """The hash a built library reports (ure_source_hash), read without loading it into this process
     through ctypes' global namespace: a throw-away handle is enough, the symbol is plain C."""

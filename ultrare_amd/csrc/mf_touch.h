@@ -198,7 +198,7 @@ __device__ __forceinline__ void touch_process(const ure_shard_t &S, const shard_
     using Row = RowVec<V4>;
     constexpr int G = kWave / LPR;
     constexpr int CAP = kSegPerLane * LPR;
-    constexpr int kGB = LPR <= 8 ? URE_KGB_NARROW : URE_KGB_WIDE;
+    constexpr int kGB = URE_TOUCH_KGB;
     const int lane = threadIdx.x & 63;
     const int sub = lane & (LPR - 1), grp = lane / LPR;
     const float lam = S.lam, mu = S.mu;

@@ -54,6 +54,12 @@
 #ifndef URE_WAVES_WIDE
 #define URE_WAVES_WIDE 4
 #endif
+#ifndef URE_TOUCH_WAVES
+#define URE_TOUCH_WAVES 4     // touch mode (mf_touch.h)
+#endif
+#ifndef URE_TOUCH_KGB
+#define URE_TOUCH_KGB 4       // rows a lane group gathers together in touch mode
+#endif
 
 namespace ure {
 
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void materialize_rows_kernel(const ure_shar
 namespace ure {
 
 template <int LPR, int V4>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void mf_touch_step_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, int shard_fast)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(URE_TOUCH_WAVES))) void mf_touch_step_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, int shard_fast)
 {
     mf_touch_step<LPR, V4>(shards, aux, tick, shard_fast);
 }
@@ -759,6 +765,27 @@ int ure_job_materialize(ure_job_t *j, int64_t ticks_done, void *stream)
     const unsigned blocks = (unsigned)std::min<int64_t>((job->max_lazy + kBlock - 1) / kBlock, 2048);
     hipLaunchKernelGGL(materialize_rows_kernel, dim3(blocks, (unsigned)n), dim3(kBlock), 0, st, job->dev, job->dev_ab, ticks_done);
     URE_HIP(hipGetLastError());
+    return 0;
+}
+
+int ure_job_touch_rows(ure_job_t *j, int64_t *rows_per_epoch)
+{
+    auto *job = reinterpret_cast<ure::ure_job *>(j);
+    URE_ARG(job && rows_per_epoch);
+    for (size_t k = 0; k < job->host.size(); ++k) rows_per_epoch[k] = -1;
+    if (!job->touch || job->next_tick == 0) return 0;
+    URE_HIP(hipDeviceSynchronize());
+    std::vector<unsigned long long> host;
+    for (size_t k = 0; k < job->host.size(); ++k) {
+        const ure_shard_t &S = job->host[k];
+        const int64_t steps = job->aux_host[k].steps;
+        const int64_t epoch = std::min<int64_t>((job->next_tick - 1) / steps, S.epochs - 1);      // the epoch the last launch belonged to
+        host.resize((size_t)S.n_user + S.n_item);
+        URE_HIP(hipMemcpy(host.data(), job->aux_host[k].mask[epoch & 1], host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        int64_t n = 0;
+        for (unsigned long long m : host) n += __builtin_popcountll(m);
+        rows_per_epoch[k] = n;
+    }
     return 0;
 }
 

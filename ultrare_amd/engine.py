@@ -267,6 +267,15 @@ class TrainJob:
         st = self.state[s]
         return st['U'][cur], st['V'][cur]
 
+    def touch_rows_per_step(self):
+        """Touch mode: rows the step kernel reads and rewrites per optimizer step, per shard (average over the shard's
+        current epoch, from the epoch's row masks; synchronises).  None otherwise."""
+        if not self.touch:
+            return None
+        out = np.zeros(len(self.shards), dtype=np.int64)
+        nv.check(nv.lib().ure_job_touch_rows(self._job, out.ctypes.data), 'ure_job_touch_rows')
+        return [float(n) / self.steps_per_epoch(s) for s, n in enumerate(out)]
+
     def epoch_sse(self, s):
         """Per-epoch sum of squared training errors (host float64 array; synchronises)."""
         return self.state[s]['sse'].double().sum(dim=1).cpu().numpy()
