@@ -162,6 +162,11 @@ int ure_job_train_profiled(ure_job_t *job, int64_t tick0, int64_t tick1, void *s
  * seeds[t]) for t < n_perms, as int32, computed on `n_threads` host threads (0 = all).
  * HOST memory; bit-identical to torch's CPU randperm for n < 2^32/20. */
 int ure_host_randperm(const int64_t *seeds, int n_perms, int64_t n, int32_t *out, int n_threads);
+/* Moves a torch CPU generator state (the bytes of torch.get_rng_state(): u64 seed, i32 left, i32 seeded,
+ * u64 next, u64 state[624], ...) past `n_draws` 32-bit MT19937 outputs without producing them: the model
+ * init fills the reference discards (utils.py:31-40: the nn.Embedding constructors' fills) and, in a
+ * multi-rank run, the draws of the shards other ranks own.  In place.                       */
+int ure_host_mt_advance(uint8_t *state, int64_t n_bytes, int64_t n_draws);
 
 /* ---------------------------------------------------------------------------
  * Host-side ingest (HOST memory throughout; linear time, `n_threads` = 0 means all cores)

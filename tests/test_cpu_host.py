@@ -491,3 +491,76 @@ def test_bench_counts_interactions_exactly():
     assert tot == 3 * 70 + 3 * 25 + 3 * 100
     assert per_tick[:4].tolist() == [30 + 25 + 30, 30 + 25 + 30, 10 + 25 + 30, 30 + 0 + 10]
     assert dense[:4].tolist() == [111, 111, 111, 101] and dense[9:].tolist() == [100, 100, 100]
+
+
+# ---------------------------------------------------------------- generator skip-ahead (ure_host_mt_advance)
+def test_mt_advance_matches_torch_generator_state():
+    """Moving torch's CPU generator past the draws of a call without making them: normal_ of n >= 16 float32
+    elements consumes n (+16 when 16 does not divide n) 32-bit outputs, an int64 random_ two each -- the
+    resulting state must be torch's own, byte for byte (ATen CPUGeneratorImpl, legacy state layout)."""
+    from ultrare_amd import rng
+    torch.manual_seed(42)
+    s0 = torch.get_rng_state()
+    body = 24 + 624 * 8
+    for n in (16, 17, 100, 623, 624, 625, 6040 * 32, 3416 * 32, 1508 * 16 + 3):
+        torch.set_rng_state(s0)
+        torch.empty(n).normal_()
+        assert torch.equal(torch.get_rng_state()[:body], rng.advance_state(s0, rng.fill_draws(n))[:body]), n
+    torch.set_rng_state(s0)
+    torch.empty(200, dtype=torch.int64).random_()
+    assert torch.equal(torch.get_rng_state(), rng.advance_state(s0, 400))
+    # a chain of calls from a state in the middle of a block
+    torch.set_rng_state(s0)
+    torch.empty(1000).normal_()
+    mid = torch.get_rng_state()
+    torch.empty(3, 70).normal_()
+    torch.empty(9, dtype=torch.int64).random_()
+    assert torch.equal(torch.get_rng_state()[:body], rng.advance_state(mid, rng.fill_draws(210) + 18)[:body])
+    assert torch.equal(rng.advance_state(mid, 0), mid)
+    with pytest.raises(Exception):
+        rng.advance_state(torch.zeros(16, dtype=torch.uint8), 5)
+
+
+def test_shard_streams_reproduce_the_sequential_draws():
+    """rng.shard_streams / mf_init(generator=) / epoch_seeds(generator=): every shard's draws taken from its own
+    generator, positioned by skip-ahead, equal the draws a single generator makes shard after shard with the
+    reference's four fills (utils.py:31-40), and the global generator ends where it would have."""
+    from ultrare_amd import rng
+    n_user, n_item, k, E, S = 300, 211, 8, 3, 4
+    torch.manual_seed(7)
+    want = []
+    for _ in range(S):
+        torch.empty(n_user, k).normal_()                      # nn.Embedding constructors: discarded
+        torch.empty(n_item, k).normal_()
+        U0, V0 = torch.empty(n_user, k).normal_(), torch.empty(n_item, k).normal_()
+        seeds = [int(torch.empty((), dtype=torch.int64).random_().item()) for _ in range(4 * E)][1::4]
+        want.append((U0, V0, seeds))
+    end = torch.get_rng_state()
+    torch.manual_seed(7)
+    starts, after = rng.shard_streams(S, n_user, n_item, k, E, True)
+    assert torch.equal(after, end)
+    for i in reversed(range(S)):                              # any order: the streams are independent
+        g = torch.Generator()
+        g.set_state(starts[i])
+        U0, V0 = rng.mf_init(n_user, n_item, k, generator=g)
+        assert torch.equal(U0, want[i][0]) and torch.equal(V0, want[i][1])
+        assert rng.epoch_seeds(E, True, generator=g) == want[i][2]
+    torch.manual_seed(7)
+    for _ in range(S):
+        rng.skip_model(n_user, n_item, k, E, True)
+    assert torch.equal(torch.get_rng_state(), end)
+    # the worker-thread form (no device): same init, seeds expanded to the same permutations
+    torch.manual_seed(7)
+    starts, _ = rng.shard_streams(S, n_user, n_item, k, E, True)
+    for i in range(S):
+        init, perms = rng.shard_draws_async(starts[i], n_user, n_item, k, E, True, 500, True, threads=2).result()
+        assert torch.equal(init[0], want[i][0]) and torch.equal(init[1], want[i][1])
+        for e in range(E):
+            assert torch.equal(perms[e], rng.epoch_perm(want[i][2][e], 500))
+        rng.release(perms)
+    assert rng.model_draws(1, 3, 4, E, True) is None          # tables under 16 elements: ATen's scalar path, replayed not skipped
+    torch.manual_seed(7)
+    a = rng.mf_init(1, 3, 4)
+    torch.manual_seed(7)
+    torch.empty(1, 4).normal_(); torch.empty(3, 4).normal_()
+    assert torch.equal(a[0], torch.empty(1, 4).normal_()) and torch.equal(a[1], torch.empty(3, 4).normal_())

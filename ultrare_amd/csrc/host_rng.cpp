@@ -10,6 +10,7 @@
 // for many epochs at once on a thread pool: each epoch has its own generator, so the
 // permutations are independent.  torch.randperm itself costs ~2 ms per 180 k-row epoch on
 // one thread, which would dominate a 50-epoch SISA job whose device time is ~10 ms.
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <thread>
@@ -52,15 +53,68 @@ struct Mt19937 {
     }
 };
 
-void one_perm(uint64_t seed, int64_t n, int32_t *r)
+// One permutation in three passes instead of one dependent loop.  The swap partner of position i,
+//     z_i = mt() % (n - i),
+// depends on the generator and on i only -- not on the swaps before it -- so all z_i are computed first:
+// the MT19937 outputs in bulk (regeneration and tempering vectorise), then the remainders through a
+// double-precision quotient (exact: x < 2^32, so x / m rounded to 53 bits never reaches the next integer
+// from below nor falls under floor(x / m); see the proof sketch in DESIGN.md 5), which vectorises too,
+// where the 32-bit `div` of the direct form costs ~25 cycles per element.  What is left of the loop-carried
+// work is the swap itself, with addresses known ahead of time.  The generated sequence is ATen's, draw for draw.
+#if defined(__HIP_DEVICE_COMPILE__) || !defined(__x86_64__)
+#define URE_HOST_CLONES
+#else
+#define URE_HOST_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))      // the library is built once, run on any host
+#endif
+URE_HOST_CLONES void fill_partners(uint32_t *st, int *idx, uint32_t *z, int64_t count, int64_t n)
+{
+    constexpr int N = Mt19937::N, M = Mt19937::M;
+    int64_t done = 0;
+    while (done < count) {
+        if (*idx >= N) {
+            int k = 0;
+            for (; k < N - M; ++k) {
+                const uint32_t y = (st[k] & 0x80000000u) | (st[k + 1] & 0x7fffffffu);
+                st[k] = st[k + M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            for (; k < N - 1; ++k) {
+                const uint32_t y = (st[k] & 0x80000000u) | (st[k + 1] & 0x7fffffffu);
+                st[k] = st[k + M - N] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            const uint32_t y = (st[N - 1] & 0x80000000u) | (st[0] & 0x7fffffffu);
+            st[N - 1] = st[M - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            *idx = 0;
+        }
+        const int64_t take = std::min<int64_t>(N - *idx, count - done);
+        const uint32_t *src = st + *idx;
+        uint32_t *dst = z + done;
+        for (int64_t t = 0; t < take; ++t) {
+            uint32_t x = src[t];
+            x ^= x >> 11;
+            x ^= (x << 7) & 0x9d2c5680u;
+            x ^= (x << 15) & 0xefc60000u;
+            x ^= x >> 18;
+            const uint32_t m = (uint32_t)(n - (done + t));
+            const uint32_t q = (uint32_t)((double)x / (double)m);
+            dst[t] = x - q * m;
+        }
+        *idx += (int)take;
+        done += take;
+    }
+}
+
+void one_perm(uint64_t seed, int64_t n, int32_t *r, std::vector<uint32_t> &z)
 {
     for (int64_t i = 0; i < n; ++i) r[i] = (int32_t)i;
+    if (n < 2) return;
     Mt19937 mt(seed);
+    z.resize((size_t)n);
+    fill_partners(mt.st, &mt.idx, z.data(), n - 1, n);
     for (int64_t i = 0; i < n - 1; ++i) {
-        const int64_t z = (int64_t)(mt.next() % (uint32_t)(n - i));
+        const int64_t j = i + (int64_t)z[(size_t)i];
         const int32_t sav = r[i];
-        r[i] = r[i + z];
-        r[i + z] = sav;
+        r[i] = r[j];
+        r[j] = sav;
     }
 }
 
@@ -75,7 +129,8 @@ extern "C" int ure_host_randperm(const int64_t *seeds, int n_perms, int64_t n, i
     nt = nt < 1 ? 1 : (nt > n_perms ? n_perms : nt);
     std::atomic<int> next{0};
     auto work = [&]() {
-        for (int t = next.fetch_add(1); t < n_perms; t = next.fetch_add(1)) one_perm((uint64_t)seeds[t], n, out + (size_t)t * n);
+        std::vector<uint32_t> z;
+        for (int t = next.fetch_add(1); t < n_perms; t = next.fetch_add(1)) one_perm((uint64_t)seeds[t], n, out + (size_t)t * n, z);
     };
     if (nt == 1) {
         work();
@@ -85,5 +140,65 @@ extern "C" int ure_host_randperm(const int64_t *seeds, int n_perms, int64_t n, i
     pool.reserve(nt);
     for (int t = 0; t < nt; ++t) pool.emplace_back(work);
     for (auto &th : pool) th.join();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Skip-ahead of torch's CPU generator.  The reference draws four N(0,1) fills per model
+// (utils.py:31-40) and throws two of them away (the nn.Embedding constructors' own fills, overwritten
+// by init_weight), and in a multi-rank run every rank replays the whole stream to reach its own
+// shards.  The draws are data independent, so the generator can be moved past them
+// without computing a single normal: only the MT19937 state has to advance by the number of 32-bit
+// outputs those calls would have consumed.  `state` is torch.get_rng_state()'s byte layout
+// (CPUGeneratorImplStateLegacy: u64 seed, i32 left, i32 seeded, u64 next, u64 state[624], ...);
+// ATen's engine draws with `if (--left == 0) next_state(); y = state[next++]`.
+// ---------------------------------------------------------------------------------------------
+extern "C" int ure_host_mt_advance(uint8_t *state, int64_t n_bytes, int64_t n_draws)
+{
+    constexpr int N = 624, M = 397;
+    if (!state || n_bytes < (int64_t)(24 + 8 * N) || n_draws < 0) return ure::fail(-1, "ure_host_mt_advance: bad arguments");
+    int32_t left;
+    uint64_t next;
+    __builtin_memcpy(&left, state + 8, 4);
+    __builtin_memcpy(&next, state + 16, 8);
+    uint64_t *wide = reinterpret_cast<uint64_t *>(state + 24);
+    if (left < 1 || left > N || next > (uint64_t)N) return ure::fail(-1, "ure_host_mt_advance: not a torch CPU generator state (left=%d next=%llu)", left, (unsigned long long)next);
+    uint32_t st[N];
+    bool loaded = false;
+    int64_t n = n_draws;
+    while (n > 0) {
+        if (left > 1) {                        // outputs left in the current block
+            const int64_t c = n < (int64_t)left - 1 ? n : (int64_t)left - 1;
+            left -= (int32_t)c;
+            next += (uint64_t)c;
+            n -= c;
+            continue;
+        }
+        if (!loaded) {
+            for (int k = 0; k < N; ++k) st[k] = (uint32_t)wide[k];
+            loaded = true;
+        }
+        // next_state(): the standard regeneration, in three runs without index wrap-around
+        int k = 0;
+        for (; k < N - M; ++k) {
+            const uint32_t y = (st[k] & 0x80000000u) | (st[k + 1] & 0x7fffffffu);
+            st[k] = st[k + M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        for (; k < N - 1; ++k) {
+            const uint32_t y = (st[k] & 0x80000000u) | (st[k + 1] & 0x7fffffffu);
+            st[k] = st[k + M - N] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        {
+            const uint32_t y = (st[N - 1] & 0x80000000u) | (st[0] & 0x7fffffffu);
+            st[N - 1] = st[M - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        left = N;
+        next = 1;                              // this draw took state[0]
+        n -= 1;
+    }
+    if (loaded)
+        for (int k = 0; k < N; ++k) wide[k] = st[k];
+    __builtin_memcpy(state + 8, &left, 4);
+    __builtin_memcpy(state + 16, &next, 8);
     return 0;
 }

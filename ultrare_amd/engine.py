@@ -155,8 +155,13 @@ class TrainJob:
         self.snapshots = bool(snapshots)
         self.lr = torch.from_numpy(lr_host).to(dev)
         self.state = []
+        self._chunks = []        # per shard whose permutations are uploaded in chunks: [(first epoch after the chunk, event), ...]
         descs = (nv.UreShard * len(shards))()
         for s, (sh, (U0, V0), perm) in enumerate(zip(shards, inits, perms)):
+            for t in (U0, V0):
+                if getattr(t, '_ure_event', None) is not None:          # uploaded on a side stream (rng.shard_draws_async)
+                    torch.cuda.current_stream(dev).wait_event(t._ure_event)
+                    t.record_stream(torch.cuda.current_stream(dev))
             U0 = torch.as_tensor(U0, dtype=torch.float32)
             V0 = torch.as_tensor(V0, dtype=torch.float32)
             assert U0.shape == (sh.n_user, self.k) and V0.shape == (sh.n_item, self.k)
@@ -168,7 +173,9 @@ class TrainJob:
             mU = torch.zeros(sh.n_user, self.d, dtype=torch.float32, device=dev)
             mV = torch.zeros(sh.n_item, self.d, dtype=torch.float32, device=dev)
             perm = torch.as_tensor(perm)
-            if getattr(perm, '_ure_event', None) is not None:       # uploaded on a side stream (rng.epoch_perms_async)
+            if getattr(perm, '_ure_chunks', None) is not None:      # still arriving in chunks of epochs (rng.shard_draws_async)
+                self._chunks.append(list(perm._ure_chunks))
+            elif getattr(perm, '_ure_event', None) is not None:     # uploaded on a side stream (rng.epoch_perms_async)
                 torch.cuda.current_stream(dev).wait_event(perm._ure_event)
             assert perm.shape == (self.epochs, sh.N), f'perm of shard {s} must be [epochs, N]'
             perm = perm.to(device=dev, dtype=torch.int32).contiguous()
@@ -216,9 +223,33 @@ class TrainJob:
     def run(self, n_ticks=None, stream=None):
         """Enqueue the next n_ticks optimizer steps of every shard (default: all)."""
         t1 = self.ticks if n_ticks is None else min(self.ticks, self.done + int(n_ticks))
-        if t1 > self.done:
-            nv.check(nv.lib().ure_job_train(self._job, self.done, t1, nv.stream_handle(stream)), 'ure_job_train')
-            self.done = t1
+        while t1 > self.done:
+            t_next = t1
+            if self._chunks:
+                # the launches of tick t read the permutation of the epoch AFTER the one a shard is in (the batch tags are
+                # prepared one epoch ahead): wait for the chunk that holds it, and launch only up to where the next one is needed
+                min_steps = min(self.steps_per_epoch(s) for s in range(len(self.shards)))
+                need = self.done // min_steps + 1                       # newest epoch any shard can read at tick self.done
+                st = stream if stream is not None else torch.cuda.current_stream(self.device)
+                horizon = self.epochs
+                def wait(chunk):                                        # host: until the worker queued the upload; device: until it is done
+                    chunk[1].wait()
+                    if chunk[2][0] is None:
+                        raise nv.NativeError('the permutation worker failed before this chunk was uploaded')
+                    st.wait_event(chunk[2][0])
+                for ch in self._chunks:
+                    while ch and ch[0][0] <= need and len(ch) > 1:      # chunks that end at or before `need`, then the one holding it
+                        wait(ch.pop(0))
+                    if ch:
+                        wait(ch[0])
+                        horizon = min(horizon, ch[0][0])                # epochs < horizon have arrived (after these waits)
+                        if len(ch) == 1 and ch[0][0] >= self.epochs:
+                            ch.pop(0)
+                self._chunks = [ch for ch in self._chunks if ch]
+                if horizon < self.epochs:
+                    t_next = min(t1, max(self.done + 1, (horizon - 1) * min_steps))
+            nv.check(nv.lib().ure_job_train(self._job, self.done, t_next, nv.stream_handle(stream)), 'ure_job_train')
+            self.done = t_next
         return self.done
 
     def run_profiled(self, n_ticks, stream=None):

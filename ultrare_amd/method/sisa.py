@@ -23,7 +23,7 @@ from torch import nn
 
 from .. import engine
 from ..read import as_loader
-from .scratch import Scratch, prepare_shard, snapshot_limit
+from .scratch import PERM_THREADS, Scratch, prepare_shard, snapshot_limit
 from .utils import MF, baseTest, padded_tables, seed_all
 
 
@@ -54,21 +54,46 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
     table of such a shard is its exchanged own rows + the closed form of U0 elsewhere)."""
     from .. import rng
     prepared = {}
+    streams = rng.shard_streams(len(ids), n_user, n_item, k, epochs, True) if on_device else None
+    if streams is not None:
+        # every shard's start state by skip-ahead, then each owned shard's draws (init, seeds, permutations, upload)
+        # on its own worker thread while this thread builds / fetches the HBM layouts
+        starts, end = streams
+        torch.set_rng_state(end)
+        mine = [pos for pos in range(len(ids)) if owner[pos] == rank]
+        per_call = max(2, PERM_THREADS // max(len(mine), 1))
+        futures = {}
+        for pos, i in enumerate(ids):
+            loader = as_loader(train_dlist[i])
+            if owner[pos] == rank:
+                futures[i] = rng.shard_draws_async(starts[pos], n_user, n_item, k, epochs, True, len(loader.dataset), loader.shuffle,
+                                                   threads=per_call, device=engine._device())
+            elif foreign_u0 is not None:
+                futures[i] = rng.shard_draws_async(starts[pos], n_user, n_item, k, epochs, True, 0, False, want_perms=False)
+        shards = {i: as_loader(train_dlist[i]).shard_data(n_user, n_item) for pos, i in enumerate(ids) if owner[pos] == rank}
+        for pos, i in enumerate(ids):
+            if i not in futures:
+                continue
+            if owner[pos] == rank:
+                prepared[i] = (shards[i], futures[i].init(), futures[i].perms())     # the permutations may still be arriving (chunks)
+            else:
+                foreign_u0[i] = futures[i].init()[0]
+        return prepared
     for pos, i in enumerate(ids):
         if owner[pos] == rank:
             if on_device:
                 prepared[i] = prepare_shard(train_dlist[i], n_user, n_item, k, epochs, True, defer=True)
             else:   # host-only (tests): same draws, no HBM layout
-                init = MF(n_user, n_item, k)
+                U0, V0 = rng.mf_init(n_user, n_item, k)
                 seeds = rng.epoch_seeds(epochs, True)
                 n = len(as_loader(train_dlist[i]).dataset)
-                prepared[i] = (None, (init.user_mat.weight.detach(), init.item_mat.weight.detach()),
-                               rng.epoch_perms(seeds, n))
-        else:
+                prepared[i] = (None, (U0, V0), rng.epoch_perms(seeds, n))
+        elif foreign_u0 is not None:
             U0, _ = rng.mf_init(n_user, n_item, k)
-            if foreign_u0 is not None:
-                foreign_u0[i] = U0
+            foreign_u0[i] = U0
             rng.epoch_seeds(epochs, True)
+        else:
+            rng.skip_model(n_user, n_item, k, epochs, True)
     for i, (shard, init, perms) in list(prepared.items()):      # permutations expanded in the background: collect
         if hasattr(perms, 'result'):
             prepared[i] = (shard, init, perms.result())
@@ -192,9 +217,9 @@ class Sisa(Scratch):
                                   [prepared[i][2] for i in mine], self.k, batch, self.epochs, self.lr, self.lam,
                                   self.momentum, self.lr_decay, snapshots=keep_logs)
             from .. import rng
+            job.run()
             for i in mine:
                 rng.release(prepared[i][2])                 # uploaded: host buffers go back to the pool
-            job.run()
             for pos, i in enumerate(mine):
                 U, V = job.tables(pos)
                 models[i] = (U.clone().contiguous(), V.clone().contiguous())

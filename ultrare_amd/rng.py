@@ -10,25 +10,71 @@ be taken up front and the permutations expanded later (or on other threads).
   torch DataLoader        _base_seed per iterator                      -> draw_seed
   torch RandomSampler     seed -> Generator -> randperm(N)             -> epoch_perm
 """
+import threading
+
 import numpy as np
 import torch
 
 
-def mf_init(n_user, n_item, k):
-    """The four N(0,1) fills of `MF(n_user, n_item, k)`; the first two (Embedding
-    constructors) are overwritten by init_weight but still advance the stream."""
-    torch.empty(n_user, k).normal_(0, 1)
-    torch.empty(n_item, k).normal_(0, 1)
-    U0 = torch.empty(n_user, k).normal_(0, 1)
-    V0 = torch.empty(n_item, k).normal_(0, 1)
+def fill_draws(n):
+    """32-bit MT19937 outputs one `tensor.normal_()` of n >= 16 float32 elements consumes on the CPU: ATen fills
+    the tensor with n uniforms and turns them into normals 16 at a time; when 16 does not divide n the last 16
+    values are drawn again (checked against the generator state in tests/test_cpu_host.py)."""
+    assert n >= 16
+    return n + (16 if n % 16 else 0)
+
+
+def advance_state(state, n_draws):
+    """A copy of a torch CPU generator state moved past n_draws 32-bit outputs (ure_host_mt_advance)."""
+    from . import _native as nv
+    out = state.clone()
+    nv.check(nv.lib().ure_host_mt_advance(out.data_ptr(), out.numel(), int(n_draws)), 'ure_host_mt_advance')
+    return out
+
+
+def model_draws(n_user, n_item, k, epochs, with_total_test):
+    """32-bit outputs of one Scratch.train call: (the two discarded constructor fills, the two kept fills of
+    init_weight, the per-epoch int64 seeds: 2 outputs each).  None when a table has fewer than 16 elements
+    (ATen then takes its scalar path, which caches a second normal: such calls are replayed, not skipped)."""
+    nu, ni = n_user * k, n_item * k
+    if min(nu, ni) < 16:
+        return None
+    fills = fill_draws(nu) + fill_draws(ni)
+    return fills, fills, 2 * epochs * (4 if with_total_test else 3)
+
+
+def mf_init(n_user, n_item, k, generator=None):
+    """The four N(0,1) fills of `MF(n_user, n_item, k)` (utils.py:31-40).  The first two (the nn.Embedding
+    constructors') are overwritten by init_weight: the stream is moved past them without computing them."""
+    g = generator
+    draws = model_draws(n_user, n_item, k, 0, False)
+    if draws is None:
+        torch.empty(n_user, k).normal_(0, 1, generator=g)
+        torch.empty(n_item, k).normal_(0, 1, generator=g)
+    elif g is None:
+        torch.set_rng_state(advance_state(torch.get_rng_state(), draws[0]))
+    else:
+        g.set_state(advance_state(g.get_state(), draws[0]))
+    U0 = torch.empty(n_user, k).normal_(0, 1, generator=g)
+    V0 = torch.empty(n_item, k).normal_(0, 1, generator=g)
     return U0, V0
+
+
+def skip_model(n_user, n_item, k, epochs, with_total_test):
+    """Move the global generator past ALL draws of one Scratch.train call (a shard another rank owns)."""
+    draws = model_draws(n_user, n_item, k, epochs, with_total_test)
+    if draws is None:
+        mf_init(n_user, n_item, k)
+        epoch_seeds(epochs, with_total_test)
+        return
+    torch.set_rng_state(advance_state(torch.get_rng_state(), sum(draws)))
 
 
 def draw_seed():
     return int(torch.empty((), dtype=torch.int64).random_().item())
 
 
-def epoch_seeds(epochs, with_total_test):
+def epoch_seeds(epochs, with_total_test, generator=None):
     """Per epoch the reference draws: train loader base seed, sampler seed, group-test
     loader base seed and (SISA only) total-test loader base seed (scratch.py:78-97).
     Returns the sampler seeds; the others only advance the stream."""
@@ -37,8 +83,23 @@ def epoch_seeds(epochs, with_total_test):
         return []
     # one vectorised draw: random_() fills serially from the same generator, so the values are those of
     # `per * epochs` scalar draws (checked in tests/test_cpu_host.py)
-    draws = torch.empty(epochs * per, dtype=torch.int64).random_()
+    draws = torch.empty(epochs * per, dtype=torch.int64).random_(generator=generator)
     return [int(v) for v in draws[1::per].tolist()]
+
+
+def shard_streams(n_shards, n_user, n_item, k, epochs, with_total_test):
+    """The generator states at which each of n_shards consecutive Scratch.train calls starts, computed by
+    skip-ahead (the draws are data independent), and the state after the last one.  With them every shard's
+    draws can be taken on its own thread from its own torch.Generator.  None when skipping is not possible."""
+    draws = model_draws(n_user, n_item, k, epochs, with_total_test)
+    if draws is None:
+        return None
+    s = torch.get_rng_state()
+    starts = []
+    for _ in range(n_shards):
+        starts.append(s)
+        s = advance_state(s, sum(draws))
+    return starts, s
 
 
 def epoch_perm(seed, n):
@@ -86,8 +147,14 @@ def release(perms):
     """Hand a permutation buffer from epoch_perms(pooled=True) back (after it was uploaded)."""
     if torch.is_tensor(perms):
         host = getattr(perms, '_ure_host', None)
-        if host is not None:                    # uploaded by the background worker: wait for that copy
-            perms._ure_event.synchronize()
+        if host is not None:                    # uploaded by a background worker: wait for the (last) copy
+            chunks = getattr(perms, '_ure_chunks', None)
+            if chunks is not None:
+                chunks[-1][1].wait()
+                if chunks[-1][2][0] is not None:
+                    chunks[-1][2][0].synchronize()
+            else:
+                perms._ure_event.synchronize()
             POOL.give(host)
             perms._ure_host = None
         else:
@@ -168,6 +235,124 @@ def epoch_perms_async(seeds, n, threads=0, pooled=False, device=None):
         on_dev._ure_event, on_dev._ure_host = ev, out
         return on_dev
     return _EXPANDER.submit(work)
+
+
+_SHARD_POOL = None
+
+
+class ShardDraws:
+    """Handle of rng.shard_draws_async: init() blocks until the model init is there (on the device when a device was
+    given); perms() returns the permutations -- at once when they arrive in chunks (a device tensor whose `_ure_chunks`
+    = [(first epoch after the chunk, threading.Event set once the chunk's upload is queued, [its HIP event])] tell a
+    consumer when each part may be read: engine.TrainJob.run does), otherwise after the worker is done."""
+
+    def __init__(self, future, chunked):
+        self._future, self._chunked = future, chunked
+
+    def init(self):
+        return self._future.result()[0] if self._chunked is None else self._init_ready()
+
+    def _init_ready(self):
+        self._chunked._ure_init_done.wait()
+        if self._chunked._ure_error:
+            self._future.result()                       # re-raises the worker's exception
+        return self._chunked._ure_init
+
+    def perms(self):
+        return self._future.result()[1] if self._chunked is None else self._chunked
+
+    def result(self):
+        return self.init(), self.perms()
+
+
+def shard_draws_async(start_state, n_user, n_item, k, epochs, with_total_test, n_rows, shuffle, threads=0, device=None, want_perms=True,
+                      chunk_epochs=8):
+    """Everything random of ONE Scratch.train call, taken on a worker thread from its own generator positioned at
+    `start_state` (shard_streams): the model init (utils.py:31-40), the per-epoch seeds and the expanded
+    permutations.  The shards of a SISA call are independent streams once their start states are known, so their
+    draws run side by side instead of one after the other.  With a HIP `device` the init tables and the permutations
+    are uploaded on a side stream, the permutations in chunks of epochs so that training starts on the first epochs
+    while the later ones are still being expanded.  -> ShardDraws."""
+    global _SHARD_POOL
+    if _SHARD_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        import os
+        _SHARD_POOL = ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 2) // 2)), thread_name_prefix='ure-shard')
+    from . import _native as nv
+    nv.lib()
+    big = n_rows >= (2 ** 32 - 1) // 20
+    host = on_dev = ready = None
+    on_device = device is not None and torch.device(device).type == 'cuda'
+    if want_perms and shuffle and n_rows > 0 and epochs > 0 and not big:
+        host = POOL.take((epochs, n_rows), torch.int32)            # the pool is not thread safe: taken here
+        if on_device:
+            dev = torch.device(device)
+            on_dev = torch.empty((epochs, n_rows), dtype=torch.int32, device=dev)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
+            on_dev._ure_host = host
+            on_dev._ure_chunks = [(min(epochs, c0 + chunk_epochs), threading.Event(), [None]) for c0 in range(0, epochs, chunk_epochs)]
+            on_dev._ure_init_done, on_dev._ure_init, on_dev._ure_error = threading.Event(), None, False
+
+    def work():
+        try:
+            return body()
+        except BaseException:
+            if on_dev is not None:                                   # never leave a consumer waiting on a chunk
+                on_dev._ure_error = True
+                on_dev._ure_init_done.set()
+                for _, flag, _ in on_dev._ure_chunks:
+                    flag.set()
+            raise
+
+    def body():
+        g = torch.Generator()
+        g.set_state(start_state)
+        init = mf_init(n_user, n_item, k, generator=g)
+        seeds = epoch_seeds(epochs, with_total_test, generator=g)
+        st = None
+        if on_device:
+            # the init tables go up first, on a side stream of this worker
+            dev = torch.device(device)
+            with torch.cuda.device(dev):
+                st = _UPLOAD_STREAMS.get((dev, threading.get_ident()))
+                if st is None:
+                    st = _UPLOAD_STREAMS[(dev, threading.get_ident())] = torch.cuda.Stream(dev)
+                with torch.cuda.stream(st):
+                    up = tuple(t.to(dev) for t in init)
+                    ev0 = torch.cuda.Event()
+                    ev0.record(st)
+            for t in up:
+                t._ure_event = ev0
+            init = up
+        if on_dev is not None:
+            on_dev._ure_init = init
+            on_dev._ure_init_done.set()
+        if not want_perms:
+            return init, None
+        if not shuffle:
+            return init, torch.arange(n_rows, dtype=torch.int32).repeat(epochs, 1)
+        if host is None:
+            return init, epoch_perms(seeds, n_rows, threads)
+        sd = np.asarray(seeds, dtype=np.uint64).astype(np.int64)
+        if on_dev is None:
+            nv.check(nv.lib().ure_host_randperm(sd.ctypes.data, len(sd), n_rows, host.data_ptr(), int(threads or 0)), 'ure_host_randperm')
+            return init, host
+        dev = on_dev.device
+        with torch.cuda.device(dev):
+            st.wait_event(ready)
+        c0 = 0
+        for c1, flag, slot in on_dev._ure_chunks:
+            nv.check(nv.lib().ure_host_randperm(sd[c0:c1].ctypes.data, c1 - c0, n_rows, host[c0:c1].data_ptr(), int(threads or 0)), 'ure_host_randperm')
+            with torch.cuda.device(dev), torch.cuda.stream(st):
+                on_dev[c0:c1].copy_(host[c0:c1], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(st)
+            slot[0] = ev
+            flag.set()
+            c0 = c1
+        return init, on_dev
+    return ShardDraws(_SHARD_POOL.submit(work), on_dev)
 
 
 def seed_all(seed):
