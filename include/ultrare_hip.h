@@ -257,6 +257,16 @@ int ure_ot_centroids(const float *X, const int32_t *label, int64_t n, int k, int
  * the plan in units of 1/(n*k); total_cost (optional) the objective <G, M>. */
 int ure_ot_assign(const float *dist_host, int64_t n, int k, int32_t *label_host,
                   int32_t *plan_nk, double *total_cost);
+/* The same exact LP from a warm start.  ure_ot_potentials: cluster potentials pi[k] (HOST, in: where to start -- zeros or
+ * the previous round's; out: the iterate with the smallest imbalance) by `iters` sign-based steps of dual ascent on the
+ * device cost matrix dist [k][n] (k <= 256; otherwise, or with iters == 0, pi = 0 and the solver starts cold);
+ * *misplaced (optional) = points that imbalance leaves to move; synchronises `stream`.  ure_ot_assign_warm: every point starts on the cluster of its
+ * cheapest reduced cost cost - pi, then successive shortest paths as in ure_ot_assign -- the result is the exact
+ * optimum for any pi, only the number of augmentations (optional output) depends on it; pi == NULL or a poor start
+ * falls back to ure_ot_assign.                                                                              */
+int ure_ot_potentials(const float *dist, int64_t n, int k, int iters, double *pi_host, int64_t *misplaced, void *stream);
+int ure_ot_assign_warm(const float *dist_host, int64_t n, int k, const double *pi, int32_t *label_host, int32_t *plan_nk,
+                       double *total_cost, int64_t *augmentations);
 
 /* ---------------------------------------------------------------------------
  * Comparison clusterers (utils.py:354-418: k-means / balanced k-means on the user embedding;

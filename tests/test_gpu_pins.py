@@ -293,3 +293,39 @@ def test_ot_rounds_k16_fractional_case(ot_ml1m):
             lab_d = torch.from_numpy(labels[r].astype(np.int32)).cuda()
             nv.check(L.ure_ot_centroids(nv.ptr(Xd), nv.ptr(lab_d), n, k, d, nv.ptr(cent_d), nv.ptr(counts_d), st), 'ure_ot_centroids')
             assert np.array_equal(cent_d.cpu().numpy(), cents[r + 1])
+
+
+@pytest.mark.parametrize('n,k,d', [(1000, 3, 8), (777, 5, 20), (5000, 7, 64), (4099, 32, 128), (300, 4, 200), (257, 2, 256), (63, 2, 4)])
+def test_ot_cost_kernel_bit_equal_numpy_order(n, k, d):
+    """ure_ot_cost (64-row LDS tiles, lane = row, wave = centroid; the untiled kernel for d = 256) against
+    utils.py:637 evaluated by numpy: every bit of every distance, ragged last tile included."""
+    from ultrare_amd import _native as nv
+    rs = np.random.RandomState(n + d)
+    X = rs.standard_normal((n, d)).astype(np.float32)
+    C = X[rs.choice(n, k, replace=False)] + rs.standard_normal((k, d)).astype(np.float32) * 0.1
+    want = ((X - C[:, np.newaxis]) ** 2).sum(axis=2)
+    Xd, Cd = torch.from_numpy(X).cuda(), torch.from_numpy(C).cuda()
+    dist_d = torch.empty(k, n, dtype=torch.float32, device='cuda')
+    nv.check(nv.lib().ure_ot_cost(nv.ptr(Xd), nv.ptr(Cd), n, k, d, nv.ptr(dist_d), nv.stream_handle()), 'ure_ot_cost')
+    assert np.array_equal(dist_d.cpu().numpy(), want)
+    assert np.array_equal(O.ot_cost(X, C), want)
+
+
+def test_ot_potentials_balance_the_loads(ot_ml1m):
+    """ure_ot_potentials (dual ascent on the device): the returned potentials leave only a handful of points to move,
+    from a start of thousands; the exact solver then finishes in a few augmentations and returns the cold solver's plan."""
+    import ctypes
+    from ultrare_amd import _native as nv
+    g, X = ot_ml1m
+    n, k = len(X), 16
+    dist = O.ot_cost(X, g['k16_round_centroids'][1])
+    dist_d = torch.from_numpy(dist).cuda()
+    pi = np.zeros(k)
+    mis = ctypes.c_int64()
+    nv.check(nv.lib().ure_ot_potentials(nv.ptr(dist_d), n, k, 400, pi.ctypes.data, ctypes.byref(mis), nv.stream_handle()), 'ure_ot_potentials')
+    start = np.abs(np.bincount(np.argmin(dist, axis=0), minlength=k) - n / k).sum() / 2
+    after = np.abs(np.bincount(np.argmin(dist.T.astype(np.float64) - pi, axis=1), minlength=k) - n / k).sum() / 2
+    assert start > 300 and after <= 25 and abs(mis.value - after) <= 2, (start, after, mis.value)
+    label, plan, obj, aug = nv.ot_assign_warm(dist, pi)
+    cold_label, cold_plan, cold_obj = nv.ot_assign(dist)
+    assert 0 <= aug <= 100 and obj == cold_obj and np.array_equal(plan, cold_plan)

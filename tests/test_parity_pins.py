@@ -261,3 +261,44 @@ def test_torch_port_base_test_matches_reference_vectors():
         models = [Table({(int(a), int(b)): float(s) for a, b, s in zip(u, i, sc[m])}) for m in range(sc.shape[0])]
         ld = DataLoader(T._Triples(u, i, r), batch_size=int(g[f'c{c}_batch']), shuffle=False)
         np.testing.assert_allclose(T.base_test(ld, models), g[f'c{c}_expect'], rtol=1e-9)
+
+
+# ------------------------------------------------------------------------------------ warm-started exact solver
+@pytest.mark.parametrize('n,k,seed', [(600, 5, 0), (640, 8, 1), (1000, 7, 2), (3001, 16, 3), (50, 50, 4), (9, 2, 5)])
+def test_warm_solver_is_exact_for_any_potentials(n, k, seed):
+    """ure_ot_assign_warm: whatever potentials it starts from (good ones, zeros, noise, garbage) the result is the
+    exact optimum -- same objective and labels as the cold solver, integer certificate -- only the number of
+    augmentations differs."""
+    from ultrare_amd import _native as nv
+    rs = np.random.RandomState(seed)
+    X = rs.standard_normal((n, 6)).astype(np.float32)
+    C = X[rs.choice(n, k, replace=False)]
+    dist = O.ot_cost(X, C)
+    cold_label, cold_plan, cold_obj = nv.ot_assign(dist)
+    assert O.ot_certificate(dist, cold_plan)['optimal']
+    D = dist.T.astype(np.float64)
+    pi = np.zeros(k)
+    for it in range(60):                                      # a few steps of the dual ascent the device does
+        L = np.bincount(np.argmin(D - pi, axis=1), minlength=k)
+        pi -= 0.5 * (D.std() / (n / k)) / (1 + it / 10) * (L - n / k)
+    for name, p in (('ascent', pi), ('zeros', np.zeros(k)), ('noise', rs.standard_normal(k) * D.std()), ('huge', np.full(k, 1e30)),
+                    ('nan', np.full(k, np.nan)), ('none', None)):
+        label, plan, obj, aug = nv.ot_assign_warm(dist, p)
+        cert = O.ot_certificate(dist, plan)
+        assert cert['feasible'] and cert['optimal'], name
+        assert obj == cold_obj, name
+        if not cert['tight_cycles']:                          # unique optimum: the plan itself is determined
+            assert np.array_equal(plan, cold_plan) and np.array_equal(label, cold_label), name
+        assert aug >= -1
+
+
+def test_warm_solver_falls_back_when_the_start_is_poor():
+    from ultrare_amd import _native as nv
+    rs = np.random.RandomState(9)
+    n, k = 40000, 8
+    dist = rs.rand(k, n).astype(np.float32)
+    dist[0] *= 0.01                                           # every point's cheapest cluster is 0: 35,000 points to move
+    label, plan, obj, aug = nv.ot_assign_warm(dist, np.zeros(k))
+    assert aug == -1                                          # the cold (heap) path ran
+    assert np.bincount(label, minlength=k).tolist() == [n // k] * k
+    assert O.ot_certificate(dist, plan)['optimal']

@@ -76,6 +76,8 @@ _PROTOTYPES = {
     'ure_kmeans_centroids': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     'ure_host_kmeans_assign': (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, ctypes.POINTER(ctypes.c_double)]),
     'ure_ot_assign': (ctypes.c_int, [_vp, _i64, ctypes.c_int, _vp, _vp, ctypes.POINTER(ctypes.c_double)]),
+    'ure_ot_potentials': (ctypes.c_int, [_vp, _i64, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_i64), _vp]),
+    'ure_ot_assign_warm': (ctypes.c_int, [_vp, _i64, ctypes.c_int, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64)]),
 }
 EXPORTS = tuple(_PROTOTYPES)
 
@@ -145,6 +147,20 @@ def ot_assign(dist_kn):
     check(lib().ure_ot_assign(dist_kn.ctypes.data, n, k, label.ctypes.data, plan.ctypes.data, ctypes.byref(obj)),
           'ure_ot_assign')
     return label, plan, obj.value
+
+
+def ot_assign_warm(dist_kn, pi, want_plan=True):
+    """ure_ot_assign_warm: as ot_assign, started from the cluster potentials pi (float64 [k], or None = cold).
+    -> (label, plan or None, objective, augmentations made; -1 = the cold solver ran)."""
+    dist_kn = np.ascontiguousarray(dist_kn, dtype=np.float32)
+    k, n = dist_kn.shape
+    label = np.empty(n, dtype=np.int32)
+    plan = np.empty((n, k), dtype=np.int32) if want_plan else None
+    obj, aug = ctypes.c_double(), _i64()
+    pi = None if pi is None else np.ascontiguousarray(pi, dtype=np.float64)
+    check(lib().ure_ot_assign_warm(dist_kn.ctypes.data, n, k, None if pi is None else pi.ctypes.data, label.ctypes.data,
+                                   plan.ctypes.data if want_plan else None, ctypes.byref(obj), ctypes.byref(aug)), 'ure_ot_assign_warm')
+    return label, plan, obj.value, aug.value
 
 
 def read_csv(path, threads=0):

@@ -16,6 +16,9 @@
 // (|x|^2 - 2 x.c + |c|^2 rounds differently and would break label parity).
 #include "ure_internal.h"
 
+#include <cmath>
+#include <cstring>
+
 namespace ure {
 
 // numpy pairwise_sum for n <= 128 contiguous fp32 terms t_j = (x_j - c_j)^2.
@@ -69,6 +72,120 @@ __global__ __launch_bounds__(kBlock) void ot_cost_kernel(const float *__restrict
         const int64_t i = t % n;
         const int c = (int)(t / n);
         dist[t] = np_pairwise(X + i * d, C + (size_t)c * d, d);
+    }
+}
+
+// The same values with coalesced HBM traffic: a workgroup stages 64 rows of X in LDS (rows padded by one float:
+// lanes that read one column of 64 different rows hit 64 different banks), then lane = row, wave = centroid
+// (c = wave, wave + 4, ...): the centroid's values are wave-uniform, the row is read from LDS in numpy's order,
+// and the 64 results of a wave go out as one 256-byte store.  X is read from HBM once instead of once per
+// centroid with a stride of d floats per lane (MI355X_MICROARCH.md: 64 lanes in 64 rows, ~17x below peak).
+constexpr int kCostRows = 64;
+__global__ __launch_bounds__(kBlock) void ot_cost_tiled_kernel(const float *__restrict__ X, const float *__restrict__ C, int64_t n, int k, int d,
+                                                               float *__restrict__ dist)
+{
+    extern __shared__ float tile[];                       // [kCostRows][d + 1]
+    const int ld = d + 1;
+    const int64_t i0 = (int64_t)blockIdx.x * kCostRows;
+    const int rows = (int)min<int64_t>(kCostRows, n - i0);
+    for (int t = threadIdx.x; t < rows * d; t += kBlock) tile[(t / d) * ld + (t % d)] = X[i0 * d + t];     // contiguous read
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane >= rows) return;
+    const float *x = tile + lane * ld;
+    for (int c = wave; c < k; c += kWavesPerBlock) dist[(size_t)c * n + i0 + lane] = np_pairwise(x, C + (size_t)c * d, d);
+}
+
+// ---- warm start of the exact solver: potentials of the clusters by dual subgradient ascent ---------------
+// The transportation LP's dual is max_pi sum_i min_c (cost[i][c] - pi[c]) + (n / k) sum_c pi[c]; a subgradient in
+// pi[c] is (n / k) - load_c(pi), load_c = the number of points whose cheapest reduced cost is c.  A hundred
+// sign-based steps against the imbalance load_c - n / k bring the loads within a few points of balance (measured
+// at n = 162,000, k = 32: 53,342 misplaced points -> 10..26), so the exact successive-shortest-path solver that follows
+// (ot_solver.cpp) has tens of augmentations to make instead of ~94,000.  This is only a starting point: the
+// solver's result is the exact optimum whatever the potentials are.
+constexpr int kPotMaxK = 256;
+struct pot_state {
+    double gap_sum;              // sum over points of (second cheapest - cheapest) cost
+    unsigned int loads[kPotMaxK];
+    float pi[kPotMaxK];
+    float step[kPotMaxK];        // per-cluster step (sign-based: robust to the scale of the costs)
+    float prev[kPotMaxK];        // sign of the cluster's previous imbalance
+    float best_pi[kPotMaxK];     // the potentials with the smallest imbalance seen so far ...
+    float best_imb;              // ... and that imbalance, sum_c |load_c - n / k|
+    int it;
+};
+
+__global__ __launch_bounds__(kBlock) void ot_pot_step_kernel(const float *__restrict__ dist, int64_t n, int k, pot_state *__restrict__ st, int measure_gap)
+{
+    __shared__ float pi[kPotMaxK];
+    __shared__ unsigned int hist[kPotMaxK];
+    __shared__ double gsum[kWavesPerBlock];
+    for (int c = threadIdx.x; c < k; c += kBlock) { pi[c] = st->pi[c]; hist[c] = 0; }
+    __syncthreads();
+    double gap = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        float best = 3.4e38f, second = 3.4e38f;
+        int arg = 0;
+        for (int c = 0; c < k; ++c) {
+            const float v = dist[(size_t)c * n + i] - pi[c];
+            if (v < best) { second = best; best = v; arg = c; }
+            else if (v < second) second = v;
+        }
+        atomicAdd(&hist[arg], 1u);
+        gap += (double)(second - best);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < k; c += kBlock)
+        if (hist[c]) atomicAdd(&st->loads[c], hist[c]);
+    if (measure_gap) {
+        for (int o = 32; o > 0; o >>= 1) gap += __shfl_xor(gap, o, kWave);
+        if ((threadIdx.x & 63) == 0) gsum[threadIdx.x >> 6] = gap;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < kWavesPerBlock; ++w) t += gsum[w];
+            atomicAdd(&st->gap_sum, t);
+        }
+    }
+}
+
+__global__ void ot_pot_update_kernel(int64_t n, int k, pot_state *__restrict__ st, int iters)
+{
+    // Sign-based steps (Rprop): a cluster's step grows by 1.3 while its imbalance keeps its sign and halves when the
+    // sign flips; near balance the move is scaled down with the relative imbalance, and over the last third of the
+    // iterations every step shrinks by 3 % per iteration.  A plain subgradient step eta_t (load - n / k) oscillated for
+    // centroids that sit close together (their cost gaps are far below the mean gap that sets eta).  The iterate with
+    // the smallest imbalance is the one handed to the solver.
+    __shared__ float red[kPotMaxK];
+    const int c = threadIdx.x;
+    const float target = (float)n / (float)k;
+    const int it = st->it;
+    const float g = c < k ? (float)st->loads[c] - target : 0.f;
+    red[c] = fabsf(g);
+    __syncthreads();
+    for (int o = kPotMaxK / 2; o > 0; o >>= 1) {
+        if (c < o) red[c] += red[c + o];
+        __syncthreads();
+    }
+    const float imb = red[0];
+    const bool better = it == 0 || imb < st->best_imb;
+    __syncthreads();
+    if (c < k) {
+        if (better) st->best_pi[c] = st->pi[c];                  // the potentials that produced these loads
+        if (it == 0) { st->step[c] = 0.05f * (float)(st->gap_sum / (double)n); st->prev[c] = 0.f; }
+        const float sgn = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
+        const float same = sgn * st->prev[c];
+        float step = st->step[c];
+        step *= same > 0.f ? 1.3f : (same < 0.f ? 0.5f : 1.0f);
+        if (3 * it > 2 * iters) step *= 0.97f;
+        st->pi[c] -= step * sgn * fminf(1.0f, fabsf(g) / (0.02f * target) + 0.05f);
+        st->step[c] = step;
+        st->prev[c] = sgn;
+        st->loads[c] = 0;
+    }
+    if (c == 0) {
+        if (better) st->best_imb = imb;
+        st->it = it + 1;
     }
 }
 
@@ -144,10 +261,45 @@ extern "C" {
 int ure_ot_cost(const float *X, const float *C, int64_t n, int k, int d, float *dist, void *stream)
 {
     URE_ARG(X && C && dist && n > 0 && k > 0 && d > 0 && d <= 256);
-    const int64_t total = n * k;
-    const unsigned blocks = (unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 256 * 16);
-    hipLaunchKernelGGL(ot_cost_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), X, C, n, k, d, dist);
+    const size_t lds = (size_t)kCostRows * (d + 1) * sizeof(float);
+    if (lds <= 64 * 1024 - 256 && (n + kCostRows - 1) / kCostRows <= 0x7fffffff) {
+        const unsigned blocks = (unsigned)((n + kCostRows - 1) / kCostRows);
+        hipLaunchKernelGGL(ot_cost_tiled_kernel, dim3(blocks), dim3(kBlock), lds, static_cast<hipStream_t>(stream), X, C, n, k, d, dist);
+    } else {      // rows too wide for the 64-row LDS tile: one thread per (point, centroid)
+        const int64_t total = n * k;
+        const unsigned blocks = (unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 256 * 16);
+        hipLaunchKernelGGL(ot_cost_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), X, C, n, k, d, dist);
+    }
     URE_HIP(hipGetLastError());
+    return 0;
+}
+
+int ure_ot_potentials(const float *dist, int64_t n, int k, int iters, double *pi_host, int64_t *misplaced, void *stream)
+{
+    URE_ARG(dist && pi_host && n > 0 && k > 0 && iters >= 0);
+    if (misplaced) *misplaced = -1;
+    if (k > kPotMaxK || k < 2 || iters == 0) {                   // no warm start: the solver starts cold
+        for (int c = 0; c < k; ++c) pi_host[c] = 0.0;
+        return 0;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    pot_state *dev = nullptr;
+    pot_state host;
+    std::memset(&host, 0, sizeof(host));
+    for (int c = 0; c < k; ++c) host.pi[c] = std::isfinite(pi_host[c]) ? (float)pi_host[c] : 0.f;      // start: the caller's (the previous round's)
+    URE_HIP(hipMalloc(&dev, sizeof(pot_state)));
+    hipError_t e = hipMemcpyAsync(dev, &host, sizeof(pot_state), hipMemcpyHostToDevice, st);
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 1024);
+    for (int it = 0; it <= iters && e == hipSuccess; ++it) {      // one more evaluation so that the last iterate is judged too
+        hipLaunchKernelGGL(ot_pot_step_kernel, dim3(blocks), dim3(kBlock), 0, st, dist, n, k, dev, it == 0 ? 1 : 0);
+        hipLaunchKernelGGL(ot_pot_update_kernel, dim3(1), dim3(kPotMaxK), 0, st, n, k, dev, iters);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, dev, sizeof(pot_state), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail((int)e, "ure_ot_potentials: %s", hipGetErrorString(e));
+    for (int c = 0; c < k; ++c) pi_host[c] = (double)host.best_pi[c];
+    if (misplaced) *misplaced = (int64_t)(host.best_imb / 2.0f + 0.5f);
     return 0;
 }
 

@@ -57,20 +57,19 @@ constexpr int64_t kInf = std::numeric_limits<int64_t>::max() / 4;
 
 }  // namespace
 
-extern "C" int ure_ot_assign(const float *dist, int64_t n, int k, int32_t *label, int32_t *plan_nk, double *total_cost)
+// fp32 costs [k][n] -> int64 [n][k] on a common power-of-two scale (exact unless the dynamic range is absurd)
+static int to_fixed_point(const float *dist, int64_t n, int k, std::vector<int64_t> &cost, int *shift_out)
 {
-    if (!dist || !label || n <= 0 || k <= 0 || k > 4096 || n > (int64_t)1 << 31)
-        return ure::fail(-1, "ure_ot_assign: bad arguments (n=%lld k=%d)", (long long)n, k);
-
-    // ---- fixed-point scale -------------------------------------------------------
     int e_min = std::numeric_limits<int>::max(), e_max = std::numeric_limits<int>::min();
     for (int64_t t = 0; t < n * k; ++t) {
         const float v = dist[t];
         if (!(v >= 0.0f) || std::isinf(v)) return ure::fail(-1, "ure_ot_assign: cost %lld is negative, NaN or inf", (long long)t);
         if (v == 0.0f) continue;
-        int e;
-        (void)std::frexp(v, &e);                 // v = m * 2^e, m in [0.5, 1): ulp(v) = 2^(e-24)
-        e_min = std::min(e_min, e - 24);
+        uint32_t bits;
+        __builtin_memcpy(&bits, &v, 4);
+        int e = (int)(bits >> 23) - 126;          // v = m * 2^e, m in [0.5, 1)  (frexp convention; subnormals: below)
+        if ((bits >> 23) == 0) (void)std::frexp(v, &e);
+        e_min = std::min(e_min, e - 24);          // ulp(v) = 2^(e-24)
         e_max = std::max(e_max, e);
     }
     int shift = 0;                               // cost_int = v * 2^shift
@@ -81,9 +80,25 @@ extern "C" int ure_ot_assign(const float *dist, int64_t n, int k, int32_t *label
         shift = -e_min;
         if (e_max + shift > budget) shift = budget - e_max;       // absurd dynamic range: round the tiniest costs
     }
-    std::vector<int64_t> cost((size_t)n * k);
-    for (int64_t i = 0; i < n; ++i)
-        for (int c = 0; c < k; ++c) cost[(size_t)i * k + c] = (int64_t)std::llround(std::ldexp((double)dist[(size_t)c * n + i], shift));
+    cost.resize((size_t)n * k);
+    const double scale = std::ldexp(1.0, shift);
+    for (int c = 0; c < k; ++c) {
+        const float *row = dist + (size_t)c * n;
+        for (int64_t i = 0; i < n; ++i) cost[(size_t)i * k + c] = (int64_t)std::llround((double)row[i] * scale);
+    }
+    *shift_out = shift;
+    return 0;
+}
+
+extern "C" int ure_ot_assign(const float *dist, int64_t n, int k, int32_t *label, int32_t *plan_nk, double *total_cost)
+{
+    if (!dist || !label || n <= 0 || k <= 0 || k > 4096 || n > (int64_t)1 << 31)
+        return ure::fail(-1, "ure_ot_assign: bad arguments (n=%lld k=%d)", (long long)n, k);
+
+    // ---- fixed-point scale -------------------------------------------------------
+    std::vector<int64_t> cost;
+    int shift = 0;
+    if (int rc = to_fixed_point(dist, n, k, cost, &shift)) return rc;
 
     // ---- initial pseudo-flow -----------------------------------------------------
     std::vector<int32_t> x((size_t)n * k, 0);
@@ -195,5 +210,180 @@ extern "C" int ure_ot_assign(const float *dist, int64_t n, int k, int32_t *label
     }
     if (plan_nk) std::copy(x.begin(), x.end(), plan_nk);
     if (total_cost) *total_cost = (double)(obj / ((long double)n * (long double)k));
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// The same LP from a warm start.  `pi` = potentials of the clusters (any values: ure_ot_potentials finds good
+// ones on the GPU, the previous round's serve too).  Every point starts on the cluster of its cheapest REDUCED
+// cost cost[i][c] - pi[c]: that pseudo-flow is optimal for its own loads (the residual graph has no negative
+// cycle: around a cycle the potentials cancel), which is all successive shortest paths needs.  With loads a few
+// points away from balance only tens of augmentations remain, so the cluster graph's edge weights
+//     w[a][b] = min over points i holding units in a of cost[i][b] - cost[i][a]
+// are kept as plain (min, argmin) pairs and a cluster's row is recomputed from its member list when its argmin
+// leaves -- O(n) per augmentation, against the O(n k) heap entries of the cold start.  Falls back to the cold
+// start when the warm start is poor (more than `kWarmMaxMoves` points to move).
+// ---------------------------------------------------------------------------------------------------
+extern "C" int ure_ot_assign_warm(const float *dist, int64_t n, int k, const double *pi, int32_t *label, int32_t *plan_nk,
+                                  double *total_cost, int64_t *augmentations)
+{
+    constexpr int64_t kWarmMaxMoves = 2048;
+    if (!dist || !label || n <= 0 || k <= 0 || k > 4096 || n > (int64_t)1 << 31)
+        return ure::fail(-1, "ure_ot_assign_warm: bad arguments (n=%lld k=%d)", (long long)n, k);
+    if (augmentations) *augmentations = -1;
+    if (!pi) return ure_ot_assign(dist, n, k, label, plan_nk, total_cost);
+    std::vector<int64_t> cost;
+    int shift = 0;
+    if (int rc = to_fixed_point(dist, n, k, cost, &shift)) return rc;
+    std::vector<int64_t> pot(k);
+    const double scale = std::ldexp(1.0, shift);
+    for (int c = 0; c < k; ++c) {
+        if (!std::isfinite(pi[c]) || std::fabs(pi[c]) * scale > 4e18 / (4.0 * k + 4)) return ure_ot_assign(dist, n, k, label, plan_nk, total_cost);
+        pot[c] = (int64_t)std::llround(pi[c] * scale);
+    }
+
+    // ---- initial pseudo-flow: cheapest reduced cost (ties: lowest cluster) ---------------------------
+    std::vector<int32_t> x((size_t)n * k, 0);
+    std::vector<int64_t> load(k, 0);
+    std::vector<std::vector<int32_t>> members(k);
+    for (int c = 0; c < k; ++c) members[c].reserve((size_t)(n / k + n / (4 * k) + 16));
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t *ci = &cost[(size_t)i * k];
+        int best = 0;
+        for (int c = 1; c < k; ++c)
+            if (ci[c] - pot[c] < ci[best] - pot[best]) best = c;
+        x[(size_t)i * k + best] = k;
+        load[best] += k;
+        members[best].push_back((int32_t)i);
+    }
+    int64_t moves = 0;
+    for (int c = 0; c < k; ++c) moves += load[c] > n ? (load[c] - n + k - 1) / k : 0;
+    if (moves > kWarmMaxMoves) return ure_ot_assign(dist, n, k, label, plan_nk, total_cost);
+
+    std::vector<int64_t> w((size_t)k * k, kInf);
+    std::vector<int32_t> arg((size_t)k * k, -1);
+    auto rescan_row = [&](int a) {
+        int64_t *wa = &w[(size_t)a * k];
+        int32_t *ga = &arg[(size_t)a * k];
+        for (int b = 0; b < k; ++b) { wa[b] = kInf; ga[b] = -1; }
+        auto &mem = members[a];
+        size_t keep = 0;
+        for (size_t q = 0; q < mem.size(); ++q) {
+            const int32_t i = mem[q];
+            if (x[(size_t)i * k + a] <= 0) continue;             // left the cluster: dropped from the list here
+            mem[keep++] = i;
+            const int64_t *ci = &cost[(size_t)i * k];
+            const int64_t base = ci[a];
+            for (int b = 0; b < k; ++b) {
+                const int64_t dlt = ci[b] - base;
+                if (dlt < wa[b] || (dlt == wa[b] && i < ga[b])) { wa[b] = dlt; ga[b] = i; }      // ties: lowest point index
+            }
+        }
+        mem.resize(keep);
+        wa[a] = kInf;
+        ga[a] = -1;
+    };
+    for (int a = 0; a < k; ++a) rescan_row(a);
+    // one edge a -> b again from a's member list (the point that realised it has left a)
+    auto rescan_edge = [&](int a, int b) {
+        int64_t best = kInf;
+        int32_t who = -1;
+        for (const int32_t i : members[a]) {
+            if (x[(size_t)i * k + a] <= 0) continue;
+            const int64_t dlt = cost[(size_t)i * k + b] - cost[(size_t)i * k + a];
+            if (dlt < best || (dlt == best && i < who)) { best = dlt; who = i; }
+        }
+        w[(size_t)a * k + b] = best;
+        arg[(size_t)a * k + b] = who;
+    };
+
+    std::vector<int64_t> dst(k);
+    std::vector<int> pred(k), path;
+    std::vector<char> dirty(k, 0);
+    int64_t n_aug = 0;
+    for (;;) {
+        bool any_excess = false;
+        for (int c = 0; c < k; ++c) any_excess = any_excess || load[c] > n;
+        if (!any_excess) break;
+        for (int a = 0; a < k; ++a) {
+            if (!dirty[a]) continue;
+            // only the edges whose argmin point no longer holds units in a; the member list is compacted now and then
+            if (members[a].size() > 2 * (size_t)(load[a] / k + 64)) rescan_row(a);
+            else
+                for (int b = 0; b < k; ++b) {
+                    const int32_t i = arg[(size_t)a * k + b];
+                    if (b != a && i >= 0 && x[(size_t)i * k + a] <= 0) rescan_edge(a, b);
+                }
+            dirty[a] = 0;
+        }
+        for (int c = 0; c < k; ++c) { dst[c] = load[c] > n ? 0 : kInf; pred[c] = -1; }
+        for (int pass = 0; pass < k; ++pass) {
+            bool changed = false;
+            for (int a = 0; a < k; ++a) {
+                if (dst[a] >= kInf) continue;
+                const int64_t *wa = &w[(size_t)a * k];
+                for (int b = 0; b < k; ++b) {
+                    if (b == a || wa[b] >= kInf) continue;
+                    if (dst[a] + wa[b] < dst[b]) { dst[b] = dst[a] + wa[b]; pred[b] = a; changed = true; }
+                }
+            }
+            if (!changed) break;
+        }
+        int tgt = -1;
+        for (int c = 0; c < k; ++c)
+            if (load[c] < n && dst[c] < kInf && (tgt < 0 || dst[c] < dst[tgt])) tgt = c;
+        if (tgt < 0) return ure::fail(-2, "ure_ot_assign_warm: no augmenting path (internal error)");
+        path.clear();
+        for (int c = tgt; c >= 0; c = pred[c]) {
+            path.push_back(c);
+            if ((int)path.size() > k) return ure::fail(-2, "ure_ot_assign_warm: predecessor cycle (internal error)");
+        }
+        std::reverse(path.begin(), path.end());
+        const int src = path.front();
+        int64_t delta = std::min(load[src] - n, n - load[tgt]);
+        for (size_t e = 0; e + 1 < path.size(); ++e) {
+            const int a = path[e], b = path[e + 1];
+            delta = std::min<int64_t>(delta, x[(size_t)arg[(size_t)a * k + b] * k + a]);
+        }
+        if (delta <= 0) return ure::fail(-2, "ure_ot_assign_warm: zero augmentation (internal error)");
+        for (size_t e = 0; e + 1 < path.size(); ++e) {
+            const int a = path[e], b = path[e + 1];
+            const int64_t i = arg[(size_t)a * k + b];
+            int32_t &xa = x[(size_t)i * k + a];
+            int32_t &xb = x[(size_t)i * k + b];
+            xa -= (int32_t)delta;
+            if (xb == 0) {                                       // the point joins b: it may lower b's outgoing edges
+                members[b].push_back((int32_t)i);
+                const int64_t *ci = &cost[(size_t)i * k];
+                for (int c = 0; c < k; ++c) {
+                    if (c == b) continue;
+                    const int64_t dlt = ci[c] - ci[b];
+                    int64_t &wbc = w[(size_t)b * k + c];
+                    int32_t &gbc = arg[(size_t)b * k + c];
+                    if (dlt < wbc || (dlt == wbc && (int32_t)i < gbc)) { wbc = dlt; gbc = (int32_t)i; }
+                }
+            }
+            xb += (int32_t)delta;
+            if (xa == 0) dirty[a] = 1;                           // it may have been the argmin of any edge out of a
+        }
+        load[src] -= delta;
+        load[tgt] += delta;
+        ++n_aug;
+    }
+
+    long double obj = 0.0L;
+    for (int64_t i = 0; i < n; ++i) {
+        int best = 0;
+        for (int c = 0; c < k; ++c) {
+            const int32_t v = x[(size_t)i * k + c];
+            if (v > x[(size_t)i * k + best]) best = c;         // np.argmax: first maximum
+            if (v) obj += (long double)v * (long double)dist[(size_t)c * n + i];
+        }
+        label[i] = best;
+    }
+    if (plan_nk) std::copy(x.begin(), x.end(), plan_nk);
+    if (total_cost) *total_cost = (double)(obj / ((long double)n * (long double)k));
+    if (augmentations) *augmentations = n_aug;
     return 0;
 }

@@ -27,6 +27,7 @@ from ..read import as_loader
 from ..rng import seed_all  # noqa: F401  (re-exported under the reference's name)
 
 STD = 1
+OT_WARM_ITERS = 400      # dual-ascent steps that warm-start the exact OT solver (ure_ot_potentials)
 
 
 class MF(nn.Module):
@@ -132,13 +133,17 @@ def timefn(fn):
     return measure_time
 
 
-def _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d):
+def _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi=None):
     """One round of utils.py:637-648 on the device + the exact host LP."""
     L, st = nv.lib(), nv.stream_handle()
     cd = torch.from_numpy(np.ascontiguousarray(centroid, dtype=np.float32)).to(Xd.device)
     nv.check(L.ure_ot_cost(nv.ptr(Xd), nv.ptr(cd), n, k, d, nv.ptr(dist_d), st), 'ure_ot_cost')
+    # cluster potentials by dual ascent on the device (a warm start only: the LP below is solved exactly for any
+    # potentials), while the cost matrix travels to the host
+    pi = np.zeros(k, dtype=np.float64) if pi is None else pi         # in: the previous round's, out: this round's
+    nv.check(L.ure_ot_potentials(nv.ptr(dist_d), n, k, OT_WARM_ITERS, pi.ctypes.data, None, st), 'ure_ot_potentials')
     dist = dist_d.cpu().numpy()                                       # [k, n] fp32 (synchronises)
-    label, _, _ = nv.ot_assign(dist)                                  # exact EMD + argmax (host)
+    label, _, _, _ = nv.ot_assign_warm(dist, pi, want_plan=False)     # exact EMD + argmax (host)
     label_d.copy_(torch.from_numpy(label))
     nv.check(L.ure_ot_centroids(nv.ptr(Xd), nv.ptr(label_d), n, k, d, nv.ptr(cent_d), nv.ptr(counts_d), st),
              'ure_ot_centroids')
@@ -160,8 +165,9 @@ def ot_cluster(X, k, max_iters=10):
     label_d = torch.empty(n, dtype=torch.int32, device=dev)
     cent_d = torch.empty(k, d, dtype=torch.float32, device=dev)
     counts_d = torch.empty(k, dtype=torch.int32, device=dev)
+    pi = np.zeros(k, dtype=np.float64)
     for _ in range(max_iters):
-        dist, label, new_centroid = _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d)
+        dist, label, new_centroid = _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi)
         inertia = np.min(dist, axis=0).sum()
         if np.allclose(centroid, new_centroid):
             break
