@@ -245,6 +245,10 @@ int ure_merge_rows(float *dst, const float *src, const int64_t *rows, int64_t n_
 /* utils.py:637: dist[c][i] = sum_j (X[i][j] - C[c][j])^2 in numpy's fp32 pairwise
  * order (bit-exact), any 1 <= d <= 256. */
 int ure_ot_cost(const float *X, const float *C, int64_t n, int k, int d, float *dist, void *stream);
+/* The same matrix as |x|^2 - 2 x.c + |c|^2 with the contraction on the matrix cores (v_mfma_f32_32x32x2_f32, fp32 in and
+ * out).  It rounds differently from utils.py:637, so it is NOT the arithmetic of record: an optional fast path whose labels
+ * the host cross-checks against ure_ot_cost's every round (method/utils.py::ot_cluster with URE_OT_MFMA=1).          */
+int ure_ot_cost_mfma(const float *X, const float *C, int64_t n, int k, int d, float *dist, void *stream);
 /* utils.py:648: C[c] = mean of the rows with label c, fp32 sequential in ascending
  * row id then one division by the count (bit-exact).  counts [k] receives sizes. */
 int ure_ot_centroids(const float *X, const int32_t *label, int64_t n, int k, int d, float *C,

@@ -133,6 +133,11 @@ void ure_oracle_merge_rows(float *dst, const float *src, const int64_t *rows, in
  * for bit for d in {16,20,32,64,128}. */
 static float np_pairwise_f32(const float *a, int32_t n)
 {
+    if (n > 128) {          /* numpy: runs longer than PW_BLOCKSIZE are split in two, the first half a multiple of 8 */
+        int32_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_f32(a, n2) + np_pairwise_f32(a + n2, n - n2);
+    }
     if (n < 8) {
         float res = 0.0f;
         for (int32_t i = 0; i < n; ++i) res += a[i];
@@ -148,10 +153,11 @@ static float np_pairwise_f32(const float *a, int32_t n)
     return res;
 }
 
-/* dist[c][i] = sum_j (X[i][j] - C[c][j])^2   (utils.py:637), d <= 128.  bit-exact. */
+/* dist[c][i] = sum_j (X[i][j] - C[c][j])^2   (utils.py:637), d <= 4096.  bit-exact. */
 void ure_oracle_ot_cost(const float *X, const float *C, int64_t n, int32_t k, int32_t d, float *dist /* [k][n] */)
 {
-    float tmp[128];
+    float tmp[4096];
+    if (d > 4096) return;
     for (int32_t c = 0; c < k; ++c)
         for (int64_t i = 0; i < n; ++i) {
             for (int32_t j = 0; j < d; ++j) {

@@ -329,3 +329,37 @@ def test_ot_potentials_balance_the_loads(ot_ml1m):
     label, plan, obj, aug = nv.ot_assign_warm(dist, pi)
     cold_label, cold_plan, cold_obj = nv.ot_assign(dist)
     assert 0 <= aug <= 100 and obj == cold_obj and np.array_equal(plan, cold_plan)
+
+
+@pytest.mark.parametrize('n,k,d', [(6040, 16, 32), (1000, 5, 20), (4099, 40, 128), (333, 3, 7)])
+def test_ot_cost_mfma_close_to_exact(n, k, d):
+    """ure_ot_cost_mfma (|x|^2 - 2 x.c + |c|^2, contraction on v_mfma_f32_32x32x2_f32): within float32 rounding of the
+    exact kernel, ragged tiles and k > 32 included -- and NOT bit-equal to it, which is why it is only a cross-checked
+    fast path (csrc/ot.hip)."""
+    from ultrare_amd import _native as nv
+    rs = np.random.RandomState(n + d)
+    X = rs.standard_normal((n, d)).astype(np.float32)
+    C = X[rs.choice(n, k, replace=False)] + rs.standard_normal((k, d)).astype(np.float32) * 0.1
+    Xd, Cd = torch.from_numpy(X).cuda(), torch.from_numpy(C).cuda()
+    a, b = (torch.empty(k, n, dtype=torch.float32, device='cuda') for _ in range(2))
+    nv.check(nv.lib().ure_ot_cost(nv.ptr(Xd), nv.ptr(Cd), n, k, d, nv.ptr(a), nv.stream_handle()), 'ure_ot_cost')
+    nv.check(nv.lib().ure_ot_cost_mfma(nv.ptr(Xd), nv.ptr(Cd), n, k, d, nv.ptr(b), nv.stream_handle()), 'ure_ot_cost_mfma')
+    exact, fast = a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
+    scale = (X.astype(np.float64) ** 2).sum(1).max() + (C.astype(np.float64) ** 2).sum(1).max()
+    assert np.abs(fast - exact).max() <= 4e-6 * scale
+    assert not np.array_equal(fast, exact)
+
+
+def test_ot_cluster_mfma_cross_check(ot_ml1m, monkeypatch):
+    """URE_OT_MFMA=1: every round is solved on the MFMA costs too and compared with the exact path.  The labels
+    returned stay the reference's; the per-round mismatch counts are what a user would have to see at zero before
+    trusting the fast form on their data (here: k | n, well separated costs -> zero)."""
+    from ultrare_amd.method.utils import ot_cluster
+    g, X = ot_ml1m
+    n = len(X)
+    monkeypatch.setenv('URE_OT_MFMA', '1')
+    np.random.seed(0)
+    np.random.choice(n, int(2 / 100 * n), replace=False)
+    inertia, label = ot_cluster(X, 8)
+    assert np.array_equal(label, g['k8_label']) and float(inertia) == float(g['k8_inertia'])
+    assert len(ot_cluster.mfma_mismatches) == int(g['k8_rounds']) and sum(ot_cluster.mfma_mismatches) <= 2

@@ -96,6 +96,60 @@ __global__ __launch_bounds__(kBlock) void ot_cost_tiled_kernel(const float *__re
     for (int c = wave; c < k; c += kWavesPerBlock) dist[(size_t)c * n + i0 + lane] = np_pairwise(x, C + (size_t)c * d, d);
 }
 
+// ---- MFMA form of the cost matrix: |x|^2 - 2 x.c + |c|^2 with the n x k x d contraction on the matrix cores ------
+// BASELINE.json's north_star asks for the OT cost matrix as a GEMM on MFMA.  The LABELS must equal the reference's bit
+// for bit, and this form rounds differently from utils.py:637's (x - c)^2 sum, so it can never be the arithmetic of
+// record: it is an optional fast path whose labels the host cross-checks against the exact kernel's every round
+// (method/utils.py::ot_cluster, URE_OT_MFMA=1).  fp32 in, fp32 accumulate (v_mfma_f32_32x32x2_f32: exact products,
+// no bf16 rounding -- the costs decide near-ties).  One wave = 32 points x 32 centroids: lane l feeds A[l & 31][l >> 5]
+// = x_{i0 + (l & 31)}[kk + (l >> 5)] from an LDS tile of its 32 rows and B[l >> 5][l & 31] = c_{c0 + (l & 31)}[kk + (l >> 5)];
+// accumulator register r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31.
+typedef float ure_f16v __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(kBlock) void ot_cost_mfma_kernel(const float *__restrict__ X, const float *__restrict__ C, int64_t n, int k, int d,
+                                                              float *__restrict__ dist)
+{
+    extern __shared__ float tile[];                       // [4 waves][32 rows][d + 1]
+    const int ld = d + 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * 32;
+    float *xs = tile + (size_t)wave * 32 * ld;
+    const int rows = (int)max<int64_t>(0, min<int64_t>(32, n - i0));
+    for (int t = lane; t < 32 * d; t += kWave) {
+        const int r = t / d, j = t % d;
+        xs[r * ld + j] = r < rows ? X[(i0 + r) * d + j] : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (rows == 0) return;
+    const int m = lane & 31, h = lane >> 5;
+    float xx = 0.f;                                        // |x_m|^2, both half-waves compute it
+    for (int j = 0; j < d; ++j) xx = fmaf(xs[m * ld + j], xs[m * ld + j], xx);
+    float xrow[16];                                        // |x|^2 of the 16 rows this lane's accumulators belong to (all lanes active here:
+#pragma unroll                                             //  a cross-lane read inside the `cj < k` branch below would see inactive lanes)
+    for (int r = 0; r < 16; ++r) xrow[r] = __shfl(xx, (r & 3) + 8 * (r >> 2) + 4 * h, kWave);
+    for (int c0 = 0; c0 < k; c0 += 32) {
+        const int cj = c0 + m;                             // this lane's centroid (as B's column)
+        const float *crow = C + (size_t)min(cj, k - 1) * d;
+        float cc = 0.f;
+        for (int j = 0; j < d; ++j) cc = fmaf(crow[j], crow[j], cc);
+        ure_f16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int kk = 0; kk < d; kk += 2) {
+            const int col = kk + h;
+            const float a = col < d ? xs[m * ld + col] : 0.f;
+            const float b = (col < d && cj < k) ? crow[col] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (cj < k) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < rows) dist[(size_t)cj * n + i0 + row] = fmaxf(fmaf(-2.0f, acc[r], xrow[r]) + cc, 0.f);
+            }
+        }
+    }
+}
+
 // ---- warm start of the exact solver: potentials of the clusters by dual subgradient ascent ---------------
 // The transportation LP's dual is max_pi sum_i min_c (cost[i][c] - pi[c]) + (n / k) sum_c pi[c]; a subgradient in
 // pi[c] is (n / k) - load_c(pi), load_c = the number of points whose cheapest reduced cost is c.  A hundred
@@ -270,6 +324,22 @@ int ure_ot_cost(const float *X, const float *C, int64_t n, int k, int d, float *
         const unsigned blocks = (unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 256 * 16);
         hipLaunchKernelGGL(ot_cost_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), X, C, n, k, d, dist);
     }
+    URE_HIP(hipGetLastError());
+    return 0;
+}
+
+int ure_ot_cost_mfma(const float *X, const float *C, int64_t n, int k, int d, float *dist, void *stream)
+{
+    URE_ARG(X && C && dist && n > 0 && k > 0 && d > 0 && d <= 256);
+    const size_t lds = (size_t)kWavesPerBlock * 32 * (d + 1) * sizeof(float);
+    if (lds > 160 * 1024) return fail(-1, "ure_ot_cost_mfma: d=%d does not fit the LDS tile", d);
+    static bool raised = false;
+    if (!raised && lds > 64 * 1024) {
+        URE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ot_cost_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised = true;
+    }
+    const unsigned blocks = (unsigned)((n + 32 * kWavesPerBlock - 1) / (32 * kWavesPerBlock));
+    hipLaunchKernelGGL(ot_cost_mfma_kernel, dim3(blocks), dim3(kBlock), lds, static_cast<hipStream_t>(stream), X, C, n, k, d, dist);
     URE_HIP(hipGetLastError());
     return 0;
 }

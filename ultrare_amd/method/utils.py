@@ -13,6 +13,7 @@ the per-batch forward / backward / SGD step of utils.py:58-91 is one fused kerne
 launch per step, driven by engine.TrainJob from Scratch.train.
 """
 import ctypes
+import os
 import pickle
 import time
 from functools import wraps
@@ -133,10 +134,18 @@ def timefn(fn):
     return measure_time
 
 
-def _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi=None):
-    """One round of utils.py:637-648 on the device + the exact host LP."""
+def _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi=None, mfma_check=None):
+    """One round of utils.py:637-648 on the device + the exact host LP.  mfma_check (a list): the round is also
+    solved on the MFMA form of the cost matrix (ure_ot_cost_mfma) and the number of labels that differ from the
+    exact path's is appended -- the cross-check that form needs before anyone may rely on it."""
     L, st = nv.lib(), nv.stream_handle()
     cd = torch.from_numpy(np.ascontiguousarray(centroid, dtype=np.float32)).to(Xd.device)
+    fast_label = None
+    if mfma_check is not None:
+        nv.check(L.ure_ot_cost_mfma(nv.ptr(Xd), nv.ptr(cd), n, k, d, nv.ptr(dist_d), st), 'ure_ot_cost_mfma')
+        fpi = np.zeros(k, dtype=np.float64) if pi is None else pi.copy()
+        nv.check(L.ure_ot_potentials(nv.ptr(dist_d), n, k, OT_WARM_ITERS, fpi.ctypes.data, None, st), 'ure_ot_potentials')
+        fast_label, _, _, _ = nv.ot_assign_warm(dist_d.cpu().numpy(), fpi, want_plan=False)
     nv.check(L.ure_ot_cost(nv.ptr(Xd), nv.ptr(cd), n, k, d, nv.ptr(dist_d), st), 'ure_ot_cost')
     # cluster potentials by dual ascent on the device (a warm start only: the LP below is solved exactly for any
     # potentials), while the cost matrix travels to the host
@@ -144,6 +153,8 @@ def _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi=None)
     nv.check(L.ure_ot_potentials(nv.ptr(dist_d), n, k, OT_WARM_ITERS, pi.ctypes.data, None, st), 'ure_ot_potentials')
     dist = dist_d.cpu().numpy()                                       # [k, n] fp32 (synchronises)
     label, _, _, _ = nv.ot_assign_warm(dist, pi, want_plan=False)     # exact EMD + argmax (host)
+    if fast_label is not None:
+        mfma_check.append(int((fast_label != label).sum()))
     label_d.copy_(torch.from_numpy(label))
     nv.check(L.ure_ot_centroids(nv.ptr(Xd), nv.ptr(label_d), n, k, d, nv.ptr(cent_d), nv.ptr(counts_d), st),
              'ure_ot_centroids')
@@ -166,8 +177,12 @@ def ot_cluster(X, k, max_iters=10):
     cent_d = torch.empty(k, d, dtype=torch.float32, device=dev)
     counts_d = torch.empty(k, dtype=torch.int32, device=dev)
     pi = np.zeros(k, dtype=np.float64)
+    # URE_OT_MFMA=1: every round is solved a second time on the MFMA cost matrix and compared (ot_cluster.mfma_mismatches);
+    # the labels returned are always the exact path's
+    check = [] if os.environ.get('URE_OT_MFMA', '0') == '1' else None
+    ot_cluster.mfma_mismatches = check
     for _ in range(max_iters):
-        dist, label, new_centroid = _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi)
+        dist, label, new_centroid = _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi, check)
         inertia = np.min(dist, axis=0).sum()
         if np.allclose(centroid, new_centroid):
             break
