@@ -130,3 +130,41 @@ def test_bench_split_mode_headline():
     out = _bench(['--gpus', '2', '--backend', 'gloo', '--force-device', '0', '--steps', '2', '--warmup', '1', '--roofline-steps', '1',
                   '--split', '1', '--shards', '8', '--d', '64', '--splits', 'none'])
     assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['config']['shards_per_gpu'] == 4
+
+
+def test_cli_under_two_ranks_writes_one_set_of_artifacts(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 main.py --group 3` (here: two processes with the launcher's
+    environment, gloo transport, one GPU): rank 0 writes param.pkl / deletion.npy / the OT label cache atomically, the
+    other rank reads the cache after a barrier, --parallel 1 is implied, the shards are spread over the ranks and ONE
+    set of model files appears -- with the final test of a single-process run of the same command."""
+    import shutil
+    import pickle
+    data = tmp_path / 'data'
+    (data / 'toy').mkdir(parents=True)
+    shutil.copy(os.path.join(G, 'toy', '0_train.csv'), data / 'toy' / '0_train.csv')
+    shutil.copy(os.path.join(G, 'toy', '0_test.csv'), data / 'toy' / '0_test.csv')
+    common = ['--dataset', 'toy', '--epoch', '2', '--verbose', '0', '--data-dir', str(data)]
+    clean = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    cli = [sys.executable, os.path.join(ROOT, 'main.py')]
+    # the full-MF stage (its user matrix is what the OT grouping clusters), then --group 3 alone as the reference of the test
+    for save in ('one', 'two'):
+        subprocess.run(cli + common + ['--group', '0', '--save-dir', str(tmp_path / save)], env=clean, check=True, stdout=subprocess.DEVNULL, timeout=600)
+    subprocess.run(cli + common + ['--group', '3', '--parallel', '1', '--save-dir', str(tmp_path / 'one')], env=clean, check=True,
+                   stdout=subprocess.DEVNULL, timeout=600)
+    os.remove(data / 'toy' / 'val' / 'emb-ot3.npy')          # the two-rank run must build (and share) the label cache itself
+    env = dict(clean, MASTER_ADDR='127.0.0.1', MASTER_PORT='29647', WORLD_SIZE='2', URE_DIST_BACKEND='gloo')
+    procs = [subprocess.Popen(cli + common + ['--group', '3', '--save-dir', str(tmp_path / 'two')], env=dict(env, RANK=str(r), LOCAL_RANK='0'),
+                              stdout=subprocess.DEVNULL) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    one, two = tmp_path / 'one' / '2' / 'rand' / 'toy_g3', tmp_path / 'two' / '2' / 'rand' / 'toy_g3'
+    assert (two / 'param.pkl').exists() and pickle.load(open(two / 'param.pkl', 'rb')).n_group == 3
+    assert not [f for f in os.listdir(two) if '.tmp' in f] and not [f for f in os.listdir(data / 'toy' / 'val') if '.tmp' in f]
+    for stage in ('MF_emb-ot_sisa_learn', 'MF_emb-ot_sisa_unlearn'):
+        a = np.load(one / stage / 'log0.npy', allow_pickle=True).item()
+        b = np.load(two / stage / 'log0.npy', allow_pickle=True).item()
+        for key in ('total_rmse', 'total_ndcg', 'total_hr'):
+            assert abs(a[key] - b[key]) <= 1e-6 * abs(a[key]), (stage, key)
+        for i in (1, 2, 3):
+            np.testing.assert_allclose(np.load(two / stage / f'user_mat{i}.npy'), np.load(one / stage / f'user_mat{i}.npy'), rtol=2e-5, atol=1e-6)
+            assert np.array_equal(np.load(two / stage / f'item_mat{i}.npy'), np.load(one / stage / f'item_mat{i}.npy'))

@@ -18,7 +18,7 @@ import numpy as np
 from .group import DATA_DIR, SAVE_DIR, Group
 from .method.scratch import Scratch
 from .method.sisa import Sisa
-from .method.utils import saveObject
+from .method.utils import atomic_save, dist_rank, saveObject
 from .read import RatingData, loadData, readRating, readSparseMat
 
 DATASETS = {
@@ -85,16 +85,22 @@ class Instance(object):
         self.name = prefix + self.param.dataset + '_g' + str(self.param.n_group)
         param_dir = self.save_root + self.name
         os.makedirs(param_dir, exist_ok=True)
+        rank, dist = dist_rank()
+        if rank == 0:          # several ranks (torch.distributed.run) run the same Instance: one of them writes
+            # save param
+            saveObject(param_dir + '/param', self.param)  # loadObject(dir + '/param')
+            # save deletion
+            deletion = [self.param.del_user, self.param.del_rating]
+            arr = np.empty(2, dtype=object)
+            arr[0], arr[1] = deletion
 
-        # save param
-        saveObject(param_dir + '/param', self.param)  # loadObject(dir + '/param')
-        # save deletion
-        deletion = [self.param.del_user, self.param.del_rating]
-        arr = np.empty(2, dtype=object)
-        arr[0], arr[1] = deletion
-        with warnings.catch_warnings():
-            warnings.simplefilter('ignore')
-            np.save(param_dir + '/deletion', arr)  # np.load('deletion.npy', allow_pickle=True)
+            def write(tmp):
+                with warnings.catch_warnings(), open(tmp, 'wb') as f:
+                    warnings.simplefilter('ignore')
+                    np.save(f, arr)  # np.load('deletion.npy', allow_pickle=True)
+            atomic_save(param_dir + '/deletion.npy', write)
+        if dist is not None:
+            dist.barrier()
 
     # read raw data (config.py:80-96)
     def _read(self, is_del=False, n_group=1, group_index=[]):
@@ -111,8 +117,7 @@ class Instance(object):
         if not is_save:
             return ''
         save_dir = self.save_root + self.name + '/' + saving_name
-        if not exists(save_dir):
-            mkdir(save_dir)
+        os.makedirs(save_dir, exist_ok=True)
         return save_dir
 
     # sub function of self.runFull (config.py:99-120)
@@ -150,9 +155,17 @@ class Instance(object):
             val_mat = readSparseMat(self.param.train_dir, self.param.n_user, self.param.n_item) \
                 if group_type.startswith('rating') else None
             user_mat = self._full_user_mat()
-            group_index = Group(val_mat, self.param.dataset, user_mat).grouping(
-                self.param.dataset, n_group, group_type, verbose=False,
-                data_dir=os.path.dirname(os.path.dirname(self.param.train_dir)))
+            rank, dist = dist_rank()
+            grouper = Group(val_mat, self.param.dataset, user_mat)
+            kw = dict(verbose=False, data_dir=os.path.dirname(os.path.dirname(self.param.train_dir)))
+            if dist is None:
+                group_index = grouper.grouping(self.param.dataset, n_group, group_type, **kw)
+            else:               # rank 0 clusters and writes the label cache (atomically); the others read it after the barrier
+                if rank == 0:
+                    group_index = grouper.grouping(self.param.dataset, n_group, group_type, **kw)
+                dist.barrier()
+                if rank != 0:
+                    group_index = grouper.grouping(self.param.dataset, n_group, group_type, **kw)
 
         train_rating, train_index, test_rating = self._read(is_del, n_group, group_index)
 

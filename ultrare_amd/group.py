@@ -11,7 +11,7 @@ from os.path import abspath, exists, join
 
 import numpy as np
 
-from .method.utils import kmeans, ot_cluster
+from .method.utils import atomic_save, kmeans, ot_cluster
 
 DATA_DIR = abspath(os.environ.get('ULTRARE_DATA_DIR', join(os.getcwd(), 'data')))
 SAVE_DIR = abspath(os.environ.get('ULTRARE_SAVE_DIR', join(os.getcwd(), 'result')))
@@ -58,7 +58,9 @@ class Group(object):
         arr = np.empty(n_group, dtype=object)
         for i, g in enumerate(res):
             arr[i] = g
-        with warnings.catch_warnings():
-            warnings.simplefilter('ignore')
-            np.save(label_dir, arr)
+        def write(tmp):
+            with warnings.catch_warnings(), open(tmp, 'wb') as f:
+                warnings.simplefilter('ignore')
+                np.save(f, arr)
+        atomic_save(label_dir, write)
         return res

@@ -45,8 +45,16 @@ def main(argv=None):
     import torch
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        dist.init_process_group('nccl')
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local)
+        dist.init_process_group(os.environ.get('URE_DIST_BACKEND', 'nccl'), device_id=torch.device('cuda', local)
+                                if os.environ.get('URE_DIST_BACKEND', 'nccl') == 'nccl' else None)
+        if args.group > 0 and not args.parallel:
+            # one process per GPU only makes sense with the shards spread over the ranks: without it every rank would train
+            # every shard and write the same files
+            if dist.get_rank() == 0:
+                print('WORLD_SIZE > 1: --parallel 1 implied (shards placed over the ranks)')
+            args.parallel = 1
 
     from .config import InsParam, Instance
 

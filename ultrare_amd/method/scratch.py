@@ -179,7 +179,8 @@ class Scratch(object):
 
     def save(self, model, save_dir, id):
         """scratch.py:131-144: model{id}.pth, user_mat{id}.npy, item_mat{id}.npy, log{id}.npy."""
-        if len(save_dir) > 0:
+        from .utils import dist_rank
+        if len(save_dir) > 0 and dist_rank()[0] == 0:       # several ranks running the same call: one set of files
             torch.save(model.state_dict(), save_dir + '/model' + str(id) + '.pth')
             np.save(save_dir + '/user_mat' + str(id), model.user_mat.weight.detach().cpu().numpy())
             np.save(save_dir + '/item_mat' + str(id), model.item_mat.weight.detach().cpu().numpy())

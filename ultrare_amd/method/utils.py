@@ -113,9 +113,26 @@ def computeDCG(r):
     return r[0] + np.sum(r[1:] / np.log2(np.arange(2, len(r) + 1)))
 
 
+def dist_rank():
+    """(rank, torch.distributed module or None): who writes artifacts when several ranks run the same call."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist
+    return 0, None
+
+
+def atomic_save(path, writer):
+    """Write a file under a temporary name and rename it into place: a reader on another rank never sees half of it."""
+    tmp = f'{path}.tmp{os.getpid()}'
+    writer(tmp)
+    os.replace(tmp, path)
+
+
 def saveObject(filename, obj):
-    with open(filename + '.pkl', 'wb') as output:
-        pickle.dump(obj, output, pickle.HIGHEST_PROTOCOL)
+    def write(tmp):
+        with open(tmp, 'wb') as output:
+            pickle.dump(obj, output, pickle.HIGHEST_PROTOCOL)
+    atomic_save(filename + '.pkl', write)
 
 
 def loadObject(filename):
