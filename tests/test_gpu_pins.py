@@ -363,3 +363,33 @@ def test_ot_cluster_mfma_cross_check(ot_ml1m, monkeypatch):
     inertia, label = ot_cluster(X, 8)
     assert np.array_equal(label, g['k8_label']) and float(inertia) == float(g['k8_inertia'])
     assert len(ot_cluster.mfma_mismatches) == int(g['k8_rounds']) and sum(ot_cluster.mfma_mismatches) <= 2
+
+
+def test_torch_library_ops_call_the_same_library():
+    """ultrare_amd/ops.py: the stateless entry points registered as torch.ops.ultrare.* (north_star's wording of the
+    boundary) -- thin calls into the C ABI, same results as the ctypes path, errors instead of a CPU fallback."""
+    import ultrare_amd.ops  # noqa: F401  (registers the ops)
+    from ultrare_amd import _native as nv
+    rs = np.random.RandomState(0)
+    U = torch.from_numpy(rs.standard_normal((50, 16)).astype(np.float32)).cuda()
+    V = torch.from_numpy(rs.standard_normal((70, 16)).astype(np.float32)).cuda()
+    uid = torch.from_numpy(rs.randint(0, 50, 300)).cuda()
+    iid = torch.from_numpy(rs.randint(0, 70, 300)).cuda()
+    pred = torch.ops.ultrare.mf_score(U, V, uid, iid)
+    want = (U[uid].double() * V[iid].double()).sum(1)
+    assert torch.allclose(pred.double(), want, rtol=1e-5, atol=1e-6)
+    X = rs.standard_normal((500, 24)).astype(np.float32)
+    C = X[:6].copy()
+    dist = torch.ops.ultrare.ot_cost(torch.from_numpy(X).cuda(), torch.from_numpy(C).cuda())
+    assert np.array_equal(dist.cpu().numpy(), ((X - C[:, np.newaxis]) ** 2).sum(axis=2))
+    fast = torch.ops.ultrare.ot_cost_mfma(torch.from_numpy(X).cuda(), torch.from_numpy(C).cuda())
+    assert torch.allclose(fast, dist, rtol=0, atol=1e-3)
+    label = dist.argmin(0)
+    cent = torch.ops.ultrare.ot_centroids(torch.from_numpy(X).cuda(), label, 6)
+    lab = label.cpu().numpy()
+    assert np.array_equal(cent.cpu().numpy(), np.array([X[lab == i].mean(axis=0) for i in range(6)]))
+    dst = torch.zeros(50, 16, device='cuda')
+    torch.ops.ultrare.merge_rows(dst, U, torch.tensor([3, 7, 11]).cuda())
+    assert torch.equal(dst[[3, 7, 11]], U[[3, 7, 11]]) and float(dst.abs().sum()) == float(U[[3, 7, 11]].abs().sum())
+    with pytest.raises(Exception):
+        torch.ops.ultrare.ot_cost(torch.from_numpy(X), torch.from_numpy(C))          # CPU tensors: an error, not a fallback

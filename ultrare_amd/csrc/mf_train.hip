@@ -227,6 +227,9 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
     if (have) {
         w = row_load<LPR, V4>((is_user ? S.U[cur] : S.V[cur]) + row_off, sub);
     }
+    // the momentum row is requested together with the weights: its latency hides behind the scan and the gathers
+    // instead of forming a memory level of its own in front of the update (bench: 12.6 -> 12.5 us per launch)
+    if (owner && !first) m4 = row_load<LPR, V4>((is_user ? S.mU : S.mV) + row_off, sub);
     float sse = 0.f;
     URE_STAMP(2);     // unit descriptor and own row arrived
     if (!dense_only) {
@@ -335,7 +338,6 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
         }
     }
     if (owner) {
-        if (!first) m4 = row_load<LPR, V4>((is_user ? S.mU : S.mV) + row_off, sub);
         sgd_update(w, m4, acc, (is_user ? S.mU : S.mV) + row_off, (is_user ? S.U[cur ^ 1] : S.V[cur ^ 1]) + row_off);
         // train loss (utils.py:82): each user row adds its own squared errors to its own slot of
         // the epoch -- owner-only read-modify-write, so no atomics and a reproducible sum
