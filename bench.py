@@ -408,6 +408,11 @@ def main():
         sys.exit(spawn_ranks(a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    # the driver reads ONE JSON line from stdout, and RCCL / gloo / the engine's progress prints write there too:
+    # from here on file descriptor 1 is stderr, and the line goes to a private copy of the real stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     D = Dist(a)
     rank, world = D.rank, D.world
     from ultrare_amd import _native as nv
@@ -450,7 +455,8 @@ def main():
 
     def emit():
         if rank == 0 and printed.acquire(blocking=False):
-            print(json.dumps(out), flush=True)
+            real_stdout.write(json.dumps(out) + '\n')
+            real_stdout.flush()
 
     if D.pg is not None:
         # ---- N > 1 extras: the exchange over RCCL and the north-star splits.  A watchdog prints the

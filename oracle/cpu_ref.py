@@ -51,6 +51,11 @@ def lib():
 
 
 def _p(a, t):
+    # the C side reads raw memory: an array of another element type (int64 ids where int32 are expected ...) would be
+    # misread silently, so the element type is checked here
+    want = {ctypes.c_float: np.float32, ctypes.c_double: np.float64, ctypes.c_int32: np.int32, ctypes.c_int64: np.int64}.get(t._type_)
+    if want is not None and (a.dtype != want or not a.flags['C_CONTIGUOUS']):
+        raise TypeError(f'oracle: expected a contiguous {np.dtype(want)} array, got {a.dtype}')
     return a.ctypes.data_as(t)
 
 

@@ -393,3 +393,25 @@ def test_torch_library_ops_call_the_same_library():
     assert torch.equal(dst[[3, 7, 11]], U[[3, 7, 11]]) and float(dst.abs().sum()) == float(U[[3, 7, 11]].abs().sum())
     with pytest.raises(Exception):
         torch.ops.ultrare.ot_cost(torch.from_numpy(X), torch.from_numpy(C))          # CPU tensors: an error, not a fallback
+
+
+def test_eval_with_nan_predictions_ranks_like_numpy_and_stays_in_bounds():
+    """A shard whose training diverged (the reference's summed-loss SGD does on heavy users) predicts NaN.  The
+    reference's np.argsort orders NaN after every number, so NaN predictions rank FIRST in top_pred; the ranking kernel
+    must do the same -- and must never turn 'no entry of rank k' into position -1 (an out-of-bounds read in front of
+    the first user's segment; found as a GPU memory fault in a two-rank run of configs[4])."""
+    from ultrare_amd import engine
+    rs = np.random.RandomState(4)
+    n_user, n_item, k = 40, 300, 16
+    uid = np.sort(np.concatenate([rs.randint(0, n_user, 1500), np.zeros(3, int), np.full(70, 7), np.full(600, 9)])).astype(np.int32)
+    iid = rs.randint(0, n_item, len(uid)).astype(np.int32)
+    r = rs.choice([0.2, 0.4, 0.6, 0.8, 1.0], len(uid)).astype(np.float32)
+    U = rs.standard_normal((n_user, k)).astype(np.float32)
+    V = rs.standard_normal((n_item, k)).astype(np.float32) * 0.3
+    U[[0, 7, 9, 23]] = np.nan                                   # whole users NaN (short, 64+ and 512+ item segments among them)
+    V[5] = np.nan                                               # and one item: NaN entries inside otherwise finite users
+    ev = engine.EvalSet(uid, iid, r)
+    got = ev.evaluate([(torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda())], k)
+    want = O.eval_metrics((uid, iid, r), [(U, V)], 3000)
+    assert np.isnan(got[0]) and np.isnan(want[0])
+    np.testing.assert_allclose(got[1:], want[1:], rtol=1e-12)

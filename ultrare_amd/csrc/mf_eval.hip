@@ -152,6 +152,12 @@ __global__ __launch_bounds__(kBlock) void score_series_kernel(const float *__res
 // ascending argsort, i.e. earlier in its reverse (utils.py:169-170).
 __device__ __forceinline__ bool key_gt(float v, int i, float bv, int bi) { return v > bv || (v == bv && i > bi); }
 
+// A model that diverged (the reference's summed-loss SGD does on heavy users, e.g. two of the 16 shards of
+// BASELINE.json configs[4] on the synthetic set) predicts NaN.  np.argsort places NaN after every number, so its
+// reverse ranks NaN first: NaN is ordered as +inf here, which keeps the keys totally ordered -- without it no entry
+// has rank k for some k and the selection returns position -1.
+__device__ __forceinline__ float nan_last(float v) { return v != v ? __builtin_inff() : v; }
+
 __device__ __forceinline__ void wave_argmax(float &v, int &i)
 {
 #pragma unroll
@@ -174,7 +180,7 @@ __device__ __forceinline__ void top_k_positions(const float *__restrict__ val, i
         float bv = -FLT_MAX;
         int bi = -1;
         for (int t = lane; t < cnt; t += kWave) {
-            const float v = val[t];
+            const float v = nan_last(val[t]);
             const bool below_prev = pinf || v < pv || (v == pv && t < pi);
             if (below_prev && (bi < 0 || key_gt(v, t, bv, bi))) { bv = v; bi = t; }
         }
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__res
     if (cnt <= kWave) {
         // the common case (a user's test items fit one per lane): both rankings are extracted from
         // registers, ten wave arg-max rounds each, no memory access per round
-        const float pv = lane < cnt ? pred[beg + lane] : 0.f;
+        const float pv = lane < cnt ? nan_last(pred[beg + lane]) : 0.f;
         const float rv = lane < cnt ? rating[beg + lane] : 0.f;
         top_k_in_registers<K>(pv, cnt, lane, tp);
         top_k_in_registers<K>(rv, cnt, lane, tr);
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__res
 #pragma unroll
         for (int r = 0; r < kRegItems; ++r) {
             const int t = lane + r * kWave;
-            pv[r] = t < cnt ? pred[beg + t] : 0.f;
+            pv[r] = t < cnt ? nan_last(pred[beg + t]) : 0.f;
             rv[r] = t < cnt ? rating[beg + t] : 0.f;
         }
         top_k_multi<K>(pv, cnt, lane, tp);
@@ -271,13 +277,13 @@ __global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__res
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         val[j] = 0.0;
-        if (j < n_top) {
+        if (j < n_top && tp[j] >= 0) {                                // (a position is always found; the guard keeps a bad input from reading out of bounds)
             const double rel = (double)rating[beg + tp[j]];          // float32 widened (utils.py:132,153)
             const bool hit = rel >= (4.0 / 5.0);                     // utils.py:175
             n_hit += hit ? 1 : 0;
             bool common = false;                                     // np.in1d(top_rating, top_pred)[j]
 #pragma unroll
-            for (int q = 0; q < K; ++q) common = common || (q < n_top && tp[q] == tr[j]);
+            for (int q = 0; q < K; ++q) common = common || (q < n_top && tr[j] >= 0 && tp[q] == tr[j]);
             val[j] = (hit && common) ? rel : 0.0;
         }
     }
