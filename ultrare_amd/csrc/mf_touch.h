@@ -393,12 +393,12 @@ __device__ __forceinline__ void mf_touch_step(const ure_shard_t *__restrict__ sh
     if (wg < nbU + nbC) {
         // ---- candidates: one lane per row finds out whether the row is trained in this step ...
         const int rel = (wg - nbU) * kBlock + (int)threadIdx.x;
+        // (the schedule entry is requested with the mask, not after it: one memory level, and both reads are coalesced)
         const unsigned long long mk = rel < n_single ? ldg(A.sched_mask + rel) : 0ull;
+        const int4 sc = rel < n_single ? ldg_i4(S.sched + 4 * (size_t)(S.n_multi + rel)) : make_int4(-1, 0, 0, 0);
         const bool hit = (mk >> s) & 1ull;
         const unsigned long long vote = __ballot(hit);
         if (lane == 0) cand_count[wave] = __popcll(vote);
-        int4 sc = make_int4(-1, 0, 0, 0);
-        if (hit) sc = ldg_i4(S.sched + 4 * (size_t)(S.n_multi + rel));
         __syncthreads();
         int base = 0, total = 0;
 #pragma unroll
