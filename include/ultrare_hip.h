@@ -253,6 +253,10 @@ int ure_ot_cost_mfma(const float *X, const float *C, int64_t n, int k, int d, fl
  * row id then one division by the count (bit-exact).  counts [k] receives sizes. */
 int ure_ot_centroids(const float *X, const int32_t *label, int64_t n, int k, int d, float *C,
                      int32_t *counts, void *stream);
+/* The same means from member lists (device): order[off[c] .. off[c+1]) = the points of cluster c in ascending id,
+ * off [k + 1] int64 -- a stable counting sort of the labels.  Same fp32 order, ~n / k rows per thread instead of n. */
+int ure_ot_centroids_members(const float *X, const int32_t *order, const int64_t *off, int64_t n, int k, int d, float *C,
+                             int32_t *counts, void *stream);
 /* utils.py:642-647: exact optimal transport between n points of mass 1/n and k
  * clusters of mass 1/k for cost dist [k][n] (HOST memory, fp32 widened to double
  * exactly), followed by label = argmax of each point's plan row (first maximum).

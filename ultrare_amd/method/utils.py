@@ -28,7 +28,13 @@ from ..read import as_loader
 from ..rng import seed_all  # noqa: F401  (re-exported under the reference's name)
 
 STD = 1
-OT_WARM_ITERS = 400      # dual-ascent steps that warm-start the exact OT solver (ure_ot_potentials)
+OT_WARM_ITERS = 400      # dual-ascent steps that warm-start the exact OT solver (ure_ot_potentials) at large n
+
+
+def ot_warm_iters(n):
+    """Fewer steps for small problems: the solver finishes a rough start of a few thousand points in a millisecond, while
+    every ascent step is two launches."""
+    return int(min(OT_WARM_ITERS, max(60, n // 400)))
 
 
 class MF(nn.Module):
@@ -161,20 +167,22 @@ def _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi=None,
     if mfma_check is not None:
         nv.check(L.ure_ot_cost_mfma(nv.ptr(Xd), nv.ptr(cd), n, k, d, nv.ptr(dist_d), st), 'ure_ot_cost_mfma')
         fpi = np.zeros(k, dtype=np.float64) if pi is None else pi.copy()
-        nv.check(L.ure_ot_potentials(nv.ptr(dist_d), n, k, OT_WARM_ITERS, fpi.ctypes.data, None, st), 'ure_ot_potentials')
+        nv.check(L.ure_ot_potentials(nv.ptr(dist_d), n, k, ot_warm_iters(n), fpi.ctypes.data, None, st), 'ure_ot_potentials')
         fast_label, _, _, _ = nv.ot_assign_warm(dist_d.cpu().numpy(), fpi, want_plan=False)
     nv.check(L.ure_ot_cost(nv.ptr(Xd), nv.ptr(cd), n, k, d, nv.ptr(dist_d), st), 'ure_ot_cost')
     # cluster potentials by dual ascent on the device (a warm start only: the LP below is solved exactly for any
     # potentials), while the cost matrix travels to the host
     pi = np.zeros(k, dtype=np.float64) if pi is None else pi         # in: the previous round's, out: this round's
-    nv.check(L.ure_ot_potentials(nv.ptr(dist_d), n, k, OT_WARM_ITERS, pi.ctypes.data, None, st), 'ure_ot_potentials')
+    nv.check(L.ure_ot_potentials(nv.ptr(dist_d), n, k, ot_warm_iters(n), pi.ctypes.data, None, st), 'ure_ot_potentials')
     dist = dist_d.cpu().numpy()                                       # [k, n] fp32 (synchronises)
     label, _, _, _ = nv.ot_assign_warm(dist, pi, want_plan=False)     # exact EMD + argmax (host)
     if fast_label is not None:
         mfma_check.append(int((fast_label != label).sum()))
-    label_d.copy_(torch.from_numpy(label))
-    nv.check(L.ure_ot_centroids(nv.ptr(Xd), nv.ptr(label_d), n, k, d, nv.ptr(cent_d), nv.ptr(counts_d), st),
-             'ure_ot_centroids')
+    # utils.py:648 from member lists: a stable sort of the labels (ascending id inside a cluster = numpy's order of addition)
+    order = torch.from_numpy(np.argsort(label, kind='stable').astype(np.int32)).to(Xd.device)
+    off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(label, minlength=k))]).astype(np.int64)).to(Xd.device)
+    nv.check(L.ure_ot_centroids_members(nv.ptr(Xd), nv.ptr(order), nv.ptr(off), n, k, d, nv.ptr(cent_d), nv.ptr(counts_d), st),
+             'ure_ot_centroids_members')
     return dist, label, cent_d.cpu().numpy()
 
 
