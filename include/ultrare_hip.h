@@ -215,8 +215,13 @@ int ure_score(const float *const *U_tables, const float *const *V_tables, int n_
  * >= 4/5), ndcg[t] = the reference's positional NDCG@10 (utils.py:190-210).
  * `log2_tab` [10] (device, float64) = log2(2..10) followed by the ideal DCG computeDCG(ones(10)),
  * both computed by the host with numpy so that every division matches the reference bit for bit. */
+/* Users [0, n_wide) get one wavefront each (segments of any length); users [n_wide, n_users) MUST have at most 16
+ * entries and share wavefronts four by four (n_wide = n_users: every user a wavefront).  top_rating (optional, device
+ * [n_users][10]): the top-10 positions of the RATINGS, which do not depend on the model -- ure_eval_rank_ratings
+ * computes them once per test set; NULL = ranked inside the call.                                               */
 int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const float *rating,
-                   const double *log2_tab, int32_t *hits, double *ndcg, void *stream);
+                   const double *log2_tab, int32_t *hits, double *ndcg, const int32_t *top_rating, int32_t n_wide, void *stream);
+int ure_eval_rank_ratings(const int32_t *off, int32_t n_users, const float *rating, int32_t *top_rating, void *stream);
 
 /* utils.py:163,183-184: out3 (device, 3 doubles) = { sqrt(sum(sse[0..URE_SCORE_PARTIALS)) / n_rows), mean(ndcg), mean(hits / 10) }
  * from the outputs of ure_score / ure_eval_users, reduced on the device in a fixed order: lets a
@@ -234,7 +239,8 @@ int ure_eval_reduce(const int32_t *hits, const double *ndcg, int32_t n_users, co
 int ure_eval_series(const float *const *U_fixed, const float *const *V_fixed, int n_fixed, const float *U_series,
                     const float *V_series, int64_t stride_u, int64_t stride_v, int n_series, const int32_t *uid, const int32_t *iid,
                     const float *rating, int64_t n, int d, const int32_t *off, int32_t n_users, const double *log2_tab, float *base,
-                    float *pred, double *sse, int32_t *hits, double *ndcg, double *out, void *stream);
+                    float *pred, double *sse, int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide,
+                    void *stream);
 
 /* sisa.py:55-56,110-111: dst[rows[t]][:] = src[rows[t]][:]. */
 int ure_merge_rows(float *dst, const float *src, const int64_t *rows, int64_t n_rows, int d, void *stream);

@@ -233,44 +233,31 @@ __device__ __forceinline__ void top_k_multi(const float (&val)[kRegItems], int c
     }
 }
 
-__global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__restrict__ off, int32_t n_users,
-                                                            const float *__restrict__ pred, const float *__restrict__ rating,
-                                                            const double *__restrict__ log2_tab,
-                                                            int32_t *__restrict__ hits, double *__restrict__ ndcg, int64_t pred_stride)
+// Rank of every entry of a segment of at most 16 entries held one per lane by a quarter wave (lanes 16 g .. 16 g + 15):
+// the in-register selection of top_k_in_registers at width 16, four users per wavefront.
+template <int K>
+__device__ __forceinline__ void top_k_quarter(float val, int cnt, int lane, int (&top)[K])
+{
+    const int g16 = lane & ~15, s = lane & 15;
+    int rank = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const float ov = __shfl(val, g16 + t, kWave);
+        rank += (t < cnt && key_gt(ov, t, val, s)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const unsigned long long m = __ballot(s < cnt && rank == k);
+        const unsigned mg = (unsigned)(m >> g16) & 0xFFFFu;
+        top[k] = mg ? (int)__builtin_ctz(mg) : -1;
+    }
+}
+
+// HR@10 / NDCG@10 of one user from the two top-10 position lists (utils.py:172-184, 190-210); one lane per user.
+__device__ __forceinline__ void user_metrics(const float *__restrict__ rating, int beg, int cnt, const int (&tp)[10], const int (&tr)[10],
+                                             const double *__restrict__ log2_tab, int32_t *hits_out, double *ndcg_out)
 {
     constexpr int K = 10;
-    const int lane = threadIdx.x & 63;
-    const int user = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
-    if (user >= n_users) return;
-    // blockIdx.y = member of a series of evaluations that share the test set (ure_eval_series)
-    pred += (size_t)blockIdx.y * pred_stride;
-    hits += (size_t)blockIdx.y * n_users;
-    ndcg += (size_t)blockIdx.y * n_users;
-    const int beg = off[user], cnt = off[user + 1] - beg;
-    int tp[K], tr[K];
-    if (cnt <= kWave) {
-        // the common case (a user's test items fit one per lane): both rankings are extracted from
-        // registers, ten wave arg-max rounds each, no memory access per round
-        const float pv = lane < cnt ? nan_last(pred[beg + lane]) : 0.f;
-        const float rv = lane < cnt ? rating[beg + lane] : 0.f;
-        top_k_in_registers<K>(pv, cnt, lane, tp);
-        top_k_in_registers<K>(rv, cnt, lane, tr);
-    } else if (cnt <= kWave * kRegItems) {
-        // heavier users: up to 8 entries per lane, loaded once; ten arg-max rounds in registers
-        float pv[kRegItems], rv[kRegItems];
-#pragma unroll
-        for (int r = 0; r < kRegItems; ++r) {
-            const int t = lane + r * kWave;
-            pv[r] = t < cnt ? nan_last(pred[beg + t]) : 0.f;
-            rv[r] = t < cnt ? rating[beg + t] : 0.f;
-        }
-        top_k_multi<K>(pv, cnt, lane, tp);
-        top_k_multi<K>(rv, cnt, lane, tr);
-    } else {
-        top_k_positions<K>(pred + beg, cnt, lane, tp);
-        top_k_positions<K>(rating + beg, cnt, lane, tr);
-    }
-    if (lane != 0) return;
     const int n_top = cnt < K ? cnt : K;
     double val[K];
     int n_hit = 0;
@@ -295,8 +282,97 @@ __global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__res
 #pragma unroll
     for (int j = 0; j < K - 1; ++j) a[j] = val[j + 1] / log2_tab[j];
     const double dcg = val[0] + ((((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + a[8]);
-    hits[user] = n_hit;
-    ndcg[user] = dcg / log2_tab[K - 1];
+    *hits_out = n_hit;
+    *ndcg_out = dcg / log2_tab[K - 1];
+}
+
+// Positions of the top-10 of `val` over the segment [beg, beg + cnt) of a wave-per-user segment (any length).
+template <bool IS_PRED>
+__device__ __forceinline__ void rank_wide(const float *__restrict__ val, int beg, int cnt, int lane, int (&top)[10])
+{
+    constexpr int K = 10;
+    if (cnt <= kWave) {
+        // the common case (the items fit one per lane): ten ballots after `cnt` broadcasts, no memory access per round
+        float v = lane < cnt ? val[beg + lane] : 0.f;
+        if (IS_PRED) v = nan_last(v);
+        top_k_in_registers<K>(v, cnt, lane, top);
+    } else if (cnt <= kWave * kRegItems) {
+        // heavier users: up to 8 entries per lane, loaded once; ten arg-max rounds in registers
+        float v[kRegItems];
+#pragma unroll
+        for (int r = 0; r < kRegItems; ++r) {
+            const int t = lane + r * kWave;
+            v[r] = t < cnt ? val[beg + t] : 0.f;
+            if (IS_PRED) v[r] = nan_last(v[r]);
+        }
+        top_k_multi<K>(v, cnt, lane, top);
+    } else {
+        top_k_positions<K>(val + beg, cnt, lane, top);
+    }
+}
+
+// The ranking of the RATINGS does not depend on the model: once per test set (ure_eval_rank_ratings).
+__global__ __launch_bounds__(kBlock) void eval_rank_ratings_kernel(const int32_t *__restrict__ off, int32_t n_users, const float *__restrict__ rating,
+                                                                   int32_t *__restrict__ top_rating)
+{
+    const int lane = threadIdx.x & 63;
+    const int user = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+    if (user >= n_users) return;
+    const int beg = off[user], cnt = off[user + 1] - beg;
+    int tr[10];
+    rank_wide<false>(rating, beg, cnt, lane, tr);
+    if (lane < 10) {
+        int v = tr[0];
+#pragma unroll
+        for (int k = 1; k < 10; ++k) v = lane == k ? tr[k] : v;
+        top_rating[(size_t)user * 10 + lane] = v;
+    }
+}
+
+// Users [0, n_wide): one wavefront each (segments of any length).  Users [n_wide, n_users): segments of at most 16
+// entries, four users per wavefront (a quarter wave each) -- on a 10 % hold-out of ml-1m two thirds of the users.
+// top_rating (optional): the cached ranking of the ratings, [n_users][10] positions.
+__global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__restrict__ off, int32_t n_users, int32_t n_wide,
+                                                            const float *__restrict__ pred, const float *__restrict__ rating,
+                                                            const int32_t *__restrict__ top_rating, const double *__restrict__ log2_tab,
+                                                            int32_t *__restrict__ hits, double *__restrict__ ndcg, int64_t pred_stride)
+{
+    constexpr int K = 10;
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+    // blockIdx.y = member of a series of evaluations that share the test set (ure_eval_series)
+    pred += (size_t)blockIdx.y * pred_stride;
+    hits += (size_t)blockIdx.y * n_users;
+    ndcg += (size_t)blockIdx.y * n_users;
+    int tp[K], tr[K];
+    if (wave < n_wide) {
+        const int user = wave;
+        const int beg = off[user], cnt = off[user + 1] - beg;
+        rank_wide<true>(pred, beg, cnt, lane, tp);
+        if (top_rating) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) tr[k] = top_rating[(size_t)user * 10 + k];
+        } else {
+            rank_wide<false>(rating, beg, cnt, lane, tr);
+        }
+        if (lane == 0) user_metrics(rating, beg, cnt, tp, tr, log2_tab, hits + user, ndcg + user);
+        return;
+    }
+    const int user = n_wide + (wave - n_wide) * 4 + (lane >> 4);
+    if (n_wide + (wave - n_wide) * 4 >= n_users) return;
+    const bool have = user < n_users;
+    const int s = lane & 15;
+    const int beg = have ? off[user] : 0, cnt = have ? off[user + 1] - beg : 0;       // cnt <= 16 by the caller's ordering
+    const float pv = s < cnt ? nan_last(pred[beg + s]) : 0.f;
+    top_k_quarter<K>(pv, cnt, lane, tp);
+    if (top_rating) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) tr[k] = have ? top_rating[(size_t)user * 10 + k] : -1;
+    } else {
+        const float rv = s < cnt ? rating[beg + s] : 0.f;
+        top_k_quarter<K>(rv, cnt, lane, tr);
+    }
+    if (have && s == 0) user_metrics(rating, beg, cnt, tp, tr, log2_tab, hits + user, ndcg + user);
 }
 
 // utils.py:163-184 tail: rmse = sqrt(sse / n_rows), ndcg = mean(ndcg), hr = mean(hits / 10), reduced on
@@ -414,14 +490,29 @@ int ure_score(const float *const *U_tables, const float *const *V_tables, int n_
     return 0;
 }
 
-int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const float *rating, const double *log2_tab,
-                   int32_t *hits, double *ndcg, void *stream)
+static unsigned eval_user_blocks(int32_t n_users, int32_t n_wide)
 {
-    URE_ARG(off && pred && rating && log2_tab && hits && ndcg && n_users >= 0);
+    const int64_t waves = (int64_t)n_wide + ((int64_t)(n_users - n_wide) + 3) / 4;
+    return (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+}
+
+int ure_eval_rank_ratings(const int32_t *off, int32_t n_users, const float *rating, int32_t *top_rating, void *stream)
+{
+    URE_ARG(off && rating && top_rating && n_users >= 0);
     if (n_users == 0) return 0;
     const unsigned blocks = (unsigned)((n_users + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(eval_users_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), off, n_users, pred,
-                       rating, log2_tab, hits, ndcg, (int64_t)0);
+    hipLaunchKernelGGL(eval_rank_ratings_kernel, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), off, n_users, rating, top_rating);
+    URE_HIP(hipGetLastError());
+    return 0;
+}
+
+int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const float *rating, const double *log2_tab,
+                   int32_t *hits, double *ndcg, const int32_t *top_rating, int32_t n_wide, void *stream)
+{
+    URE_ARG(off && pred && rating && log2_tab && hits && ndcg && n_users >= 0 && n_wide >= 0 && n_wide <= n_users);
+    if (n_users == 0) return 0;
+    hipLaunchKernelGGL(eval_users_kernel, dim3(eval_user_blocks(n_users, n_wide)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), off, n_users,
+                       n_wide, pred, rating, top_rating, log2_tab, hits, ndcg, (int64_t)0);
     URE_HIP(hipGetLastError());
     return 0;
 }
@@ -439,8 +530,9 @@ int ure_eval_reduce(const int32_t *hits, const double *ndcg, int32_t n_users, co
 int ure_eval_series(const float *const *U_fixed, const float *const *V_fixed, int n_fixed, const float *U_series,
                     const float *V_series, int64_t stride_u, int64_t stride_v, int n_series, const int32_t *uid, const int32_t *iid,
                     const float *rating, int64_t n, int d, const int32_t *off, int32_t n_users, const double *log2_tab, float *base,
-                    float *pred, double *sse, int32_t *hits, double *ndcg, double *out, void *stream)
+                    float *pred, double *sse, int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide, void *stream)
 {
+    URE_ARG(n_wide >= 0 && n_wide <= n_users);
     URE_ARG(n_fixed >= 0 && (n_fixed == 0 || (U_fixed && V_fixed && base)) && U_series && V_series && n_series > 0 && n_series <= 65535);
     URE_ARG(uid && iid && rating && n > 0 && pow2(d) && d >= 4 && d <= 256 && off && n_users >= 0 && log2_tab && pred && sse && hits &&
             ndcg && out);
@@ -462,11 +554,9 @@ int ure_eval_series(const float *const *U_fixed, const float *const *V_fixed, in
         case 64: launch_score_series<64>(U_series, V_series, stride_u, stride_v, n_series, nt, uid, iid, rating, n, b, pred, sse, st); break;
         default: return fail(-1, "ure_eval_series: unsupported d=%d", d);
     }
-    if (n_users > 0) {
-        const unsigned blocks = (unsigned)((n_users + kWavesPerBlock - 1) / kWavesPerBlock);
-        hipLaunchKernelGGL(eval_users_kernel, dim3(blocks, (unsigned)n_series), dim3(kBlock), 0, st, off, n_users, pred, rating, log2_tab,
-                           hits, ndcg, n);
-    }
+    if (n_users > 0)
+        hipLaunchKernelGGL(eval_users_kernel, dim3(eval_user_blocks(n_users, n_wide), (unsigned)n_series), dim3(kBlock), 0, st, off, n_users, n_wide,
+                           pred, rating, top_rating, log2_tab, hits, ndcg, n);
     hipLaunchKernelGGL(eval_reduce_kernel, dim3((unsigned)n_series), dim3(1024), 0, st, hits, ndcg, n_users, sse, n, out);
     URE_HIP(hipGetLastError());
     return 0;

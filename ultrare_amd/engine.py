@@ -338,13 +338,21 @@ class EvalSet:
         rating = np.ascontiguousarray(rating, dtype=np.float32)
         self.n = len(uid)
         self.device = device or _device()
+        self.n_wide = 0
         if self.n:
             _, first = np.unique(uid, return_index=True)
-            users = uid[np.sort(first)]                       # first-appearance order
+            users = uid[np.sort(first)]                       # first-appearance order (utils.py:156-163) ...
             rank = np.empty(int(uid.max()) + 1, dtype=np.int64)
             rank[users] = np.arange(len(users))
-            order = np.argsort(rank[uid], kind='stable')
             counts = np.bincount(rank[uid], minlength=len(users))
+            # ... inside two classes: users with more than 16 test items first (a wavefront each in the ranking kernel),
+            # then the others (four per wavefront).  The metrics are means over users: their order does not enter.
+            wide = counts > 16
+            self.n_wide = int(wide.sum())
+            cls = np.argsort(~wide, kind='stable')
+            users, counts = users[cls], counts[cls]
+            rank[users] = np.arange(len(users))
+            order = np.argsort(rank[uid], kind='stable')
         else:
             users, order, counts = np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0, np.int64)
         off = np.zeros(len(users) + 1, dtype=np.int32)
@@ -359,6 +367,11 @@ class EvalSet:
         self.sse = torch.zeros(SCORE_PARTIALS, dtype=torch.float64, device=dev)
         self.log2 = to(_LOG2_TAB)
         self.order = order
+        # the ranking of the ratings is a property of the test set: once, here
+        self.top_rating = torch.empty(max(self.n_users, 1) * 10, dtype=torch.int32, device=dev)
+        if self.n_users:
+            nv.check(nv.lib().ure_eval_rank_ratings(nv.ptr(self.off), self.n_users, nv.ptr(self.rating), nv.ptr(self.top_rating),
+                                                    nv.stream_handle()), 'ure_eval_rank_ratings')
 
     def evaluate(self, models, d, stream=None, top_k=10, out=None):
         """baseTest (utils.py:115-187) for an ensemble: `models` = list of (U, V) device
@@ -380,7 +393,8 @@ class EvalSet:
                                  nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating), self.n, d,
                                  nv.ptr(self.pred), nv.ptr(self.sse), st), 'ure_score')
         nv.check(L.ure_eval_users(nv.ptr(self.off), self.n_users, nv.ptr(self.pred), nv.ptr(self.rating),
-                                  nv.ptr(self.log2), nv.ptr(self.hits), nv.ptr(self.ndcg), st), 'ure_eval_users')
+                                  nv.ptr(self.log2), nv.ptr(self.hits), nv.ptr(self.ndcg), nv.ptr(self.top_rating), self.n_wide, st),
+                 'ure_eval_users')
         if out is not None:
             # queued evaluation: (rmse, ndcg, hr) land in `out` (device, 3 float64); nothing synchronises
             nv.check(L.ure_eval_reduce(nv.ptr(self.hits), nv.ptr(self.ndcg), self.n_users, nv.ptr(self.sse), self.n,
@@ -421,7 +435,8 @@ class EvalSet:
             nv.check(L.ure_eval_series(Up, Vp, len(fixed), nv.ptr(U_series[e0]), nv.ptr(V_series[e0]), U_series.stride(0),
                                        V_series.stride(0), m, nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating), self.n, d,
                                        nv.ptr(self.off), self.n_users, nv.ptr(self.log2), nv.ptr(b['base']), nv.ptr(b['pred']),
-                                       nv.ptr(b['sse']), nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), st),
+                                       nv.ptr(b['sse']), nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating),
+                                       self.n_wide, st),
                      'ure_eval_series')
         return out
 
