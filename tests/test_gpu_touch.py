@@ -163,3 +163,26 @@ def test_touch_mode_d128_shards_at_configs3_size_vs_oracle():
         assert rel(U, st.U) < 2e-5 and rel(V, st.V) < 2e-5, s
         np.testing.assert_allclose(np.sqrt(job.epoch_sse(s) / len(parts[s][0])), losses, rtol=2e-5)
     job.close()
+
+
+def test_touch_rows_accounting_matches_the_permutations():
+    """ure_job_touch_rows (what bench.py's roofline counts as streamed rows in touch mode): the number of (row, step)
+    pairs of the last epoch in which a row has an interaction, recomputed here from the epoch's permutation."""
+    from ultrare_amd import engine
+    k, B, E = 16, 900, 3
+    parts, inits, perms, shards = _setup(2, k, B, E, seed=12)
+    job = engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=True)
+    job.run()
+    got = job.touch_rows_per_step()
+    for s, p in enumerate(parts):
+        n = len(p[0])
+        steps = (n + B - 1) // B
+        perm = perms[s][E - 1].numpy()
+        step_of = np.empty(n, dtype=np.int64)
+        step_of[perm] = np.arange(n) // B                                  # read.py:133: batch b = perm[b*B:(b+1)*B]
+        pairs = len(np.unique(p[0].astype(np.int64) * steps + step_of)) + len(np.unique((N_USER + p[1].astype(np.int64)) * steps + step_of))
+        assert abs(got[s] * steps - pairs) < 0.5, (s, got[s] * steps, pairs)
+    job.close()
+    dense = engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=False)
+    assert dense.touch_rows_per_step() is None
+    dense.close()

@@ -210,7 +210,7 @@ class Sisa(Scratch):
             import warnings
             warnings.warn(f'per-epoch test logs of this call are NaN: {snap_bytes / 2**30:.1f} GiB of end-of-epoch snapshots '
                           f'exceed URE_SNAPSHOT_LIMIT_GB ({snapshot_limit() / 2**30:.3g}); train_loss and log0 are complete')
-        models, job, losses = {}, None, {}
+        models, job = {}, None
         if mine:
             batch = as_loader(train_dlist[mine[0]]).batch_size
             job = engine.TrainJob([prepared[i][0] for i in mine], [prepared[i][1] for i in mine],
@@ -223,7 +223,6 @@ class Sisa(Scratch):
             for pos, i in enumerate(mine):
                 U, V = job.tables(pos)
                 models[i] = (U.clone().contiguous(), V.clone().contiguous())
-                losses[i] = [float(x) for x in np.sqrt(job.epoch_sse(pos) / prepared[i][0].N)]
         if dist:
             # the only exchange of the path (sisa.py:52-58): own user rows + item table of every shard, one all-gather
             dev = engine._device()
@@ -245,9 +244,8 @@ class Sisa(Scratch):
         out = {i: MF.from_tables(*models[i]) for i in ids}
 
         # ---- logs, shard after shard in the reference's order (one dict for all shards)
-        logs = {}
-        for i in mine:
-            entry = {'train_loss': losses[i]}
+        logs, queued = {}, {}
+        for i in mine:                # every shard's two test series are queued first; results are read once, below
             if keep_logs:
                 total_ev = as_loader(test_data).eval_set()
                 test_ev = as_loader(test_dlist[i]).eval_set()
@@ -266,7 +264,11 @@ class Sisa(Scratch):
                 snapU, snapV = job.snapshots_of(pos)
                 test_ev.evaluate_series(before, snapU, snapV, job.d, res[0])
                 total_ev.evaluate_series(before, snapU, snapV, job.d, res[1])
-                res = res.cpu().numpy().transpose(1, 0, 2)
+                queued[i] = res
+        for pos, i in enumerate(mine):
+            entry = {'train_loss': [float(x) for x in np.sqrt(job.epoch_sse(pos) / prepared[i][0].N)]}
+            if keep_logs:
+                res = queued[i].cpu().numpy().transpose(1, 0, 2)
                 for c, key in enumerate(('test_rmse', 'test_ndcg', 'test_hr')):
                     entry[key] = [float(x) for x in res[:, 0, c]]
                 for c, key in enumerate(('total_rmse', 'total_ndcg', 'total_hr')):
