@@ -18,7 +18,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def measure(shards=5, k=32, epochs=50, parallel=1, delper=2.0, data=None, reps=3):
+def measure(shards=5, k=32, epochs=50, parallel=1, delper=2.0, data=None, reps=3, workload='ml1m'):
     """Wall time of Sisa.learn and Sisa.unlearn (per-epoch evals, merge and final test included)
     on the ml-1m-shaped synthetic set; the last of `reps` repetitions is reported (the first two warm
     the device allocator and the pinned permutation pool)."""
@@ -27,7 +27,7 @@ def measure(shards=5, k=32, epochs=50, parallel=1, delper=2.0, data=None, reps=3
     from ultrare_amd.method.sisa import Sisa
     from ultrare_amd.read import RatingData, loadData
 
-    data = data or synth.make_dataset(**synth.ML1M)
+    data = data or synth.make_dataset(**(synth.ML1M if workload == 'ml1m' else synth.ML25M))
     n_user, n_item = data['n_user'], data['n_item']
     shard_of, groups = synth.uniform_shards(n_user, a.shards)
     del_user = np.random.RandomState(1).choice(n_user, int(a.delper / 100 * n_user), replace=False)
@@ -78,8 +78,10 @@ def main():
     ap.add_argument('--epochs', type=int, default=50)
     ap.add_argument('--parallel', type=int, default=1)
     ap.add_argument('--delper', type=float, default=2.0)
+    ap.add_argument('--workload', choices=['ml1m', 'ml25m'], default='ml1m')
+    ap.add_argument('--reps', type=int, default=3)
     a = ap.parse_args()
-    print(json.dumps(measure(a.shards, a.k, a.epochs, a.parallel, a.delper)))
+    print(json.dumps(measure(a.shards, a.k, a.epochs, a.parallel, a.delper, reps=a.reps, workload=a.workload)))
 
 
 if __name__ == '__main__':
