@@ -254,3 +254,26 @@ def test_kmeans_kernels_vs_oracle_random(n, k, d, balanced):
     np.random.seed(3)
     label, inertia = singleKmeans(k, n, X, balanced, 6)
     assert np.array_equal(label, want_label) and inertia == want_inertia
+
+
+@pytest.mark.gpu
+def test_late_permutation_chunks_do_not_change_results(monkeypatch):
+    """The parallel path uploads the epoch permutations in chunks of 8 epochs while training already runs; TrainJob.run
+    must not launch a step whose batch tags need a chunk that has not arrived.  With the workers slowed down so that
+    every chunk is late (the device would otherwise run far ahead), the models and logs stay bitwise the same."""
+    from ultrare_amd import rng
+    from ultrare_amd.method.sisa import Sisa
+    S, E = 3, 20
+    idx, trd, ted, tot = _sisa_inputs(S)
+    out = []
+    for delay in (0.0, 0.03):
+        monkeypatch.setattr(rng, '_TEST_CHUNK_DELAY_S', delay)
+        sisa = Sisa(Param(E, parallel=True), 'mf', S, idx)
+        torch.manual_seed(42)
+        ml = sisa.learn(trd, ted, tot, 0, '')
+        out.append(([m.item_mat.weight.detach().clone() for m in ml], ml[0].user_mat.weight.detach().clone(), dict(sisa.log), dict(sisa.log0)))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(out[0][1], out[1][1])
+    assert out[0][2]['train_loss'] == out[1][2]['train_loss'] and out[0][2]['total_ndcg'] == out[1][2]['total_ndcg']
+    assert out[0][3] == out[1][3]

@@ -238,6 +238,7 @@ def epoch_perms_async(seeds, n, threads=0, pooled=False, device=None):
 
 
 _SHARD_POOL = None
+_TEST_CHUNK_DELAY_S = 0.0      # tests only: the worker sleeps this long before every chunk (late arrivals must not change results)
 
 
 class ShardDraws:
@@ -343,6 +344,9 @@ def shard_draws_async(start_state, n_user, n_item, k, epochs, with_total_test, n
             st.wait_event(ready)
         c0 = 0
         for c1, flag, slot in on_dev._ure_chunks:
+            if _TEST_CHUNK_DELAY_S:
+                import time
+                time.sleep(_TEST_CHUNK_DELAY_S)
             nv.check(nv.lib().ure_host_randperm(sd[c0:c1].ctypes.data, c1 - c0, n_rows, host[c0:c1].data_ptr(), int(threads or 0)), 'ure_host_randperm')
             with torch.cuda.device(dev), torch.cuda.stream(st):
                 on_dev[c0:c1].copy_(host[c0:c1], non_blocking=True)
