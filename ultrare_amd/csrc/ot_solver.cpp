@@ -29,10 +29,12 @@
 // round, next to training steps that run hundreds of thousands of times.  The cost
 // matrix (ure_ot_cost) and the centroid update (ure_ot_centroids) stay on the GPU.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "ultrare_hip.h"
@@ -57,21 +59,43 @@ constexpr int64_t kInf = std::numeric_limits<int64_t>::max() / 4;
 
 }  // namespace
 
+// [0, n) cut into contiguous pieces, one per host thread (the large instances -- n = 162,000, k = 32 -- spend their
+// time in O(n k) passes over the cost matrix; small ones run on the calling thread)
+template <typename F>
+static void parallel_ranges(int64_t n, int64_t grain, F &&body)
+{
+    int nt = (int)std::min<int64_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), (n + grain - 1) / grain);
+    if (nt <= 1) { body(0, n, 0); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) pool.emplace_back([&, t]() { body(n * t / nt, n * (t + 1) / nt, t); });
+    for (auto &th : pool) th.join();
+}
+
 // fp32 costs [k][n] -> int64 [n][k] on a common power-of-two scale (exact unless the dynamic range is absurd)
 static int to_fixed_point(const float *dist, int64_t n, int k, std::vector<int64_t> &cost, int *shift_out)
 {
     int e_min = std::numeric_limits<int>::max(), e_max = std::numeric_limits<int>::min();
-    for (int64_t t = 0; t < n * k; ++t) {
-        const float v = dist[t];
-        if (!(v >= 0.0f) || std::isinf(v)) return ure::fail(-1, "ure_ot_assign: cost %lld is negative, NaN or inf", (long long)t);
-        if (v == 0.0f) continue;
-        uint32_t bits;
-        __builtin_memcpy(&bits, &v, 4);
-        int e = (int)(bits >> 23) - 126;          // v = m * 2^e, m in [0.5, 1)  (frexp convention; subnormals: below)
-        if ((bits >> 23) == 0) (void)std::frexp(v, &e);
-        e_min = std::min(e_min, e - 24);          // ulp(v) = 2^(e-24)
-        e_max = std::max(e_max, e);
-    }
+    std::atomic<int64_t> bad{-1};
+    int lo[16], hi[16];
+    for (int t = 0; t < 16; ++t) { lo[t] = e_min; hi[t] = e_max; }
+    parallel_ranges(n * k, 1 << 18, [&](int64_t b, int64_t e_, int th) {
+        int mn = std::numeric_limits<int>::max(), mx = std::numeric_limits<int>::min();
+        for (int64_t t = b; t < e_; ++t) {
+            const float v = dist[t];
+            if (!(v >= 0.0f) || std::isinf(v)) { bad.store(t); return; }
+            if (v == 0.0f) continue;
+            uint32_t bits;
+            __builtin_memcpy(&bits, &v, 4);
+            int e = (int)(bits >> 23) - 126;      // v = m * 2^e, m in [0.5, 1)  (frexp convention; subnormals: below)
+            if ((bits >> 23) == 0) (void)std::frexp(v, &e);
+            mn = std::min(mn, e - 24);            // ulp(v) = 2^(e-24)
+            mx = std::max(mx, e);
+        }
+        lo[th] = mn;
+        hi[th] = mx;
+    });
+    if (bad.load() >= 0) return ure::fail(-1, "ure_ot_assign: cost %lld is negative, NaN or inf", (long long)bad.load());
+    for (int t = 0; t < 16; ++t) { e_min = std::min(e_min, lo[t]); e_max = std::max(e_max, hi[t]); }
     int shift = 0;                               // cost_int = v * 2^shift
     if (e_max != std::numeric_limits<int>::min()) {
         int guard = 3;
@@ -82,10 +106,12 @@ static int to_fixed_point(const float *dist, int64_t n, int k, std::vector<int64
     }
     cost.resize((size_t)n * k);
     const double scale = std::ldexp(1.0, shift);
-    for (int c = 0; c < k; ++c) {
-        const float *row = dist + (size_t)c * n;
-        for (int64_t i = 0; i < n; ++i) cost[(size_t)i * k + c] = (int64_t)std::llround((double)row[i] * scale);
-    }
+    parallel_ranges(n, 4096, [&](int64_t b, int64_t e_, int) {      // transposing write, a block of points per thread
+        for (int c = 0; c < k; ++c) {
+            const float *row = dist + (size_t)c * n;
+            for (int64_t i = b; i < e_; ++i) cost[(size_t)i * k + c] = (int64_t)std::llround((double)row[i] * scale);
+        }
+    });
     *shift_out = shift;
     return 0;
 }
@@ -248,11 +274,18 @@ extern "C" int ure_ot_assign_warm(const float *dist, int64_t n, int k, const dou
     std::vector<int64_t> load(k, 0);
     std::vector<std::vector<int32_t>> members(k);
     for (int c = 0; c < k; ++c) members[c].reserve((size_t)(n / k + n / (4 * k) + 16));
-    for (int64_t i = 0; i < n; ++i) {
-        const int64_t *ci = &cost[(size_t)i * k];
-        int best = 0;
-        for (int c = 1; c < k; ++c)
-            if (ci[c] - pot[c] < ci[best] - pot[best]) best = c;
+    std::vector<int32_t> first(n);
+    parallel_ranges(n, 8192, [&](int64_t b, int64_t e_, int) {
+        for (int64_t i = b; i < e_; ++i) {
+            const int64_t *ci = &cost[(size_t)i * k];
+            int best = 0;
+            for (int c = 1; c < k; ++c)
+                if (ci[c] - pot[c] < ci[best] - pot[best]) best = c;
+            first[i] = best;
+        }
+    });
+    for (int64_t i = 0; i < n; ++i) {                            // member lists in ascending point id
+        const int best = first[i];
         x[(size_t)i * k + best] = k;
         load[best] += k;
         members[best].push_back((int32_t)i);
@@ -284,7 +317,12 @@ extern "C" int ure_ot_assign_warm(const float *dist, int64_t n, int k, const dou
         wa[a] = kInf;
         ga[a] = -1;
     };
-    for (int a = 0; a < k; ++a) rescan_row(a);
+    {   // all rows once, in parallel (each touches its own row of w / arg and its own member list)
+        std::atomic<int> next{0};
+        parallel_ranges(std::min<int64_t>(k, 16), 1, [&](int64_t, int64_t, int) {
+            for (int a = next.fetch_add(1); a < k; a = next.fetch_add(1)) rescan_row(a);
+        });
+    }
     // one edge a -> b again from a's member list (the point that realised it has left a)
     auto rescan_edge = [&](int a, int b) {
         int64_t best = kInf;
