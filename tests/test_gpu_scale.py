@@ -207,3 +207,40 @@ def test_ml1m_size_vs_reference_golden(ml1m, tmp_path):
         np.testing.assert_allclose([sisa.log0['total_rmse'], sisa.log0['total_ndcg'], sisa.log0['total_hr']], g['sisa_log0'], rtol=1e-4)
         for key in ('train_loss', 'test_rmse', 'test_ndcg', 'test_hr', 'total_rmse', 'total_ndcg', 'total_hr'):
             np.testing.assert_allclose(sisa.log[key], g['sisa_log_' + key], rtol=1e-4, err_msg=key)
+
+
+def test_configs4_shards_50_epochs_vs_oracle_including_the_ones_that_diverge(ml1m):
+    """BASELINE configs[4] (ml-1m, 16 shards, k = 16) over the full 50 epochs.  On the synthetic set two shards hold a
+    user with ~2,800 ratings and the reference's summed-loss SGD diverges on them: the engine must follow
+    the oracle there too -- finite while the oracle is finite, NaN once it is NaN -- and match it to 1e-4 on a shard
+    that converges."""
+    from ultrare_amd import engine, rng, synth
+    n_user, n_item, k, B, E, S = ml1m['n_user'], ml1m['n_item'], 16, 30000, 50, 16
+    shard_of, _ = synth.uniform_shards(n_user, S)
+    parts = synth.split_shards(ml1m['train'], shard_of, S)
+    torch.manual_seed(42)
+    inits, perms = [], []
+    for p in parts:
+        inits.append(rng.mf_init(n_user, n_item, k))
+        perms.append(rng.epoch_perms(rng.epoch_seeds(E, True), len(p[0])))
+    pick = [3, 13]
+    job = engine.TrainJob([engine.ShardData(*parts[s], n_user, n_item) for s in pick], [inits[s] for s in pick],
+                          [perms[s] for s in pick], k, B, E, 1e-3, 0.1, 0.9, 0.95)
+    job.run()
+    seen_nan = False
+    for pos, s in enumerate(pick):
+        st = O.MFState(inits[s][0].numpy().copy(), inits[s][1].numpy().copy())
+        want = np.array([O.train_epoch(st, parts[s], perms[s][t].numpy(), B, 1e-3, 0.1, 0.9)[0] for t in range(E)])
+        got = np.sqrt(job.epoch_sse(pos) / len(parts[s][0]))
+        U, V = (t.cpu().numpy() for t in job.tables(pos))
+        if np.isfinite(want).all():
+            assert rel(U, st.U) < 1e-4 and rel(V, st.V) < 1e-4
+            np.testing.assert_allclose(got, want, rtol=1e-4)
+        else:
+            seen_nan = True
+            first = int(np.flatnonzero(~np.isfinite(want))[0])
+            assert first > 5 and not np.isfinite(got[first:]).any() and np.isnan(U).any() and np.isnan(st.U).any()
+            np.testing.assert_allclose(got[:first - 3], want[:first - 3], rtol=1e-3)     # identical until the blow-up amplifies rounding
+            assert np.isfinite(got[:first - 1]).all()
+    assert seen_nan, 'the synthetic set changed: no shard of this selection diverges any more'
+    job.close()
