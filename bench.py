@@ -72,6 +72,9 @@ def parse():
 # ------------------------------------------------------------------------------------------------
 # N > 1 without a launcher: start the ranks ourselves, BEFORE this process touches the GPU
 # ------------------------------------------------------------------------------------------------
+SPAWN_GRACE_S = 10.0
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` with no WORLD_SIZE: N children of this script, one per GPU, with the
     torch.distributed environment of a single-node launch.  Children are fresh processes (never an
@@ -79,13 +82,16 @@ def spawn_ranks(n):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the hosts of this pool support dmabuf IPC only; with the legacy mode RCCL's
+    # intra-node transport setup fails in hipIpcGetMemHandle ("invalid argument").  The image exports it already;
+    # it is repeated here so that a caller's scrubbed environment cannot drop it.
     base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                 HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                               env=dict(base, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=None if r == 0 else subprocess.DEVNULL)
              for r in range(n)]
-    rc = 0
+    rc, deadline = 0, None
     try:
         pending = set(range(n))
         while pending:
@@ -95,9 +101,13 @@ def spawn_ranks(n):
                     continue
                 pending.discard(r)
                 if code != 0 and rc == 0:
-                    rc = code
-                    for q in pending:          # one rank failed: the others would wait in a collective for ever
-                        procs[q].terminate()
+                    # one rank failed: the others would wait in a collective for ever.  They get a grace period
+                    # to fail (and say why) by themselves before they are terminated.
+                    rc, deadline = code, time.time() + SPAWN_GRACE_S
+            if deadline is not None and time.time() > deadline:
+                for q in pending:
+                    procs[q].terminate()
+                deadline = float('inf')
             time.sleep(0.05)
     finally:
         for p in procs:

@@ -463,7 +463,9 @@ def test_bench_spawn_propagates_rank_failure_without_hanging():
     if torch.cuda.is_available():
         pytest.skip('a GPU is visible: covered by tests/test_gpu_multirank.py')
     assert p.returncode != 0 and time.time() - t0 < 120
-    assert b'needs an MI355X' in p.stderr and p.stderr.count(b'needs an MI355X') == 2      # both ranks were started
+    # the first failing rank decides the code; its peers get a grace period to report by themselves before they are
+    # terminated, so at least one message (normally both) arrives
+    assert 1 <= p.stderr.count(b'needs an MI355X') <= 2
 
 
 def test_exchange_plan_is_a_padded_all_gather_v():
