@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define URE_ABI_VERSION 3
+#define URE_ABI_VERSION 4
 #define URE_MAX_MODELS_PER_CALL 32
 #define URE_SCORE_PARTIALS 2048       /* length of ure_score's sse buffer */
 
@@ -103,6 +103,11 @@ typedef struct ure_shard {
     float       *snapU;     /* [epochs][n_user][d]                                   */
     float       *snapV;     /* [epochs][n_item][d]                                   */
     const float *snap_a;    /* [epochs] device                                       */
+    /* The same in compact form (instead of snapU / snapV; needs lazy_rows): only the n_active rows that have
+     * interactions in the shard are stored, in schedule order -- snap[e][idx] = the row sched[idx] after epoch e.
+     * Every other row of the tables is a_e * w0 by construction and is rebuilt where it is read
+     * (ure_eval_series_compact).  At BASELINE.json configs[3] a shard has 60.8 k active rows of 222 k.   */
+    float       *snap;      /* [epochs][n_active][d]                                 */
     /* per-epoch inputs / outputs */
     const int32_t *perm;    /* [epochs][N] the epoch permutations (RandomSampler)   */
     const float   *lr;      /* [epochs] learning rate of each epoch (StepLR)        */
@@ -112,11 +117,12 @@ typedef struct ure_shard {
     int32_t batch;          /* B (config.py:26)                                     */
     int32_t epochs;
     float   lam, mu;        /* weight decay, momentum (config.py:20,29)             */
-    /* Touch mode (needs lazy_rows, at most 64 steps per epoch, and the same lr / lam / mu schedule for
+    /* Touch mode (needs lazy_rows, at most 32000 steps per epoch, and the same lr / lam / mu schedule for
      * every shard of the job): a step visits only the rows it trains; rows are kept valid for their NEXT
-     * own step and advanced over the steps in between by the optimizer's closed form (csrc/mf_touch.h).
-     * For jobs whose tables do not fit the caches (BASELINE.json configs[3]).  The tables can then be
-     * read (ure_job_materialize, snapshots) at the shard's epoch boundaries only.               */
+     * own step and advanced over the steps in between by the optimizer's closed form (csrc/mf_touch.h;
+     * epochs longer than 64 steps are worked off in windows of 64).
+     * For jobs whose tables do not fit the caches (BASELINE.json configs[3], full MF at 25 M rows).  The
+     * tables can then be read (ure_job_materialize, snapshots) at the shard's epoch boundaries only.   */
     int32_t touch_mode;
     /* touch mode: the first n_multi rows of the schedule are longer than one scan pass (8 * lanes slots)
      * and `units` covers exactly those; the rows [n_multi, n_active) fit in one pass and are worked off
@@ -147,10 +153,11 @@ int ure_job_train(ure_job_t *job, int64_t tick0, int64_t tick1, void *stream);
  * every shard, for `ticks_done` = the number of ticks trained so far.  Call before reading
  * the tables; training may continue afterwards.  No-op for shards with lazy_rows == 0. */
 int ure_job_materialize(ure_job_t *job, int64_t ticks_done, void *stream);
-/* Touch mode accounting (synchronises): rows_per_epoch[s] = the number of (row, step) pairs of shard s's current
- * epoch in which a row is trained -- the rows the step kernel actually reads and rewrites, summed over the epoch's
- * steps (from the epoch's row masks); -1 for a job that is not in touch mode.                                   */
-int ure_job_touch_rows(ure_job_t *job, int64_t *rows_per_epoch);
+/* Touch mode accounting (synchronises): pairs[s] = the number of (row, step) pairs of shard s's current window of
+ * (at most 64) steps in which a row is trained -- the rows the step kernel actually reads and rewrites, summed over
+ * the window's steps (from the window's row masks) -- and window_steps[s] = the number of steps of that window;
+ * pairs = -1 for a job that is not in touch mode.                                                                */
+int ure_job_touch_rows(ure_job_t *job, int64_t *pairs, int64_t *window_steps);
 /* Measurement aid (bench.py's roofline leg): the same ticks, each kernel launch
  * bracketed by a pair of HIP events on `stream`; synchronises the stream and returns
  * the summed durations and launch counts of the step kernel and of the per-epoch
@@ -241,6 +248,17 @@ int ure_eval_series(const float *const *U_fixed, const float *const *V_fixed, in
                     const float *rating, int64_t n, int d, const int32_t *off, int32_t n_users, const double *log2_tab, float *base,
                     float *pred, double *sse, int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide,
                     void *stream);
+
+/* The same series on COMPACT end-of-epoch snapshots (struct ure_shard: snap): member e's own model is
+ * row r -> row_slot[r] >= 0 ? snap[e * stride + row_slot[r] * d ..] : snap_a[e] * (U0 | V0)[r], with row ids
+ * r = u for users and n_user_rows + i for items (row_slot [n_user_rows + n_item_rows] int32, device: the row's index
+ * in the schedule when it is one of the n_active stored rows, -1 otherwise).  Results are identical to
+ * ure_eval_series on full snapshots: the closed form is evaluated with the same fp32 product.              */
+int ure_eval_series_compact(const float *const *U_fixed, const float *const *V_fixed, int n_fixed, const float *snap, int64_t stride,
+                            const int32_t *row_slot, const float *U0, const float *V0, const float *snap_a, int32_t n_user_rows,
+                            int n_series, const int32_t *uid, const int32_t *iid, const float *rating, int64_t n, int d,
+                            const int32_t *off, int32_t n_users, const double *log2_tab, float *base, float *pred, double *sse,
+                            int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide, void *stream);
 
 /* sisa.py:55-56,110-111: dst[rows[t]][:] = src[rows[t]][:]. */
 int ure_merge_rows(float *dst, const float *src, const int64_t *rows, int64_t n_rows, int d, void *stream);

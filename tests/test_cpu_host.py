@@ -56,6 +56,22 @@ def test_descriptor_struct_matches_header_layout(lib):
     assert got == [ctypes.sizeof(S), S.sched.offset, S.U.offset, S.N.offset, S.lam.offset]
 
 
+def test_no_step_kernel_instantiation_spills(lib):
+    """at d = 16 (the reference's default k, config.py:19) and d = 8 the step kernel was compiled under the
+    register budget tuned for d = 32 and spilled 15-16 VGPRs to scratch.  The per-width budgets (mf_train.hip: step_waves /
+    step_kgb) leave none: read from the code objects' metadata notes (tools/isa_report.py), for every instantiation of
+    both step kernels."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import isa_report
+    rows = [r for r in isa_report.kernels(lib.LIB_PATH) if 'step_kernel<' in r['name']]
+    assert len([r for r in rows if r['name'].startswith('mf_step_kernel<')]) == 7
+    assert len([r for r in rows if r['name'].startswith('mf_touch_step_kernel<')]) == 7
+    for r in rows:
+        assert r['vgpr_spill'] == 0 and r['sgpr_spill'] == 0 and r['scratch'] == 0, r
+    # and no kernel of the library at all keeps VGPRs in scratch
+    assert all(r['vgpr_spill'] == 0 for r in isa_report.kernels(lib.LIB_PATH))
+
+
 def test_argument_errors_are_reported_not_crashed(lib):
     L = lib.lib()
     out = ctypes.c_void_p()

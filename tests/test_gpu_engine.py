@@ -315,3 +315,60 @@ def test_edge_cases_tiny_shards_ragged_eval_and_large_ensembles():
     np.testing.assert_allclose(out.cpu().numpy(), got, rtol=1e-12)
     empty = engine.EvalSet(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
     assert all(np.isnan(x) for x in empty.evaluate(dev[:1], 8))
+
+
+# ---------------------------------------------------------------- compact end-of-epoch snapshots (round 3)
+@pytest.mark.parametrize('touch', [False, True])
+def test_compact_snapshots_give_the_series_of_full_snapshots(toy, touch):
+    """scratch.py:83-97 after shards were trained side by side: the per-epoch test series from COMPACT snapshots (the rows
+    with interactions in the shard; every other row rebuilt as a_e * w0 inside ure_eval_series_compact) are bit for bit those
+    from full snapshots.  Four shards of the toy set: three quarters of a shard's user rows are never trained in it."""
+    from ultrare_amd import engine, rng
+    from oracle import cpu_ref as O
+    train, test = toy
+    S, k, E, B = 4, 16, 6, 700
+    idx = O.uniform_groups(N_USER, S)
+    parts = O.partition(*train, idx)
+    torch.manual_seed(9)
+    inits = [rng.mf_init(N_USER, N_ITEM, k) for _ in parts]
+    perms = [rng.epoch_perms(rng.epoch_seeds(E, True), len(p[0])) for p in parts]
+    shards = [engine.ShardData(*p, N_USER, N_ITEM) for p in parts]
+    assert all(sh.n_active < 0.6 * (N_USER + N_ITEM) for sh in shards)
+    jobs = {m: engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, snapshots=m, touch=touch) for m in ('full', 'compact')}
+    assert jobs['compact'].snapshots == 'compact' and jobs['full'].snapshots == 'full' and jobs['compact'].touch == touch
+    for j in jobs.values():
+        j.run()
+    ev = engine.EvalSet(*test)
+    fixed = [tuple(torch.randn(n, jobs['full'].d, device=ev.device) * 0.3 for n in (N_USER, N_ITEM)) for _ in range(2)]
+    for s in range(S):
+        for before in ([], fixed):
+            res = {m: j.evaluate_series(s, ev, before, torch.zeros(E, 3, dtype=torch.float64, device=ev.device)) for m, j in jobs.items()}
+            torch.cuda.synchronize()
+            assert torch.isfinite(res['full']).all() and torch.equal(res['full'], res['compact']), (s, len(before))
+        # and member e of the series is what evaluate() gives on the full tables of epoch e
+        want = torch.zeros(E, 3, dtype=torch.float64, device=ev.device)
+        for e in range(E):
+            ev.evaluate(fixed + [jobs['full'].snapshot(s, e)], jobs['full'].d, out=want[e])
+        got = jobs['compact'].evaluate_series(s, ev, fixed, torch.zeros(E, 3, dtype=torch.float64, device=ev.device))
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    small = engine.TrainJob.snapshot_bytes(shards, E, k, 'compact')
+    assert small < 0.6 * engine.TrainJob.snapshot_bytes(shards, E, k, 'full')
+    for j in jobs.values():
+        j.close()
+
+
+def test_compact_snapshots_need_lazy_rows(toy):
+    """URE_LAZY_ROWS=0 streams every row like the reference's dense optimizer: there is no closed form to rebuild the
+    untrained rows from, so the engine keeps full snapshots."""
+    from ultrare_amd import engine, rng
+    train, _ = toy
+    torch.manual_seed(1)
+    init = rng.mf_init(N_USER, N_ITEM, 8)
+    perms = rng.epoch_perms(rng.epoch_seeds(2, False), len(train[0]))
+    job = engine.TrainJob([engine.ShardData(*train, N_USER, N_ITEM)], [init], [perms], 8, 3000, 2, 1e-3, 0.1, 0.9, lazy_rows=False, snapshots='compact')
+    assert job.snapshots == 'full'
+    job.run()
+    U, V = job.padded_tables(0)
+    assert torch.equal(job.snapshot(0, 1)[0], U) and torch.equal(job.snapshot(0, 1)[1], V)
+    job.close()

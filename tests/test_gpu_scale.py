@@ -1,6 +1,8 @@
 """GPU parity at BASELINE.json's sizes (the configs other than the bench workload are
 parity cases): the HIP path against the CPU oracle on the same seeded inputs where the
 oracle finishes in seconds, plus size-independent properties of the SISA path."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -244,3 +246,34 @@ def test_configs4_shards_50_epochs_vs_oracle_including_the_ones_that_diverge(ml1
             assert np.isfinite(got[:first - 1]).all()
     assert seen_nan, 'the synthetic set changed: no shard of this selection diverges any more'
     job.close()
+
+
+# ---------------------------------------------------------------- what bench.py's unlearn figures time (round 3)
+def _tool(name):
+    import importlib.util
+    sp = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(os.path.dirname(__file__)), 'tools', name + '.py'))
+    mod = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(mod)
+    return mod
+
+
+def test_timed_unlearn_call_builds_its_layouts():
+    """`unlearn_wall_s` used to be a third repetition over the same loaders, whose HBM layouts were cached by the
+    first.  Every repetition of tools/e2e_sisa.measure is now a new request -- its own deletion set, freshly made train loaders --
+    so the timed learn builds the layout of every shard and the timed unlearn that of every shard it retrains."""
+    from ultrare_amd import synth
+    data = synth.make_dataset(n_user=1200, n_item=900, n_train=90000, n_test=10000, seed=5)
+    r = _tool('e2e_sisa').measure(shards=4, k=8, epochs=2, parallel=1, delper=2.0, data=data, reps=2)
+    assert r['layouts_built'] == {'learn': 4, 'unlearn': r['retrained_shards']} and r['retrained_shards'] >= 1
+    assert r['deleted_users'] == 24 and np.isfinite(list(r['unlearn_log0'].values())).all()
+
+
+def test_cold_request_rebuilds_everything():
+    """tools/e2e_cold.measure (bench.py: unlearn.cold_request_s) is the reference's CLI flow, config.py:139-172: CSV files ->
+    readRating with the deletion list -> loaders -> layouts -> unlearn -> merge -> test, nothing resident beforehand."""
+    from ultrare_amd import synth
+    data = synth.make_dataset(n_user=1200, n_item=900, n_train=90000, n_test=10000, seed=5)
+    r = _tool('e2e_cold').measure(shards=4, k=8, epochs=2, data=data)
+    assert r['learn']['layouts_built'] == 4 and r['unlearn']['layouts_built'] == r['retrained'] >= 1
+    assert r['unlearn']['total_s'] >= r['unlearn']['train_merge_test_s'] > 0
+    assert np.isfinite(list(r['unlearn_log0'].values())).all()

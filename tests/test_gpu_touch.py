@@ -122,12 +122,12 @@ def test_touch_mode_is_bitwise_reproducible():
 
 
 def test_touch_mode_refusals():
-    """More than 64 steps per epoch, or without lazy rows: the engine falls back to the default kernel; the C ABI
-    refuses a descriptor that asks for touch mode there."""
+    """Without lazy rows the engine falls back to the default kernel (the C ABI refuses a descriptor that asks for touch
+    mode there); 95 steps per epoch -- refused in round 2 -- now run in two windows."""
     from ultrare_amd import engine
     parts, inits, perms, shards = _setup(1, 16, 300, 1)           # 95 steps per epoch
     job = engine.TrainJob(shards, inits, perms, 16, 300, 1, 1e-3, 0.1, 0.9, 0.95, touch=True)
-    assert not job.touch
+    assert job.touch
     job.run()
     job.close()
     job = engine.TrainJob(shards, inits, perms, 16, 300, 1, 1e-3, 0.1, 0.9, 0.95, touch=True, lazy_rows=False)
@@ -186,3 +186,72 @@ def test_touch_rows_accounting_matches_the_permutations():
     dense = engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=False)
     assert dense.touch_rows_per_step() is None
     dense.close()
+
+
+# ---------------------------------------------------------------- epochs longer than one 64-step window (round 3)
+def _truncate(part, n):
+    return tuple(x[:n] for x in part)
+
+
+@pytest.mark.parametrize('n_rows,B,k,E', [(None, 437, 16, 3), (None, 219, 32, 2), (27714, 37, 16, 2), (None, 219, 128, 2)])
+def test_touch_mode_windows_vs_oracle(n_rows, B, k, E):
+    """65, 130 and 750 optimizer steps per epoch (full MF at 25 M rows has 750: config.py:182-188 with batch 30,000): an
+    epoch is worked off in windows of 64 steps, each with its own row masks; a row that is not trained in a window is
+    carried to the window's end in one closed-form step and on from there.  Against the C oracle's dense optimizer."""
+    from ultrare_amd import engine, rng
+    raw = O.load_csv(TRAIN)
+    part = O.partition(*raw, O.uniform_groups(N_USER, 1))[0]
+    if n_rows:
+        part = _truncate(part, n_rows)
+    steps = (len(part[0]) + B - 1) // B
+    assert steps in (65, 130, 750), steps
+    torch.manual_seed(11)
+    init = rng.mf_init(N_USER, N_ITEM, k)
+    perms = rng.epoch_perms(rng.epoch_seeds(E, True), len(part[0]))
+    job = engine.TrainJob([engine.ShardData(*part, N_USER, N_ITEM)], [init], [perms], k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=True)
+    assert job.touch
+    job.run()
+    st = O.MFState(init[0].numpy().copy(), init[1].numpy().copy())
+    losses = [O.train_epoch(st, part, perms[t].numpy(), B, 1e-3, 0.1, 0.9)[0] for t in range(E)]
+    U, V = job.tables(0)
+    assert rel(U, st.U) < 2e-5 and rel(V, st.V) < 2e-5, (rel(U, st.U), rel(V, st.V))
+    np.testing.assert_allclose(np.sqrt(job.epoch_sse(0) / len(part[0])), losses, rtol=2e-5)
+    job.close()
+
+
+def test_touch_mode_windows_with_shards_of_different_length_and_the_steplr_boundary():
+    """Three shards whose epochs have 93-96 steps (one full window and a short one, ending on different ticks), 52 epochs:
+    window starts of different shards fall on different ticks, and epochs 51-52 run at the decayed learning rate."""
+    from ultrare_amd import engine
+    S, k, B, E = 3, 16, 100, 52
+    parts, inits, perms, shards = _setup(S, k, B, E, seed=5)
+    assert len({(len(p[0]) + B - 1) // B for p in parts}) > 1 and all((len(p[0]) + B - 1) // B > 64 for p in parts)
+    job = engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=True, snapshots='compact')
+    job.run()
+    for s, p in enumerate(parts):
+        st = O.MFState(inits[s][0].numpy().copy(), inits[s][1].numpy().copy())
+        for t in range(E):
+            O.train_epoch(st, p, perms[s][t].numpy(), B, 1e-3 * 0.95 ** (t // 50), 0.1, 0.9)
+        U, V = job.tables(s)
+        assert rel(U, st.U) < 3e-5 and rel(V, st.V) < 3e-5, (s, rel(U, st.U), rel(V, st.V))
+        # the last compact snapshot holds the active rows of the final tables
+        sh = shards[s]
+        rows = torch.as_tensor(sh._sched_host[:sh.n_active, 0].astype(np.int64)).to(U.device)
+        full = torch.cat([job.padded_tables(s)[0], job.padded_tables(s)[1]])
+        assert torch.equal(job.state[s]['snap'][E - 1], full[rows])
+    job.close()
+
+
+def test_touch_mode_windows_match_the_default_kernel_epoch_by_epoch():
+    from ultrare_amd import engine
+    k, B, E = 32, 150, 3
+    parts, inits, perms, shards = _setup(1, k, B, E, seed=3)
+    assert (len(parts[0][0]) + B - 1) // B > 128
+    jobs = [engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=t) for t in (False, True)]
+    for e in range(E):
+        for j in jobs:
+            j.run_epochs(1)
+        (U0, V0), (U1, V1) = jobs[0].tables(0), jobs[1].tables(0)
+        assert rel(U1, U0) < 1e-5 and rel(V1, V0) < 1e-5, e
+    for j in jobs:
+        j.close()

@@ -19,18 +19,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def measure(shards=5, k=32, epochs=50, parallel=1, delper=2.0, data=None, reps=3, workload='ml1m'):
-    """Wall time of Sisa.learn and Sisa.unlearn (per-epoch evals, merge and final test included)
-    on the ml-1m-shaped synthetic set; the last of `reps` repetitions is reported (the first two warm
-    the device allocator and the pinned permutation pool)."""
+    """Wall time of Sisa.learn and Sisa.unlearn (per-epoch evals, merge and final test included) on the synthetic set;
+    the last of `reps` repetitions is reported.  Every repetition is a NEW request: its own deletion set (a different 2 %
+    of the users) and freshly made train loaders, so the HBM layouts of the shards it trains are built and uploaded
+    INSIDE the timed calls (`layouts_built` counts them); what the earlier repetitions leave behind is a warm device
+    allocator, the pinned permutation pool and the test sets (a deletion does not change them: config.py:139-172 reads
+    the test files without the deletion list)."""
     a = argparse.Namespace(shards=shards, k=k, epochs=epochs, parallel=parallel, delper=delper)
-    from ultrare_amd import synth
+    from ultrare_amd import engine, synth
     from ultrare_amd.method.sisa import Sisa
     from ultrare_amd.read import RatingData, loadData
 
     data = data or synth.make_dataset(**(synth.ML1M if workload == 'ml1m' else synth.ML25M))
     n_user, n_item = data['n_user'], data['n_item']
     shard_of, groups = synth.uniform_shards(n_user, a.shards)
-    del_user = np.random.RandomState(1).choice(n_user, int(a.delper / 100 * n_user), replace=False)
 
     class P:
         k, lam, seed, batch, lr, lr_decay, momentum, epochs = a.k, 0.1, 42, 30000, 0.001, 0.95, 0.9, a.epochs
@@ -40,34 +42,43 @@ def measure(shards=5, k=32, epochs=50, parallel=1, delper=2.0, data=None, reps=3
     def loaders(triple, shuffle):
         return [loadData(RatingData(np.vstack(p)), P.batch, 24, shuffle) for p in synth.split_shards(triple, shard_of, a.shards)]
 
-    keep = ~np.isin(data['train'][0], del_user)
-    trd, ted = loaders(data['train'], True), loaders(data['test'], False)
-    trd_del = loaders(tuple(x[keep] for x in data['train']), True)
+    ted = loaders(data['test'], False)
     tot_arr = [np.concatenate([p[c] for p in synth.split_shards(data['test'], shard_of, a.shards)]) for c in range(3)]
     tot = loadData(RatingData(np.vstack(tot_arr)), P.batch, 24, False)
     torch.cuda.synchronize()
 
     out = {'shards': a.shards, 'k': a.k, 'epochs': a.epochs, 'parallel': bool(a.parallel),
-           'train_rows': int(len(data['train'][0])), 'deleted_users': int(len(del_user))}
-    for rep in range(reps):       # rep 0 warms allocator / caches / layout caches
+           'train_rows': int(len(data['train'][0]))}
+    for rep in range(reps):       # earlier repetitions warm the allocator and the pinned pool; no layout survives them
+        del_user = np.random.RandomState(1 + rep).choice(n_user, int(a.delper / 100 * n_user), replace=False)
+        keep = ~np.isin(data['train'][0], del_user)
+        trd = loaders(data['train'], True)
+        trd_del = loaders(tuple(x[keep] for x in data['train']), True)
         sisa = Sisa(P, 'mf', a.shards, groups)
         torch.manual_seed(42)
+        built0 = engine.ShardData.built
         t0 = time.perf_counter()
         ml = sisa.learn(trd, ted, tot, 0, '')
         torch.cuda.synchronize()
         t_learn = time.perf_counter() - t0
+        built_learn = engine.ShardData.built - built0
         s2 = Sisa(P, 'mf', a.shards, groups)
         snap = [copy.deepcopy(m) for m in ml]
         torch.manual_seed(42)
+        built0 = engine.ShardData.built
         t0 = time.perf_counter()
         s2.unlearn(snap, trd_del, ted, tot, del_user.tolist(), 0, '')
         torch.cuda.synchronize()
         t_unlearn = time.perf_counter() - t0
+        built_unlearn = engine.ShardData.built - built0
     n_learn = len(data['train'][0]) * a.epochs
     n_un = int(keep.sum()) * a.epochs if len(s2.retrained) == a.shards else None
-    out.update(learn_s=round(t_learn, 4), unlearn_s=round(t_unlearn, 4), retrained_shards=len(s2.retrained),
+    nan_shards = int(sum(1 for m in s2.model_list if not bool(torch.isfinite(m.item_mat.weight).all())))
+    out.update(learn_s=round(t_learn, 4), unlearn_s=round(t_unlearn, 4), retrained_shards=len(s2.retrained), deleted_users=int(len(del_user)),
+               deletion_set=f'RandomState({reps}).choice: a different 2 % in every repetition',
+               layouts_built={'learn': built_learn, 'unlearn': built_unlearn},
                learn_interactions_per_s=round(n_learn / t_learn, 1), log0=sisa.log0, unlearn_log0=s2.log0,
-               unlearn_interactions=n_un)
+               unlearn_interactions=n_un, nan_shards=nan_shards)
     return out
 
 

@@ -11,7 +11,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('URE_LIB') or os.path.join(_PKG, 'libultrare_hip.so')      # URE_LIB: experiment builds (tools/) only
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_MODELS_PER_CALL = 32
 
 _vp = ctypes.c_void_p
@@ -26,7 +26,7 @@ class UreShard(ctypes.Structure):
         ('sched', _vp), ('units', _vp), ('n_units', _i32), ('n_active', _i32), ('n_slots', _i64),
         ('U', _vp * 2), ('V', _vp * 2), ('mU', _vp), ('mV', _vp),
         ('U0', _vp), ('V0', _vp), ('lr_host', _vp), ('lazy_rows', _i32),
-        ('snapU', _vp), ('snapV', _vp), ('snap_a', _vp),
+        ('snapU', _vp), ('snapV', _vp), ('snap_a', _vp), ('snap', _vp),
         ('perm', _vp), ('lr', _vp), ('sse', _vp),
         ('N', _i32), ('n_user', _i32), ('n_item', _i32), ('d', _i32),
         ('batch', _i32), ('epochs', _i32),
@@ -51,7 +51,7 @@ _PROTOTYPES = {
     'ure_job_ticks': (_i64, [_vp]),
     'ure_job_train': (ctypes.c_int, [_vp, _i64, _i64, _vp]),
     'ure_job_materialize': (ctypes.c_int, [_vp, _i64, _vp]),
-    'ure_job_touch_rows': (ctypes.c_int, [_vp, _vp]),
+    'ure_job_touch_rows': (ctypes.c_int, [_vp, _vp, _vp]),
     'ure_job_train_profiled': (ctypes.c_int, [_vp, _i64, _i64, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
                                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64)]),
     'ure_host_randperm': (ctypes.c_int, [_vp, ctypes.c_int, _i64, _vp, ctypes.c_int]),
@@ -70,6 +70,9 @@ _PROTOTYPES = {
     'ure_eval_reduce': (ctypes.c_int, [_vp, _vp, _i32, _vp, _i64, _vp, _vp]),
     'ure_eval_series': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, _vp, _vp, _i64, _i64, ctypes.c_int, _vp, _vp,
                                        _vp, _i64, ctypes.c_int, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    'ure_eval_series_compact': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, _vp, _i64, _vp, _vp, _vp, _vp, _i32,
+                                               ctypes.c_int, _vp, _vp, _vp, _i64, ctypes.c_int, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                               _vp, _i32, _vp]),
     'ure_merge_rows': (ctypes.c_int, [_vp, _vp, _vp, _i64, ctypes.c_int, _vp]),
     'ure_ot_cost': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'ure_ot_cost_mfma': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp]),

@@ -9,8 +9,10 @@
 // epoch's learning rate: StepLR changes it between epochs only).  Touch mode keeps every row in
 // NEXT-TOUCH FORM: the stored (w, m) are valid for the step at which the row has its next interaction
 // (or the end of the epoch).  Then
-//   * a step visits only the rows it trains: a 64-bit mask per row and epoch says in which steps of
-//     the epoch the row has interactions (steps per epoch <= 64 -- 24..27 at configs[3]);
+//   * a step visits only the rows it trains: a 64-bit mask per row says in which steps of the current
+//     WINDOW of 64 steps the row has interactions.  An epoch of up to 64 steps is one window (24..27 steps
+//     at configs[3]); longer epochs (full MF at 25 M rows: 750 steps, config.py:182-188) are cut into
+//     windows, and every window start does what an epoch start does (below);
 //   * whoever gathers a row reads w only, with no time stamp and no catching up: a row is gathered in
 //     exactly the steps in which it is trained itself (interaction (u, i) of step s makes u gather i
 //     and i gather u in step s), and for those steps its stored w is current by construction;
@@ -28,9 +30,11 @@
 // 125 k workgroups per launch whose fixed cost -- two dependent loads and an exit -- set the launch time,
 // 0.94 ms against 1.03 ms for the dense kernel; profiles/r02/NOTES.md.)
 //
-// At an epoch start three launches (A) clear the epoch's mask buffer, (B) build the row masks from the
-// epoch's batch tags, (C) copy them into work order, put the buffer bits into the tags, and bring every
-// row from "valid at the epoch boundary" to "valid at its first step", into buffer 0.
+// At a window start two launches (B) build the row masks of the window from the epoch's batch tags -- a row's
+// slots belong to one workgroup, so its mask is combined in registers / LDS and stored once, in row order and
+// in work order, without atomics or a clearing pass (round 2 had a third launch for that) -- and (C) put the
+// buffer bits into the tags of the window's slots and bring every row from "valid at the window boundary" to
+// "valid at its first step of the window", into buffer 0.
 //
 // Included by mf_train.hip after its constants (kQueue, kSegPerLane, lanes_per_row) and helpers.
 #pragma once
@@ -38,9 +42,26 @@
 
 namespace ure {
 
-constexpr int kTouchMaxSteps = 64;          // steps per epoch a 64-bit row mask can describe
-constexpr int kTouchTab = kTouchMaxSteps + 1;
+constexpr int kTouchMaxSteps = 32000;       // steps per epoch: the step number shares the 16-bit tag with the buffer bit (padding slots read 0x7FFF)
+constexpr int kTouchTab = kTouchWindow + 1;
 constexpr unsigned kTagStep = 0x7FFFu;      // touch mode: bits 0..14 of a tag = the step, bit 15 = buffer of the gathered row
+
+// Where an optimizer step stands in touch mode.
+struct TouchPos {
+    int epoch, s;       // epoch, step of the epoch
+    int win, sl;        // window of the epoch, step inside the window (the bit of the row masks)
+    int wlen;           // steps of this window
+    int64_t gwin;       // global window index (parity = which mask buffer)
+};
+__device__ __forceinline__ TouchPos touch_pos(const shard_aux &A, int epoch, int s)
+{
+    TouchPos p;
+    p.epoch = epoch; p.s = s;
+    p.win = s >> kTouchWindowBits; p.sl = s & (kTouchWindow - 1);
+    p.wlen = min(kTouchWindow, A.steps - (p.win << kTouchWindowBits));
+    p.gwin = (int64_t)epoch * A.windows + p.win;
+    return p;
+}
 
 __device__ __forceinline__ unsigned long long mask_below(int s) { return s >= 64 ? ~0ull : ((1ull << s) - 1ull); }
 __device__ __forceinline__ int mask_rank_parity(unsigned long long mk, int s) { return __popcll(mk & mask_below(s)) & 1; }
@@ -66,7 +87,7 @@ __device__ __forceinline__ void row_advance(RowVec<V4> &w, RowVec<V4> &m, const 
 // -> the lane group's piece {row id or -1, first slot, end slot, unit index or -1}; *sched_idx = the row's
 // place among the single-pass rows (or -1).
 template <int LPR>
-__device__ __forceinline__ int4 touch_piece(const ure_shard_t &S, int wg, int *sched_idx)
+__device__ __forceinline__ int4 touch_piece(const ure_shard_t &S, int wg, int *sched_idx, int *unit_word = nullptr)
 {
     constexpr int UPB = kBlock / LPR;
     const int nbU = S.n_units / UPB;
@@ -75,6 +96,7 @@ __device__ __forceinline__ int4 touch_piece(const ure_shard_t &S, int wg, int *s
     *sched_idx = -1;
     if (wg < nbU) {
         const int4 du = ldg_i4(S.units + 4 * ((size_t)wg * UPB + local));
+        if (unit_word) *unit_word = du.w;
         return make_int4(du.x, du.y, du.z, wg * UPB + local);
     }
     const int rel = (wg - nbU) * UPB + local;
@@ -90,46 +112,80 @@ __host__ __device__ inline int touch_piece_blocks(int n_units, int n_active, int
     return n_units / UPB + (n_active - n_multi + UPB - 1) / UPB;
 }
 
-// ---- epoch start, launch B: the step mask of every row from the epoch's (fresh) batch tags -------------
+// ---- window start, launch B: the step mask of every row from the epoch's batch tags, stored in row order
+// (A.mask, for whoever gathers the row) and in work order (unit_mask / sched_mask, for the step kernel).
+// OR over the LPR lanes of a group (every lane ends with the result)
 template <int LPR>
-__device__ __forceinline__ void touch_build_masks(const ure_shard_t &S, const shard_aux &A, int epoch, int wg)
+__device__ __forceinline__ unsigned long long group_or(unsigned long long v)
 {
-    constexpr int CAP = kSegPerLane * LPR;
-    int si;
-    const int4 pc = touch_piece<LPR>(S, wg, &si);
-    if (pc.x < 0) return;
-    const int sub = threadIdx.x & (LPR - 1);
-    const uint16_t *__restrict__ ent_tag = S.ent_tag + (size_t)(epoch & 1) * S.n_slots;
-    unsigned long long mk = 0;
-    for (int p0 = pc.y + sub * kSegPerLane; p0 < pc.z; p0 += CAP) {
-        const uint4 t4 = ldg_u4(ent_tag + p0);
-        const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const unsigned tg = (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
-            if (tg < (unsigned)kTouchMaxSteps) mk |= 1ull << tg;
-        }
-    }
-    if (mk) atomicOr(A.mask[epoch & 1] + pc.x, mk);
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    if (LPR >= 2) { lo |= (unsigned)dpp_i<kDppQuadXor1>((int)lo); hi |= (unsigned)dpp_i<kDppQuadXor1>((int)hi); }
+    if (LPR >= 4) { lo |= (unsigned)dpp_i<kDppQuadXor2>((int)lo); hi |= (unsigned)dpp_i<kDppQuadXor2>((int)hi); }
+    if (LPR >= 8) { lo |= (unsigned)dpp_i<kDppHalfMirror>((int)lo); hi |= (unsigned)dpp_i<kDppHalfMirror>((int)hi); }
+    if (LPR >= 16) { lo |= (unsigned)dpp_i<kDppRowMirror>((int)lo); hi |= (unsigned)dpp_i<kDppRowMirror>((int)hi); }
+    if (LPR >= 32) { lo |= (unsigned)__shfl_xor((int)lo, 16, kWave); hi |= (unsigned)__shfl_xor((int)hi, 16, kWave); }
+    if (LPR >= 64) { lo |= (unsigned)__shfl_xor((int)lo, 32, kWave); hi |= (unsigned)__shfl_xor((int)hi, 32, kWave); }
+    return ((unsigned long long)hi << 32) | lo;
 }
 
-// ---- epoch start, launch C, part 1: bit 15 of every slot's tag = the buffer the slot's OTHER row is in at the
-// slot's step (parity of that row's steps before it), and the masks copied into work order
 template <int LPR>
-__device__ __forceinline__ void touch_mark_tags(const ure_shard_t &S, const shard_aux &A, int epoch, int wg)
+__device__ __forceinline__ void touch_build_masks(const ure_shard_t &S, const shard_aux &A, const TouchPos &P, int wg, unsigned long long *wg_mask)
+{
+    constexpr int CAP = kSegPerLane * LPR;
+    constexpr int UPB = kBlock / LPR;
+    int si, uw = 0;
+    const int4 pc = touch_piece<LPR>(S, wg, &si, &uw);
+    const bool in_units = wg < S.n_units / UPB;              // workgroup-uniform
+    const int sub = threadIdx.x & (LPR - 1);
+    const int local = (int)threadIdx.x / LPR;
+    const uint16_t *__restrict__ ent_tag = S.ent_tag + (size_t)(P.epoch & 1) * S.n_slots;
+    unsigned long long mk = 0;
+    if (pc.x >= 0) {
+        for (int p0 = pc.y + sub * kSegPerLane; p0 < pc.z; p0 += CAP) {
+            const uint4 t4 = ldg_u4(ent_tag + p0);
+            const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned st = (tw[k >> 1] >> ((k & 1) * 16)) & kTagStep;      // (slots of earlier windows carry their buffer bit already)
+                if ((int)(st >> kTouchWindowBits) == P.win) mk |= 1ull << (st & (kTouchWindow - 1));
+            }
+        }
+    }
+    mk = group_or<LPR>(mk);
+    if (!in_units) {
+        // a single-pass row: this lane group has seen all of its slots
+        if (pc.x >= 0 && sub == 0) {
+            stg(A.mask[P.gwin & 1] + pc.x, mk);
+            stg(A.sched_mask + si, mk);
+        }
+        return;
+    }
+    // work units: the units of a row sit side by side in this workgroup; the row's first unit combines them
+    const int leader = uw & 0xFFFF, count = (uw >> 16) & 0x3FFF;
+    if (sub == 0) wg_mask[local] = mk;
+    __syncthreads();
+    if (pc.x >= 0 && sub == 0 && local == leader) {
+        unsigned long long all = mk;
+        for (int k = 1; k < count; ++k) all |= wg_mask[leader + k];
+        stg(A.mask[P.gwin & 1] + pc.x, all);
+        wg_mask[leader] = all;
+    }
+    __syncthreads();
+    if (pc.x >= 0 && sub == 0) stg(A.unit_mask + pc.w, wg_mask[leader]);
+}
+
+// ---- window start, launch C, part 1: bit 15 of the tag of every slot trained in this window = the buffer the slot's
+// OTHER row is in at the slot's step (parity of that row's steps of the window before it)
+template <int LPR>
+__device__ __forceinline__ void touch_mark_tags(const ure_shard_t &S, const shard_aux &A, const TouchPos &P, int wg)
 {
     constexpr int CAP = kSegPerLane * LPR;
     int si;
     const int4 pc = touch_piece<LPR>(S, wg, &si);
     if (pc.x < 0) return;
     const int sub = threadIdx.x & (LPR - 1);
-    const unsigned long long *__restrict__ masks = A.mask[epoch & 1];
-    if (sub == 0) {
-        const unsigned long long mine = ldg(masks + pc.x);
-        if (pc.w >= 0) stg(A.unit_mask + pc.w, mine);            // work unit -> its row's mask
-        else stg(A.sched_mask + si, mine);                       // single-pass row, in schedule order
-    }
-    uint16_t *__restrict__ ent_tag = S.ent_tag + (size_t)(epoch & 1) * S.n_slots;
+    const unsigned long long *__restrict__ masks = A.mask[P.gwin & 1];
+    uint16_t *__restrict__ ent_tag = S.ent_tag + (size_t)(P.epoch & 1) * S.n_slots;
     const int other_base = pc.x < S.n_user ? S.n_user : 0;
     for (int p0 = pc.y + sub * kSegPerLane; p0 < pc.z; p0 += CAP) {
         const uint4 t4 = ldg_u4(ent_tag + p0);
@@ -137,32 +193,37 @@ __device__ __forceinline__ void touch_mark_tags(const ure_shard_t &S, const shar
         const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
         const int ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
         unsigned out[8];
+        bool any = false;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const unsigned tg = (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            const unsigned st = tg & kTagStep;
             out[k] = tg;
-            if (tg < (unsigned)kTouchMaxSteps) out[k] = tg | ((unsigned)mask_rank_parity(ldg(masks + other_base + ov[k]), (int)tg) << 15);
+            if ((int)(st >> kTouchWindowBits) == P.win) {
+                out[k] = st | ((unsigned)mask_rank_parity(ldg(masks + other_base + ov[k]), (int)(st & (kTouchWindow - 1))) << 15);
+                any = true;
+            }
         }
-        stg_u4(ent_tag + p0, make_uint4(out[0] | (out[1] << 16), out[2] | (out[3] << 16), out[4] | (out[5] << 16), out[6] | (out[7] << 16)));
+        if (any) stg_u4(ent_tag + p0, make_uint4(out[0] | (out[1] << 16), out[2] | (out[3] << 16), out[4] | (out[5] << 16), out[6] | (out[7] << 16)));
     }
 }
 
-// ---- epoch start, launch C, part 2: every active row from "valid at the epoch boundary" (buffer = parity of
-// its number of steps in the epoch that ended) to "valid at its first step of this epoch", in buffer 0.
+// ---- window start, launch C, part 2: every active row from "valid at the window boundary" (buffer = parity of
+// its number of steps in the window that ended) to "valid at its first step of this window", in buffer 0.
 // One lane per float4 of a row.
-__device__ __forceinline__ void touch_advance_rows(const ure_shard_t &S, const shard_aux &A, int epoch, int blk, int n_blk)
+__device__ __forceinline__ void touch_advance_rows(const ure_shard_t &S, const shard_aux &A, const TouchPos &P, int blk, int n_blk)
 {
     const int d4 = S.d / 4;
     const int64_t total = (int64_t)S.n_active * d4;
-    const unsigned long long *__restrict__ m_new = A.mask[epoch & 1];
-    const unsigned long long *__restrict__ m_old = A.mask[(epoch & 1) ^ 1];
-    const float4 *__restrict__ tab = A.ptab + (size_t)epoch * kTouchTab;
+    const unsigned long long *__restrict__ m_new = A.mask[P.gwin & 1];
+    const unsigned long long *__restrict__ m_old = A.mask[(P.gwin & 1) ^ 1];      // (all zero before the first window: buffer 0)
+    const float4 *__restrict__ tab = A.ptab + (size_t)P.epoch * kTouchTab;
     for (int64_t t = (int64_t)blk * kBlock + threadIdx.x; t < total; t += (int64_t)n_blk * kBlock) {
         const int idx = (int)(t / d4), c4 = (int)(t % d4);
         const int row_id = ldg(S.sched + 4 * (size_t)idx);
         const unsigned long long mo = ldg(m_old + row_id), mn = ldg(m_new + row_id);
         const int from = __popcll(mo) & 1;
-        const int j = mn ? __ffsll((long long)mn) - 1 : A.steps;          // steps that pass before the row's first own step
+        const int j = mn ? __ffsll((long long)mn) - 1 : P.wlen;           // steps that pass before the row's first own step (none: to the window's end)
         const bool is_user = row_id < S.n_user;
         const size_t o = (size_t)(is_user ? row_id : row_id - S.n_user) * S.d + (size_t)c4 * 4;
         float *wsrc = (is_user ? S.U[from] : S.V[from]) + o, *wdst = (is_user ? S.U[0] : S.V[0]) + o;
@@ -178,22 +239,15 @@ __device__ __forceinline__ void touch_advance_rows(const ure_shard_t &S, const s
     }
 }
 
-// epoch start, launch A: the mask buffer of this epoch's parity still holds the masks of two epochs ago
-__device__ __forceinline__ void touch_clear_masks(const ure_shard_t &S, const shard_aux &A, int epoch, int blk, int n_blk)
-{
-    unsigned long long *__restrict__ mk = A.mask[epoch & 1];
-    const int n_rows = S.n_user + S.n_item;
-    for (int r = blk * kBlock + threadIdx.x; r < n_rows; r += n_blk * kBlock) stg(mk + r, 0ull);
-}
-
 // ---- one row (or one work unit of a multi-pass row) of a step in touch mode: the scan, compaction and gather
 // loop of mf_step (mf_train.hip); what differs is marked [touch].  du = {row id, first slot, end slot, leader |
 // count << 16 | multi << 30}, mk = the row's step mask, hit = the row is trained in step s (lane-group uniform).
 template <int LPR, int V4>
 __device__ __forceinline__ void touch_process(const ure_shard_t &S, const shard_aux &A, const int4 du, const unsigned long long mk, const bool hit,
-                                              const int local, const int epoch, const int s, const int steps, const float lr, int *qo, float *qr,
+                                              const int local, const TouchPos &P, const float lr, int *qo, float *qr,
                                               float (*q_r)[kQueue], float4 (*part_acc)[V4][LPR])
 {
+    const int epoch = P.epoch, s = P.s;
     constexpr int D = LPR * V4 * 4;
     using Row = RowVec<V4>;
     constexpr int G = kWave / LPR;
@@ -211,8 +265,8 @@ __device__ __forceinline__ void touch_process(const ure_shard_t &S, const shard_
     const bool is_user = du.x < S.n_user;
     const int row = is_user ? du.x : du.x - S.n_user;
     const size_t row_off = (size_t)(hit ? row : 0) * D;
-    // [touch] the row's k-th step of the epoch reads buffer k & 1 (next-touch form: w is valid for THIS step)
-    const int buf = mask_rank_parity(mk, s);
+    // [touch] the row's k-th step of the window reads buffer k & 1 (next-touch form: w is valid for THIS step)
+    const int buf = mask_rank_parity(mk, P.sl);
     Row w = row_zero<V4>(), acc = w, m4 = w;
     float *mom = (is_user ? S.mU : S.mV) + row_off;
     if (hit) w = row_load<LPR, V4>((is_user ? S.U[buf] : S.V[buf]) + row_off, sub);
@@ -322,10 +376,10 @@ __device__ __forceinline__ void touch_process(const ure_shard_t &S, const shard_
             gr2.q[i] = g;
             nr.q[i] = wn;
         }
-        // [touch] bring the row to its next own step of the epoch (or to the epoch's end): the steps in between
+        // [touch] bring the row to its next own step of the window (or to the window's end): the steps in between
         // apply weight decay and momentum only, one 2x2 map for all of them
-        const unsigned long long rest = s + 1 < 64 ? mk >> (s + 1) : 0ull;
-        const int gap = rest ? __ffsll((long long)rest) - 1 : steps - 1 - s;
+        const unsigned long long rest = P.sl + 1 < 64 ? mk >> (P.sl + 1) : 0ull;
+        const int gap = rest ? __ffsll((long long)rest) - 1 : P.wlen - 1 - P.sl;
         if (gap > 0) row_advance<V4>(nr, gr2, A.ptab[(size_t)epoch * kTouchTab + gap]);
         row_store<LPR, V4>(mom, sub, gr2);
         row_store<LPR, V4>((is_user ? S.U[buf ^ 1] : S.V[buf ^ 1]) + row_off, sub, nr);
@@ -369,6 +423,7 @@ __device__ __forceinline__ void mf_touch_step(const ure_shard_t *__restrict__ sh
     if (tick >= (int64_t)steps * S.epochs) return;
     const int epoch = (int)epoch_of(A, tick);
     const int s = (int)(tick - (int64_t)epoch * steps);
+    const TouchPos P = touch_pos(A, epoch, s);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = lane / LPR;
     const float lr = ldg(S.lr + epoch);
@@ -384,10 +439,10 @@ __device__ __forceinline__ void mf_touch_step(const ure_shard_t *__restrict__ sh
         const size_t u = (size_t)wg * UPB + local;
         const int4 du = ldg_i4(S.units + 4 * u);
         const unsigned long long mk = ldg(A.unit_mask + u);
-        const bool hit = du.x >= 0 && ((mk >> s) & 1ull);
+        const bool hit = du.x >= 0 && ((mk >> P.sl) & 1ull);
         const bool multi = (du.w >> 30) & 1;
         if (!multi && !__any(hit)) return;
-        touch_process<LPR, V4>(S, A, du, mk, hit, local, epoch, s, steps, lr, qo, qr, q_r, part_acc);
+        touch_process<LPR, V4>(S, A, du, mk, hit, local, P, lr, qo, qr, q_r, part_acc);
         return;
     }
     if (wg < nbU + nbC) {
@@ -396,7 +451,7 @@ __device__ __forceinline__ void mf_touch_step(const ure_shard_t *__restrict__ sh
         // (the schedule entry is requested with the mask, not after it: one memory level, and both reads are coalesced)
         const unsigned long long mk = rel < n_single ? ldg(A.sched_mask + rel) : 0ull;
         const int4 sc = rel < n_single ? ldg_i4(S.sched + 4 * (size_t)(S.n_multi + rel)) : make_int4(-1, 0, 0, 0);
-        const bool hit = (mk >> s) & 1ull;
+        const bool hit = (mk >> P.sl) & 1ull;
         const unsigned long long vote = __ballot(hit);
         if (lane == 0) cand_count[wave] = __popcll(vote);
         __syncthreads();
@@ -421,7 +476,7 @@ __device__ __forceinline__ void mf_touch_step(const ure_shard_t *__restrict__ sh
             unsigned long long rm = 0ull;
             if (have) { du = cand_row[e]; rm = cand_mask[e]; }
             du.w = local | (1 << 16);                          // its own leader, one unit, no partial sums to combine
-            touch_process<LPR, V4>(S, A, du, rm, have, local, epoch, s, steps, lr, qo, qr, q_r, part_acc);
+            touch_process<LPR, V4>(S, A, du, rm, have, local, P, lr, qo, qr, q_r, part_acc);
         }
         return;
     }
@@ -440,7 +495,7 @@ __device__ __forceinline__ void touch_collect_rows(const ure_shard_t &S, const s
 {
     const int d4 = S.d / 4;
     const int64_t total = (int64_t)S.n_active * d4;
-    const unsigned long long *__restrict__ mk = A.mask[last_epoch & 1];
+    const unsigned long long *__restrict__ mk = A.mask[touch_last_window(A, last_epoch < 0 ? 0 : last_epoch) & 1];
     for (int64_t t = (int64_t)blk * kBlock + threadIdx.x; t < total; t += (int64_t)n_blk * kBlock) {
         const int idx = (int)(t / d4), c4 = (int)(t % d4);
         const int row_id = ldg(S.sched + 4 * (size_t)idx);

@@ -43,7 +43,23 @@
 
 // Tuning knobs (defaults = the swept optimum; -D overrides are for sweeps only)
 #ifndef URE_KGB_NARROW
-#define URE_KGB_NARROW 5      // rows a lane group gathers together, d <= 32
+#define URE_KGB_NARROW 5      // rows a lane group gathers together, d = 32
+#endif
+// d <= 16 (LPR <= 4): more lane groups per wavefront, each with its own queue positions and gather addresses live at once --
+// the d = 32 optimum (5 rows in flight under a 7-wave register budget) leaves the allocator 72 VGPRs where these need ~88,
+// and it spilled 15-16 of them (13 scratch loads + 13 stores per launch path, 16.5 us per launch at d = 16, round 2).
+// Per-width knobs: URE_KGB_D16 / URE_WAVES_D16 for d = 16, URE_KGB_D8 / URE_WAVES_D8 for d <= 8.
+#ifndef URE_KGB_D16
+#define URE_KGB_D16 5
+#endif
+#ifndef URE_WAVES_D16
+#define URE_WAVES_D16 5
+#endif
+#ifndef URE_KGB_D8
+#define URE_KGB_D8 5
+#endif
+#ifndef URE_WAVES_D8
+#define URE_WAVES_D8 5
 #endif
 #ifndef URE_KGB_WIDE
 #define URE_KGB_WIDE 4        // the same for d >= 64 (two float4 per lane)
@@ -70,6 +86,11 @@ constexpr int kSegPerLane = 8;  // slots one lane scans per pass over its unit
 // per wavefront.  Measured (us per launch): d = 64, 8 shards: 29.3 -> 26.2; d = 128, 25 M workload:
 // 1327 -> 1206; four pieces per lane at d = 128: 1530; two pieces at d = 32: 24.9 vs 18.6.
 __host__ __device__ constexpr int lanes_per_row(int d) { return d <= URE_NARROW_MAX ? d / 4 : d / 8; }
+
+// per-instantiation tuning of the step kernel: rows gathered together, and the occupancy the register allocator must
+// leave room for (tools/isa_report.py + tests/test_cpu_host.py: no instantiation may spill)
+__host__ __device__ constexpr int step_kgb(int lpr, int v4) { return v4 > 1 ? URE_KGB_WIDE : lpr >= 8 ? URE_KGB_NARROW : lpr == 4 ? URE_KGB_D16 : URE_KGB_D8; }
+__host__ __device__ constexpr int step_waves(int lpr, int v4) { return v4 > 1 ? URE_WAVES_WIDE : lpr >= 8 ? URE_WAVES_NARROW : lpr == 4 ? URE_WAVES_D16 : URE_WAVES_D8; }
 
 __device__ __forceinline__ int shard_steps(const ure_shard_t &S) { return (S.N + S.batch - 1) / S.batch; }
 
@@ -99,7 +120,7 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
     // table rows a lane group gathers together on the group path: six while rows are narrow (swept on
     // hardware: 18.5 us vs 18.9 at four, 19.7 at eight for d = 32); four for wide rows, where the
     // extra registers cost occupancy (d = 128: 1.55 ms vs 1.34 ms per launch of the 25 M workload)
-    constexpr int kGB = LPR <= 8 ? URE_KGB_NARROW : URE_KGB_WIDE;
+    constexpr int kGB = step_kgb(LPR, V4);
     // one raw LDS block: the row paths use it as match queues, the tag riders overlay their own
     // arrays on it (tag_prep.h)
     constexpr int kQueueBytes = kWavesPerBlock * kQueue * 8;
@@ -349,7 +370,7 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
 }
 
 template <int LPR, int V4>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(V4 == 1 ? URE_WAVES_NARROW : URE_WAVES_WIDE))) void mf_step_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, int shard_fast)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(step_waves(LPR, V4)))) void mf_step_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, int shard_fast)
 {
 #ifdef URE_TIMELINE
     const long long t0 = wall_clock64();
@@ -375,17 +396,19 @@ __global__ __launch_bounds__(kBlock) void snapshot_kernel(const ure_shard_t *__r
 {
     const ure_shard_t &S = shards[blockIdx.y];
     const unsigned long long *__restrict__ row_mask = nullptr;
-    if (!S.snapU || !S.snapV) return;
+    const bool compact = S.snap != nullptr;
+    if (!compact && (!S.snapU || !S.snapV)) return;
     const int steps = shard_steps(S);
     if (ticks_done > (int64_t)steps * S.epochs || ticks_done % steps != 0) return;   // only at an epoch end of this shard
     const int epoch = (int)(ticks_done / steps) - 1;
     const int cur = (int)(ticks_done & 1);
-    if (S.touch_mode) row_mask = aux[blockIdx.y].mask[epoch & 1];      // touch mode: a row's w sits in the buffer of its step-count parity
+    if (S.touch_mode) row_mask = aux[blockIdx.y].mask[touch_last_window(aux[blockIdx.y], epoch) & 1];      // touch mode: a row's w sits in the buffer of its step-count parity
     const float a = S.lazy_rows ? ldg(S.snap_a + epoch) : 0.f;
     const int d4 = S.d / 4;
-    const int n_rows = S.n_user + S.n_item;
-    float *__restrict__ su = S.snapU + (size_t)epoch * S.n_user * S.d;
-    float *__restrict__ sv = S.snapV + (size_t)epoch * S.n_item * S.d;
+    const int n_rows = compact ? S.n_active : S.n_user + S.n_item;
+    float *__restrict__ su = compact ? nullptr : S.snapU + (size_t)epoch * S.n_user * S.d;
+    float *__restrict__ sv = compact ? nullptr : S.snapV + (size_t)epoch * S.n_item * S.d;
+    float *__restrict__ sc = compact ? S.snap + (size_t)epoch * S.n_active * S.d : nullptr;      // compact: the active rows only, in schedule order
     const int64_t total = (int64_t)n_rows * d4;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
         const int idx = (int)(t / d4);
@@ -400,7 +423,8 @@ __global__ __launch_bounds__(kBlock) void snapshot_kernel(const ure_shard_t *__r
             const int from = row_mask ? (__popcll(ldg(row_mask + row_id)) & 1) : cur;
             v = ldg_f4((is_user ? S.U[from] : S.V[from]) + o);
         }
-        stg_f4((is_user ? su : sv) + o, v);
+        if (compact) stg_f4(sc + t * 4, v);
+        else stg_f4((is_user ? su : sv) + o, v);
     }
 }
 
@@ -441,26 +465,31 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(URE_TOUC
     mf_touch_step<LPR, V4>(shards, aux, tick, shard_fast);
 }
 
-// Epoch start of a shard in touch mode: phase 0 clears the epoch's mask buffer, 1 builds the row masks from
-// the batch tags, 2 advances every active row to its first step (mf_touch.h).  One launch per phase.
-__device__ __forceinline__ int touch_epoch_start(const ure_shard_t &S, const shard_aux &A, int64_t tick)
+// Window start of a shard in touch mode (mf_touch.h): phase 1 builds the row masks of the window from the batch tags,
+// phase 2 puts the buffer bits into the window's tags and advances every active row to its first step.  One launch per phase.
+__device__ __forceinline__ bool touch_window_start(const ure_shard_t &S, const shard_aux &A, int64_t tick, TouchPos *P)
 {
-    if (tick >= (int64_t)A.steps * S.epochs || tick % A.steps != 0) return -1;
-    return (int)(tick / A.steps);
+    if (tick >= (int64_t)A.steps * S.epochs) return false;
+    const int epoch = (int)epoch_of(A, tick);
+    const int s = (int)(tick - (int64_t)epoch * A.steps);
+    if (s & (kTouchWindow - 1)) return false;
+    *P = touch_pos(A, epoch, s);
+    return true;
 }
 
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void touch_prep_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, int phase,
                                                             int piece_blocks)
 {
+    __shared__ unsigned long long wg_mask[kBlock];
     const ure_shard_t &S = shards[blockIdx.y];
     const shard_aux &A = aux[blockIdx.y];
-    const int epoch = touch_epoch_start(S, A, tick);
-    if (epoch < 0) return;
-    if (phase == 0) touch_clear_masks(S, A, epoch, (int)blockIdx.x, (int)gridDim.x);
-    else if (phase == 1) touch_build_masks<LPR>(S, A, epoch, (int)blockIdx.x);
-    else if ((int)blockIdx.x < piece_blocks) touch_mark_tags<LPR>(S, A, epoch, (int)blockIdx.x);
-    else touch_advance_rows(S, A, epoch, (int)blockIdx.x - piece_blocks, (int)gridDim.x - piece_blocks);
+    TouchPos P;
+    if (!touch_window_start(S, A, tick, &P)) return;
+    if (phase == 1) {
+        if ((int)blockIdx.x < touch_piece_blocks<LPR>(S.n_units, S.n_active, S.n_multi)) touch_build_masks<LPR>(S, A, P, (int)blockIdx.x, wg_mask);
+    } else if ((int)blockIdx.x < piece_blocks) touch_mark_tags<LPR>(S, A, P, (int)blockIdx.x);
+    else touch_advance_rows(S, A, P, (int)blockIdx.x - piece_blocks, (int)gridDim.x - piece_blocks);
 }
 
 // Tables read at `ticks_done`: a shard must stand at one of its epoch boundaries (or have finished).
@@ -478,21 +507,19 @@ static bool touch_prep_needed(const ure_job *job, int64_t tick)
     if (!job->touch) return false;
     for (size_t k = 0; k < job->host.size(); ++k) {
         const int64_t steps = job->aux_host[k].steps;
-        if (tick < steps * job->host[k].epochs && tick % steps == 0) return true;
+        if (tick < steps * job->host[k].epochs && (tick % steps) % kTouchWindow == 0) return true;
     }
     return false;
 }
 
-// the three launches of an epoch start in touch mode (after the epoch's batch tags are complete)
+// the two launches of a window start in touch mode (an epoch start: after the epoch's batch tags are complete)
 template <int LPR>
 static void launch_touch_prep(const ure_job *job, int64_t tick, hipStream_t st)
 {
     const unsigned n_sh = (unsigned)job->host.size();
-    const unsigned rows_b = (unsigned)std::max<int64_t>(1, std::min<int64_t>((job->max_rows + kBlock - 1) / kBlock, 1024));
     int pieces = 1;
     for (const ure_shard_t &S : job->host) pieces = std::max(pieces, touch_piece_blocks<LPR>(S.n_units, S.n_active, S.n_multi));
     const unsigned adv_b = (unsigned)std::max<int64_t>(1, std::min<int64_t>((job->max_active4 + kBlock - 1) / kBlock, 8192));
-    hipLaunchKernelGGL((touch_prep_kernel<LPR>), dim3(rows_b, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, 0, pieces);
     hipLaunchKernelGGL((touch_prep_kernel<LPR>), dim3((unsigned)pieces, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, 1, pieces);
     hipLaunchKernelGGL((touch_prep_kernel<LPR>), dim3((unsigned)pieces + adv_b, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, 2, pieces);
 }
@@ -571,10 +598,12 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         job->lr_host.emplace_back(S.lr_host ? std::vector<float>(S.lr_host, S.lr_host + S.epochs) : std::vector<float>());
         job->host[k].lr_host = nullptr;                       // the caller's array need not outlive this call
         job->max_lazy = std::max<int64_t>(job->max_lazy, S.lazy_rows ? (int64_t)(S.n_user + S.n_item - S.n_active) * (S.d / 4) : 0);
-        if (S.snapU || S.snapV) {
-            if (!(S.snapU && S.snapV) || (S.lazy_rows && !S.snap_a)) { delete job; return fail(-1, "ure_job_create: shard %d has an incomplete snapshot set", k); }
+        if (S.snapU || S.snapV || S.snap) {
+            const bool full = S.snapU && S.snapV && !S.snap, compact = S.snap && !S.snapU && !S.snapV && S.lazy_rows;
+            if (!(full || compact) || (S.lazy_rows && !S.snap_a)) { delete job; return fail(-1, "ure_job_create: shard %d has an incomplete snapshot set (full: snapU + snapV; compact: snap with lazy_rows; snap_a with lazy_rows)", k); }
             job->snapshots = true;
-            job->snap_blocks = std::max<unsigned>(job->snap_blocks, (unsigned)std::min<int64_t>(((int64_t)(S.n_user + S.n_item) * (S.d / 4) + kBlock - 1) / kBlock, 2048));
+            const int64_t rows = compact ? S.n_active : S.n_user + S.n_item;
+            job->snap_blocks = std::max<unsigned>(job->snap_blocks, (unsigned)std::max<int64_t>(1, std::min<int64_t>((rows * (S.d / 4) + kBlock - 1) / kBlock, 2048)));
         }
     }
     for (int k = 0; k < n_shards; ++k) job->aux_host.push_back(make_shard_aux(shards[k]));
@@ -585,7 +614,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             const ure_shard_t &S = shards[k];
             const char *why = !S.touch_mode ? "every shard of a job must ask for it" :
                               !S.lazy_rows ? "it needs lazy_rows" :
-                              job->aux_host[k].steps > kTouchMaxSteps ? "more than 64 steps per epoch" :
+                              job->aux_host[k].steps > kTouchMaxSteps ? "more than 32000 steps per epoch (the step number shares the 16-bit batch tag with the buffer bit)" :
                               (S.epochs != shards[0].epochs || S.lam != shards[0].lam || S.mu != shards[0].mu ||
                                job->lr_host[k] != job->lr_host[0]) ? "the shards' optimizer schedules differ" : nullptr;
             if (why) { delete job; return fail(-1, "ure_job_create: touch mode refused for shard %d: %s", k, why); }
@@ -598,7 +627,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
     if (e == hipSuccess) e = hipMemcpy(job->dev, job->host.data(), sizeof(ure_shard_t) * n_shards, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&job->dev_ab, sizeof(double) * 2 * n_shards);
     if (job->touch && e == hipSuccess) {
-        // A_e^j for j = 0..64 at every epoch's learning rate, in double: (w, m)' = A (w, m),
+        // A_e^j for j = 0..64 (the length of a window) at every epoch's learning rate, in double: (w, m)' = A (w, m),
         // m' = mu m + lam w, w' = w - lr m'
         const int E = shards[0].epochs;
         std::vector<float> tab((size_t)E * kTouchTab * 4);
@@ -719,7 +748,7 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
             bool epoch_end = false;
             for (const ure_shard_t &S : job->host) {
                 const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
-                if (S.snapU && t + 1 <= steps * S.epochs && (t + 1) % steps == 0) { epoch_end = true; break; }
+                if ((S.snapU || S.snap) && t + 1 <= steps * S.epochs && (t + 1) % steps == 0) { epoch_end = true; break; }
             }
             if (epoch_end)
                 hipLaunchKernelGGL(snapshot_kernel, dim3(job->snap_blocks, (unsigned)job->host.size()), dim3(kBlock), 0, st, job->dev, job->dev_aux, t + 1);
@@ -770,23 +799,26 @@ int ure_job_materialize(ure_job_t *j, int64_t ticks_done, void *stream)
     return 0;
 }
 
-int ure_job_touch_rows(ure_job_t *j, int64_t *rows_per_epoch)
+int ure_job_touch_rows(ure_job_t *j, int64_t *pairs, int64_t *window_steps)
 {
     auto *job = reinterpret_cast<ure::ure_job *>(j);
-    URE_ARG(job && rows_per_epoch);
-    for (size_t k = 0; k < job->host.size(); ++k) rows_per_epoch[k] = -1;
+    URE_ARG(job && pairs && window_steps);
+    for (size_t k = 0; k < job->host.size(); ++k) { pairs[k] = -1; window_steps[k] = 0; }
     if (!job->touch || job->next_tick == 0) return 0;
     URE_HIP(hipDeviceSynchronize());
     std::vector<unsigned long long> host;
     for (size_t k = 0; k < job->host.size(); ++k) {
         const ure_shard_t &S = job->host[k];
-        const int64_t steps = job->aux_host[k].steps;
-        const int64_t epoch = std::min<int64_t>((job->next_tick - 1) / steps, S.epochs - 1);      // the epoch the last launch belonged to
+        const shard_aux &A = job->aux_host[k];
+        const int64_t steps = A.steps;
+        const int64_t last = std::min<int64_t>(job->next_tick, steps * S.epochs) - 1;      // the last step of the shard that was launched
+        const int64_t epoch = last / steps, win = (last % steps) / kTouchWindow;
         host.resize((size_t)S.n_user + S.n_item);
-        URE_HIP(hipMemcpy(host.data(), job->aux_host[k].mask[epoch & 1], host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        URE_HIP(hipMemcpy(host.data(), A.mask[(epoch * A.windows + win) & 1], host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         int64_t n = 0;
         for (unsigned long long m : host) n += __builtin_popcountll(m);
-        rows_per_epoch[k] = n;
+        pairs[k] = n;
+        window_steps[k] = std::min<int64_t>(kTouchWindow, steps - win * kTouchWindow);
     }
     return 0;
 }

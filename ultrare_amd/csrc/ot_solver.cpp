@@ -61,10 +61,11 @@ constexpr int64_t kInf = std::numeric_limits<int64_t>::max() / 4;
 
 // [0, n) cut into contiguous pieces, one per host thread (the large instances -- n = 162,000, k = 32 -- spend their
 // time in O(n k) passes over the cost matrix; small ones run on the calling thread)
+constexpr int kMaxHostThreads = 64;      // (round 2 stopped at 16: on a 256-CPU host the O(n k) passes then ran on 6 % of it)
 template <typename F>
 static void parallel_ranges(int64_t n, int64_t grain, F &&body)
 {
-    int nt = (int)std::min<int64_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), (n + grain - 1) / grain);
+    int nt = (int)std::min<int64_t>(std::max(1u, std::min((unsigned)kMaxHostThreads, std::thread::hardware_concurrency())), (n + grain - 1) / grain);
     if (nt <= 1) { body(0, n, 0); return; }
     std::vector<std::thread> pool;
     for (int t = 0; t < nt; ++t) pool.emplace_back([&, t]() { body(n * t / nt, n * (t + 1) / nt, t); });
@@ -76,8 +77,8 @@ static int to_fixed_point(const float *dist, int64_t n, int k, std::vector<int64
 {
     int e_min = std::numeric_limits<int>::max(), e_max = std::numeric_limits<int>::min();
     std::atomic<int64_t> bad{-1};
-    int lo[16], hi[16];
-    for (int t = 0; t < 16; ++t) { lo[t] = e_min; hi[t] = e_max; }
+    int lo[kMaxHostThreads], hi[kMaxHostThreads];
+    for (int t = 0; t < kMaxHostThreads; ++t) { lo[t] = e_min; hi[t] = e_max; }
     parallel_ranges(n * k, 1 << 18, [&](int64_t b, int64_t e_, int th) {
         int mn = std::numeric_limits<int>::max(), mx = std::numeric_limits<int>::min();
         for (int64_t t = b; t < e_; ++t) {
@@ -95,7 +96,7 @@ static int to_fixed_point(const float *dist, int64_t n, int k, std::vector<int64
         hi[th] = mx;
     });
     if (bad.load() >= 0) return ure::fail(-1, "ure_ot_assign: cost %lld is negative, NaN or inf", (long long)bad.load());
-    for (int t = 0; t < 16; ++t) { e_min = std::min(e_min, lo[t]); e_max = std::max(e_max, hi[t]); }
+    for (int t = 0; t < kMaxHostThreads; ++t) { e_min = std::min(e_min, lo[t]); e_max = std::max(e_max, hi[t]); }
     int shift = 0;                               // cost_int = v * 2^shift
     if (e_max != std::numeric_limits<int>::min()) {
         int guard = 3;
@@ -319,7 +320,7 @@ extern "C" int ure_ot_assign_warm(const float *dist, int64_t n, int k, const dou
     };
     {   // all rows once, in parallel (each touches its own row of w / arg and its own member list)
         std::atomic<int> next{0};
-        parallel_ranges(std::min<int64_t>(k, 16), 1, [&](int64_t, int64_t, int) {
+        parallel_ranges(std::min<int64_t>(k, kMaxHostThreads), 1, [&](int64_t, int64_t, int) {
             for (int a = next.fetch_add(1); a < k; a = next.fetch_add(1)) rescan_row(a);
         });
     }

@@ -182,12 +182,19 @@ struct shard_aux {
     int32_t ride_c;         // the same for phase C
     int32_t ranges;         // tag_ranges(N)
     int32_t derive_blocks;  // tag_derive_blocks(n_slots)
-    // touch mode (mf_touch.h); library-owned device memory, NULL otherwise
-    unsigned long long *mask[2];   // [n_user + n_item] steps of the epoch in which the row is trained, by epoch parity
+    // touch mode (mf_touch.h); library-owned device memory, NULL otherwise.  An epoch is cut into WINDOWS of 64 steps
+    // (the last one shorter); window w of epoch e has the global index e * windows + w.
+    int32_t windows;               // windows per epoch = ceil(steps / 64)
+    unsigned long long *mask[2];   // [n_user + n_item] steps of the window in which the row is trained (bit = step - 64 w), by global window parity
     const float4 *ptab;            // [epochs][65] A_e^j = {p11, p12, p21, p22}: j optimizer steps without a gradient at epoch e's lr
-    unsigned long long *unit_mask; // [n_units] the current epoch's mask of each work unit's row
+    unsigned long long *unit_mask; // [n_units] the current window's mask of each work unit's row
     unsigned long long *sched_mask;// [n_active - n_multi] the same for the single-pass rows, in schedule order
 };
+
+constexpr int kTouchWindow = 64;            // steps a 64-bit row mask describes
+constexpr int kTouchWindowBits = 6;
+// global index of the last window of `epoch` (the window whose masks say in which buffer a row's weights are at the epoch's end)
+__host__ __device__ inline int64_t touch_last_window(const shard_aux &a, int64_t epoch) { return (epoch + 1) * a.windows - 1; }
 
 inline shard_aux make_shard_aux(const ure_shard_t &S)
 {
@@ -196,6 +203,7 @@ inline shard_aux make_shard_aux(const ure_shard_t &S)
     a.inv_steps = a.steps == 1 ? 0 : ~0ull / (uint64_t)a.steps + 1;
     a.ranges = tag_ranges(S.N);
     a.derive_blocks = tag_derive_blocks(S.n_slots);
+    a.windows = (a.steps + kTouchWindow - 1) / kTouchWindow;
     a.ride_m = a.steps >= 3 && tag_partitioned(S.N) ? a.steps / 3 : 0;
     if (a.ride_m) {
         a.ride_ab = (a.ranges + a.ride_m - 1) / a.ride_m;

@@ -25,7 +25,7 @@ from . import _native as nv
 SCORE_PARTIALS = 2048     # URE_SCORE_PARTIALS of the C ABI
 SERIES_SCRATCH_BYTES = 256 << 20     # prediction scratch of one ure_eval_series call
 LAZY_ROWS = os.environ.get('URE_LAZY_ROWS', '1') != '0'
-TOUCH_MAX_STEPS = 64                 # kTouchMaxSteps of csrc/mf_touch.h
+TOUCH_MAX_STEPS = 32000              # kTouchMaxSteps of csrc/mf_touch.h (epochs longer than 64 steps run in windows of 64)
 TOUCH_MIN_TABLE_BYTES = 256 << 20    # auto rule: the job's live rows (w, m, second buffer) exceed the Infinity Cache
 
 
@@ -82,6 +82,19 @@ class ShardData:
         self.sched = to(sched)
         self._sched_host = sched
         self._units = {}
+        self._row_slot = None
+        ShardData.built += 1
+
+    built = 0            # layouts built (and uploaded) by this process: lets a measurement show that its timed call paid for them
+
+    def row_slot(self):
+        """Device int32 [n_user + n_item]: a row's index in the schedule when it is one of the n_active rows with
+        interactions in this shard (the rows a compact snapshot stores), -1 otherwise."""
+        if self._row_slot is None:
+            slot = np.full(self.n_user + self.n_item, -1, dtype=np.int32)
+            slot[self._sched_host[:self.n_active, 0]] = np.arange(self.n_active, dtype=np.int32)
+            self._row_slot = torch.from_numpy(slot).to(self.device)
+        return self._row_slot
 
     def units(self, d, touch=False):
         """The work units of the step kernel for table width d (device int32 [n_units, 4]).  touch: only the rows
@@ -152,7 +165,9 @@ class TrainJob:
             live = sum(sh.n_active for sh in shards) * self.d * 12
             touch = (env == '1') or (env == 'auto' and live > TOUCH_MIN_TABLE_BYTES)
         self.touch = bool(touch) and self.lazy_rows and max(steps_all) <= TOUCH_MAX_STEPS
-        self.snapshots = bool(snapshots)
+        # end-of-epoch snapshots: 'compact' keeps the n_active rows with interactions only (every other row is a_e * w0 and is
+        # rebuilt where it is read: ure_eval_series_compact; needs lazy_rows), True / 'full' keeps complete tables
+        self.snapshots = ('compact' if self.lazy_rows else 'full') if snapshots == 'compact' else ('full' if snapshots else False)
         self.lr = torch.from_numpy(lr_host).to(dev)
         self.state = []
         self._chunks = []        # per shard whose permutations are uploaded in chunks: [(first epoch after the chunk, event), ...]
@@ -200,12 +215,19 @@ class TrainJob:
             D.lam, D.mu = float(lam), float(momentum)
             D.touch_mode = int(self.touch)
             if self.snapshots:
-                snapU = torch.empty(self.epochs, sh.n_user, self.d, dtype=torch.float32, device=dev)
-                snapV = torch.empty(self.epochs, sh.n_item, self.d, dtype=torch.float32, device=dev)
                 steps = (sh.N + self.batch - 1) // self.batch
                 snap_a = torch.from_numpy(closed_form_scalars(lr_host, steps, float(np.float32(lam)), float(np.float32(momentum)))).to(dev)
-                self.state[-1].update(snapU=snapU, snapV=snapV, snap_a=snap_a)
-                D.snapU, D.snapV, D.snap_a = nv.ptr(snapU), nv.ptr(snapV), nv.ptr(snap_a)
+                self.state[-1].update(snap_a=snap_a)
+                D.snap_a = nv.ptr(snap_a)
+                if self.snapshots == 'compact':
+                    snap = torch.empty(self.epochs, sh.n_active, self.d, dtype=torch.float32, device=dev)
+                    self.state[-1].update(snap=snap)
+                    D.snap = nv.ptr(snap)
+                else:
+                    snapU = torch.empty(self.epochs, sh.n_user, self.d, dtype=torch.float32, device=dev)
+                    snapV = torch.empty(self.epochs, sh.n_item, self.d, dtype=torch.float32, device=dev)
+                    self.state[-1].update(snapU=snapU, snapV=snapV)
+                    D.snapU, D.snapV = nv.ptr(snapU), nv.ptr(snapV)
             if self.lazy_rows:
                 U0d, V0d = U[0].clone(), V[0].clone()
                 self.state[-1].update(U0=U0d, V0=V0d)
@@ -269,15 +291,30 @@ class TrainJob:
         assert len(self.shards) == 1
         return self.run(n_epochs * self.steps_per_epoch(0), stream)
 
+    @staticmethod
+    def snapshot_bytes(shards, epochs, d, mode):
+        """Device bytes the end-of-epoch snapshots of `shards` need ('compact': active rows only)."""
+        rows = sum((sh.n_active if mode == 'compact' else sh.n_user + sh.n_item) for sh in shards)
+        return int(epochs) * rows * pad_dim(d) * 4
+
     def snapshot(self, s, epoch):
-        """(U, V) of shard s as they were at the end of `epoch` (padded width; needs snapshots=True)."""
+        """(U, V) of shard s as they were at the end of `epoch` (padded width; needs full snapshots)."""
         st = self.state[s]
         return st['snapU'][epoch], st['snapV'][epoch]
 
     def snapshots_of(self, s):
-        """All end-of-epoch tables of shard s: (U [epochs, n_user, d], V [epochs, n_item, d])."""
+        """All end-of-epoch tables of shard s: (U [epochs, n_user, d], V [epochs, n_item, d]) (full snapshots)."""
         st = self.state[s]
         return st['snapU'], st['snapV']
+
+    def evaluate_series(self, s, eval_set, fixed, out, stream=None):
+        """scratch.py:83-97 for every epoch of shard s on `eval_set`: member e = the ensemble `fixed` + the shard's model
+        after epoch e, from whichever kind of snapshots the job keeps.  out: device float64 [epochs, 3]."""
+        st = self.state[s]
+        if self.snapshots == 'compact':
+            sh = self.shards[s]
+            return eval_set.evaluate_series_compact(fixed, st['snap'], sh.row_slot(), st['U0'], st['V0'], st['snap_a'], sh.n_user, self.d, out, stream)
+        return eval_set.evaluate_series(fixed, st['snapU'], st['snapV'], self.d, out, stream)
 
     def materialize(self, stream=None):
         """Bring the lazily advanced rows (lazy_rows) up to date in the current tables."""
@@ -300,12 +337,12 @@ class TrainJob:
 
     def touch_rows_per_step(self):
         """Touch mode: rows the step kernel reads and rewrites per optimizer step, per shard (average over the shard's
-        current epoch, from the epoch's row masks; synchronises).  None otherwise."""
+        current window of up to 64 steps, from the window's row masks; synchronises).  None otherwise."""
         if not self.touch:
             return None
-        out = np.zeros(len(self.shards), dtype=np.int64)
-        nv.check(nv.lib().ure_job_touch_rows(self._job, out.ctypes.data), 'ure_job_touch_rows')
-        return [float(n) / self.steps_per_epoch(s) for s, n in enumerate(out)]
+        out, win = np.zeros(len(self.shards), dtype=np.int64), np.zeros(len(self.shards), dtype=np.int64)
+        nv.check(nv.lib().ure_job_touch_rows(self._job, out.ctypes.data, win.ctypes.data), 'ure_job_touch_rows')
+        return [float(n) / max(int(w), 1) for n, w in zip(out, win)]
 
     def epoch_sse(self, s):
         """Per-epoch sum of squared training errors (host float64 array; synchronises)."""
@@ -406,6 +443,19 @@ class EvalSet:
         rmse = float(np.sqrt(sse / self.n))
         return rmse, float(np.mean(ndcg)), float(np.mean(hits / top_k))
 
+    def _series_buffers(self, E):
+        """Scratch of one series call (kept on the set): -> (buffers, members per call)."""
+        per_call = max(1, min(E, SERIES_SCRATCH_BYTES // (4 * self.n)))
+        if getattr(self, '_series_cap', 0) < per_call:
+            dev = self.device
+            self._series = {'base': torch.empty(self.n, dtype=torch.float32, device=dev),
+                            'pred': torch.empty(per_call, self.n, dtype=torch.float32, device=dev),
+                            'sse': torch.empty(per_call, SCORE_PARTIALS, dtype=torch.float64, device=dev),
+                            'hits': torch.empty(per_call, max(self.n_users, 1), dtype=torch.int32, device=dev),
+                            'ndcg': torch.empty(per_call, max(self.n_users, 1), dtype=torch.float64, device=dev)}
+            self._series_cap = per_call
+        return self._series, per_call
+
     def evaluate_series(self, fixed, U_series, V_series, d, out, stream=None):
         """scratch.py:83-97 for every epoch of a shard in four launches (ure_eval_series): member e of
         the series is the ensemble `fixed` + [(U_series[e], V_series[e])]; out[e] (device float64
@@ -416,16 +466,7 @@ class EvalSet:
         if self.n == 0:
             return out.fill_(float('nan'))
         L, st = nv.lib(), nv.stream_handle(stream)
-        per_call = max(1, min(E, SERIES_SCRATCH_BYTES // (4 * self.n)))
-        if getattr(self, '_series_cap', 0) < per_call:
-            dev = self.device
-            self._series = {'base': torch.empty(self.n, dtype=torch.float32, device=dev),
-                            'pred': torch.empty(per_call, self.n, dtype=torch.float32, device=dev),
-                            'sse': torch.empty(per_call, SCORE_PARTIALS, dtype=torch.float64, device=dev),
-                            'hits': torch.empty(per_call, max(self.n_users, 1), dtype=torch.int32, device=dev),
-                            'ndcg': torch.empty(per_call, max(self.n_users, 1), dtype=torch.float64, device=dev)}
-            self._series_cap = per_call
-        b = self._series
+        b, per_call = self._series_buffers(E)
         for U, V in fixed:
             assert U.is_contiguous() and V.is_contiguous() and U.shape[1] == d and V.shape[1] == d
         Up = (ctypes.c_void_p * max(len(fixed), 1))(*[U.data_ptr() for U, _ in fixed])
@@ -438,6 +479,30 @@ class EvalSet:
                                        nv.ptr(b['sse']), nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating),
                                        self.n_wide, st),
                      'ure_eval_series')
+        return out
+
+    def evaluate_series_compact(self, fixed, snap, row_slot, U0, V0, snap_a, n_user_rows, d, out, stream=None):
+        """evaluate_series on COMPACT snapshots (ure_eval_series_compact): snap [E, n_active, d] holds the rows with
+        interactions in the shard, row_slot maps a row id to its place in it (-1: the row is snap_a[e] * (U0 | V0)[row])."""
+        E = int(snap.shape[0])
+        assert out.shape == (E, 3) and out.dtype == torch.float64 and out.is_contiguous()
+        assert snap.is_contiguous() and snap.shape[2] == d and U0.is_contiguous() and V0.is_contiguous() and U0.shape[1] == d and V0.shape[1] == d
+        assert row_slot.dtype == torch.int32 and row_slot.numel() == U0.shape[0] + V0.shape[0] and snap_a.numel() == E
+        if self.n == 0:
+            return out.fill_(float('nan'))
+        L, st = nv.lib(), nv.stream_handle(stream)
+        b, per_call = self._series_buffers(E)
+        for U, V in fixed:
+            assert U.is_contiguous() and V.is_contiguous() and U.shape[1] == d and V.shape[1] == d
+        Up = (ctypes.c_void_p * max(len(fixed), 1))(*[U.data_ptr() for U, _ in fixed])
+        Vp = (ctypes.c_void_p * max(len(fixed), 1))(*[V.data_ptr() for _, V in fixed])
+        for e0 in range(0, E, per_call):
+            m = min(per_call, E - e0)
+            nv.check(L.ure_eval_series_compact(Up, Vp, len(fixed), nv.ptr(snap[e0]), snap.stride(0), nv.ptr(row_slot), nv.ptr(U0), nv.ptr(V0),
+                                               nv.ptr(snap_a[e0:]), int(n_user_rows), m, nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating),
+                                               self.n, d, nv.ptr(self.off), self.n_users, nv.ptr(self.log2), nv.ptr(b['base']), nv.ptr(b['pred']),
+                                               nv.ptr(b['sse']), nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating),
+                                               self.n_wide, st), 'ure_eval_series_compact')
         return out
 
     def predictions(self):

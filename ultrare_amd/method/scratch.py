@@ -18,10 +18,11 @@ from .. import engine, rng
 from ..read import as_loader
 from .utils import MF, padded_tables, seed_all
 
-PERM_THREADS = int(os.environ.get('URE_PERM_THREADS', str(min(16, os.cpu_count() or 1))))
-# end-of-epoch snapshots kept on the device for the per-epoch test series (per shard job)
+PERM_THREADS = rng.perm_threads()
+# end-of-epoch snapshots kept on the device for the per-epoch test series (per job).  They hold the rows with interactions in
+# the shard only (engine: 'compact'): 5 GiB for 5 epochs of BASELINE.json configs[3] (32 shards, d = 128) on a 288 GB card.
 def snapshot_limit():
-    return int(float(os.environ.get('URE_SNAPSHOT_LIMIT_GB', '8')) * 2 ** 30)
+    return int(float(os.environ.get('URE_SNAPSHOT_LIMIT_GB', '64')) * 2 ** 30)
 
 
 def _is_empty(x):
@@ -102,10 +103,10 @@ class Scratch(object):
         # on the device (snapshots) and the two test series of scratch.py:83-97 are computed afterwards
         # in four launches each (ure_eval_series); otherwise each epoch synchronises to print
         queued = verbose == 0
-        snap_bytes = self.epochs * (self.n_user + self.n_item) * engine.pad_dim(self.k) * 4
-        series = queued and snap_bytes <= snapshot_limit()
+        snap_mode = 'compact' if engine.LAZY_ROWS else 'full'
+        series = queued and engine.TrainJob.snapshot_bytes([shard], self.epochs, self.k, snap_mode) <= snapshot_limit()
         job = engine.TrainJob([shard], [init], [perms], self.k, batch, self.epochs, self.lr, self.lam, self.momentum,
-                              self.lr_decay, snapshots=series)
+                              self.lr_decay, snapshots=snap_mode if series else False)
         rng.release(perms)                                  # uploaded: the host buffer goes back to the pool
         test_ev = as_loader(test_data).eval_set()
         total_ev = as_loader(test_total).eval_set() if has_total else None
@@ -117,9 +118,8 @@ class Scratch(object):
         if series:
             job.run()
             res = torch.zeros(2, self.epochs, 3, dtype=torch.float64, device=shard.device)
-            snapU, snapV = job.snapshots_of(0)
-            test_ev.evaluate_series(before, snapU, snapV, job.d, res[0])
-            (total_ev if has_total else test_ev).evaluate_series(before, snapU, snapV, job.d, res[1])
+            job.evaluate_series(0, test_ev, before, res[0])
+            job.evaluate_series(0, total_ev if has_total else test_ev, before, res[1])
             res = res.transpose(0, 1).contiguous()
             times = ['00:00:00'] * self.epochs
         for t in range(0 if not series else self.epochs, self.epochs):

@@ -204,7 +204,8 @@ class Sisa(Scratch):
         prepared = prepare_owned(ids, owner, rank, train_dlist, self.n_user, self.n_item, self.k, self.epochs,
                                  foreign_u0=foreign_u0)
         mine = [i for pos, i in enumerate(ids) if owner[pos] == rank]
-        snap_bytes = len(mine) * self.epochs * (self.n_user + self.n_item) * engine.pad_dim(self.k) * 4
+        snap_mode = 'compact' if engine.LAZY_ROWS else 'full'
+        snap_bytes = engine.TrainJob.snapshot_bytes([prepared[i][0] for i in mine], self.epochs, self.k, snap_mode)
         keep_logs = self.epoch_logs and snap_bytes <= snapshot_limit()
         if self.epoch_logs and not keep_logs:
             import warnings
@@ -215,7 +216,7 @@ class Sisa(Scratch):
             batch = as_loader(train_dlist[mine[0]]).batch_size
             job = engine.TrainJob([prepared[i][0] for i in mine], [prepared[i][1] for i in mine],
                                   [prepared[i][2] for i in mine], self.k, batch, self.epochs, self.lr, self.lam,
-                                  self.momentum, self.lr_decay, snapshots=keep_logs)
+                                  self.momentum, self.lr_decay, snapshots=snap_mode if keep_logs else False)
             from .. import rng
             job.run()
             for i in mine:
@@ -261,9 +262,8 @@ class Sisa(Scratch):
                 pos = mine.index(i)
                 # all epochs of the shard at once: the ensembles differ in their last model only
                 res = torch.zeros(2, self.epochs, 3, dtype=torch.float64, device=engine._device())
-                snapU, snapV = job.snapshots_of(pos)
-                test_ev.evaluate_series(before, snapU, snapV, job.d, res[0])
-                total_ev.evaluate_series(before, snapU, snapV, job.d, res[1])
+                job.evaluate_series(pos, test_ev, before, res[0])
+                job.evaluate_series(pos, total_ev, before, res[1])
                 queued[i] = res
         for pos, i in enumerate(mine):
             entry = {'train_loss': [float(x) for x in np.sqrt(job.epoch_sse(pos) / prepared[i][0].N)]}

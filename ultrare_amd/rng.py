@@ -16,6 +16,25 @@ import numpy as np
 import torch
 
 
+def host_cpus():
+    """CPUs this rank may use: the process's affinity mask (not the machine's CPU count) shared among the ranks the
+    launcher started on this host (LOCAL_WORLD_SIZE)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, n // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1)))
+
+
+def perm_threads():
+    """Host threads of the permutation expander per SISA call: URE_PERM_THREADS, else every CPU of the rank up to 64
+    (250 Fisher-Yates permutations of 0.5 ms each are half of a 5-shard, 50-epoch call's wall time on 16 threads)."""
+    import os
+    env = os.environ.get('URE_PERM_THREADS')
+    return max(1, int(env)) if env else min(64, host_cpus())
+
+
 def fill_draws(n):
     """32-bit MT19937 outputs one `tensor.normal_()` of n >= 16 float32 elements consumes on the CPU: ATen fills
     the tensor with n uniforms and turns them into normals 16 at a time; when 16 does not divide n the last 16
@@ -277,8 +296,9 @@ def shard_draws_async(start_state, n_user, n_item, k, epochs, with_total_test, n
     global _SHARD_POOL
     if _SHARD_POOL is None:
         from concurrent.futures import ThreadPoolExecutor
-        import os
-        _SHARD_POOL = ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 2) // 2)), thread_name_prefix='ure-shard')
+        # one worker per shard of a call up to 64: a worker spends its time inside native calls that release the GIL
+        # (8 workers -- round 2 -- left half of a 16-shard call's draws waiting behind the other half)
+        _SHARD_POOL = ThreadPoolExecutor(max_workers=max(2, min(64, 2 * host_cpus())), thread_name_prefix='ure-shard')
     from . import _native as nv
     nv.lib()
     big = n_rows >= (2 ** 32 - 1) // 20
