@@ -197,6 +197,14 @@ int ure_host_partition(const int32_t *uid, const int32_t *iid, const double *rat
 int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *rating, int64_t n, int32_t n_user, int32_t n_item,
                           int32_t *ent_oid, float *ent_r, int32_t *ent_src, int32_t *sched,
                           int64_t *n_slots, int32_t *n_active, int32_t *u_pos, int32_t *i_pos);
+/* The same for all shards of a call at once, side by side on `n_threads` host threads (0 = all), from the triples as
+ * RatingData holds them (read.py:108-124: int64 ids, float64 ratings; a rating is cast to float32 once, read.py:124).
+ * Shard s is written PACKED into region[s] -- int32 words, at least 6 n[s] + 29 (n_user + n_item) + 24 of them:
+ *   ent_oid [k] | ent_r [k] | ent_src [k] | sched [n_user + n_item][4] | row_slot [n_user + n_item],   k = n_slots[s]
+ * row_slot[r] = the row's index in the schedule when it has interactions in the shard (one of the n_active rows a compact
+ * snapshot stores), -1 otherwise.  A region can be pinned host memory: it is what goes to the device, in one copy. */
+int ure_host_build_layouts(int n_shards, const int64_t *const *uid, const int64_t *const *iid, const double *const *rating, const int64_t *n,
+                           int32_t n_user, int32_t n_item, int32_t *const *region, int64_t *n_slots, int32_t *n_active, int n_threads);
 /* Cuts the active rows of a schedule into the work units of struct ure_shard for row width d and
  * packs them into workgroups.  units == NULL: only *n_units is written (size query); otherwise
  * `capacity` units may be written. */

@@ -582,3 +582,26 @@ def test_shard_streams_reproduce_the_sequential_draws():
     torch.manual_seed(7)
     torch.empty(1, 4).normal_(); torch.empty(3, 4).normal_()
     assert torch.equal(a[0], torch.empty(1, 4).normal_()) and torch.equal(a[1], torch.empty(3, 4).normal_())
+
+
+def test_batched_layout_builder_equals_the_single_one(lib):
+    """ure_host_build_layouts (all shards of a call in one native call, from int64 / float64 triples as RatingData holds
+    them, packed regions, row_slot) against ure_host_build_layout shard by shard."""
+    tr = O.load_csv(TRAIN)
+    parts = O.partition(*tr, O.uniform_groups(N_USER, 3))
+    raw = [(p[0].astype(np.int64), p[1].astype(np.int64), p[2].astype(np.float64)) for p in parts]
+    regs = [np.full(lib.layout_region_words(len(r[0]), N_USER, N_ITEM), 12345, dtype=np.int32) for r in raw]
+    n_slots, n_active = lib.build_layouts(raw, N_USER, N_ITEM, regs, threads=3)
+    rows = N_USER + N_ITEM
+    for p, reg, k, na in zip(parts, regs, n_slots, n_active):
+        one = lib.build_layout(p[0].astype(np.int32), p[1].astype(np.int32), p[2].astype(np.float32), N_USER, N_ITEM)
+        assert one['n_slots'] == k and one['n_active'] == na
+        assert np.array_equal(reg[:k], one['ent_oid']) and np.array_equal(reg[k:2 * k].view(np.float32), one['ent_r'])
+        assert np.array_equal(reg[2 * k:3 * k], one['ent_src']) and np.array_equal(reg[3 * k:3 * k + 4 * rows].reshape(rows, 4), one['sched'])
+        slot = reg[3 * k + 4 * rows:3 * k + 5 * rows]
+        want = np.full(rows, -1, dtype=np.int32)
+        want[one['sched'][:na, 0]] = np.arange(na)
+        assert np.array_equal(slot, want)
+    with pytest.raises(lib.NativeError, match='shard 1'):
+        bad = [raw[0], (raw[1][0], raw[1][1] + N_ITEM, raw[1][2]), raw[2]]
+        lib.build_layouts(bad, N_USER, N_ITEM, regs, threads=2)

@@ -193,7 +193,7 @@ def _truncate(part, n):
     return tuple(x[:n] for x in part)
 
 
-@pytest.mark.parametrize('n_rows,B,k,E', [(None, 437, 16, 3), (None, 219, 32, 2), (27714, 37, 16, 2), (None, 219, 128, 2)])
+@pytest.mark.parametrize('n_rows,B,k,E', [(None, 437, 16, 3), (None, 219, 32, 2), (27714, 37, 16, 2), (None, 219, 128, 2)])   # d = 128: two float4 per lane
 def test_touch_mode_windows_vs_oracle(n_rows, B, k, E):
     """65, 130 and 750 optimizer steps per epoch (full MF at 25 M rows has 750: config.py:182-188 with batch 30,000): an
     epoch is worked off in windows of 64 steps, each with its own row masks; a row that is not trained in a window is
@@ -207,6 +207,8 @@ def test_touch_mode_windows_vs_oracle(n_rows, B, k, E):
     assert steps in (65, 130, 750), steps
     torch.manual_seed(11)
     init = rng.mf_init(N_USER, N_ITEM, k)
+    if k > 64:      # N(0, 1) rows of width 128 start with predictions of +-11 and diverge in the reference's arithmetic (oracle: NaN)
+        init = tuple(t * 0.3 for t in init)
     perms = rng.epoch_perms(rng.epoch_seeds(E, True), len(part[0]))
     job = engine.TrainJob([engine.ShardData(*part, N_USER, N_ITEM)], [init], [perms], k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=True)
     assert job.touch
@@ -214,6 +216,7 @@ def test_touch_mode_windows_vs_oracle(n_rows, B, k, E):
     st = O.MFState(init[0].numpy().copy(), init[1].numpy().copy())
     losses = [O.train_epoch(st, part, perms[t].numpy(), B, 1e-3, 0.1, 0.9)[0] for t in range(E)]
     U, V = job.tables(0)
+    assert np.isfinite(st.U).all() and np.isfinite(st.V).all()
     assert rel(U, st.U) < 2e-5 and rel(V, st.V) < 2e-5, (rel(U, st.U), rel(V, st.V))
     np.testing.assert_allclose(np.sqrt(job.epoch_sse(0) / len(part[0])), losses, rtol=2e-5)
     job.close()

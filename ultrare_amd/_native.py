@@ -62,6 +62,8 @@ _PROTOTYPES = {
     'ure_host_partition': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, ctypes.c_double, _vp, _vp, _vp, _vp, _vp]),
     'ure_host_build_layout': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp,
                                              ctypes.POINTER(_i64), ctypes.POINTER(_i32), _vp, _vp]),
+    'ure_host_build_layouts': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i32, _i32,
+                                              ctypes.POINTER(_vp), _vp, _vp, ctypes.c_int]),
     'ure_host_build_units': (ctypes.c_int, [_vp, _i32, _i32, _vp, _i64, ctypes.POINTER(_i64)]),
     'ure_score': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_int, _vp, _vp, _vp, _i64, ctypes.c_int, _vp, _vp, _vp]),
@@ -204,14 +206,51 @@ def partition(uid, iid, rating, shard_of_user, n_shards, max_rating):
     return [(ou[off[s]:off[s + 1]], oi[off[s]:off[s + 1]], orr[off[s]:off[s + 1]]) for s in range(n_shards)]
 
 
-def build_layout(uid, iid, rating, n_user, n_item, want_pos=False):
-    """ure_host_build_layout on numpy triples -> dict of numpy arrays + counts."""
+def layout_region_words(n, n_user, n_item):
+    """int32 words of a packed layout region (ure_host_build_layouts) for n interactions."""
+    return 3 * layout_capacity(n, n_user, n_item) + 5 * (n_user + n_item)
+
+
+def build_layouts(triples, n_user, n_item, regions, threads=0):
+    """ure_host_build_layouts: triples = [(uid int64, iid int64, rating float64)], regions = [int32 numpy views of
+    layout_region_words() words] -> (n_slots [S], n_active [S])."""
+    S = len(triples)
+    keep = []
+    def col(c, dt):
+        arr = [np.ascontiguousarray(t[c], dtype=dt) for t in triples]
+        keep.append(arr)
+        return (_vp * S)(*[a.ctypes.data for a in arr])
+    n = np.array([len(t[0]) for t in triples], dtype=np.int64)
+    for s, (t, r) in enumerate(zip(triples, regions)):
+        assert len(t[0]) == len(t[1]) == len(t[2]) and r.dtype == np.int32 and r.flags['C_CONTIGUOUS']
+        assert len(r) >= layout_region_words(len(t[0]), n_user, n_item)
+    reg = (_vp * S)(*[r.ctypes.data for r in regions])
+    n_slots, n_active = np.zeros(S, dtype=np.int64), np.zeros(S, dtype=np.int32)
+    check(lib().ure_host_build_layouts(S, col(0, np.int64), col(1, np.int64), col(2, np.float64), n.ctypes.data, n_user, n_item, reg,
+                                       n_slots.ctypes.data, n_active.ctypes.data, int(threads)), 'ure_host_build_layouts')
+    return n_slots, n_active
+
+
+def layout_capacity(n, n_user, n_item):
+    """Slots ure_host_build_layout may write for n interactions (every row's segment is padded to a multiple of 8)."""
+    return 2 * n + 8 * (n_user + n_item) + 8
+
+
+def build_layout(uid, iid, rating, n_user, n_item, want_pos=False, out=None):
+    """ure_host_build_layout on numpy triples -> dict of numpy arrays + counts.  out = (ent_oid, ent_r, ent_src, sched):
+    caller-owned destinations of layout_capacity() slots / [n_user + n_item, 4] (e.g. views of a pinned staging buffer)."""
     n = len(uid)
-    cap = 2 * n + 8 * (n_user + n_item) + 8
-    ent_oid = np.empty(cap, dtype=np.int32)
-    ent_r = np.empty(cap, dtype=np.float32)
-    ent_src = np.empty(cap, dtype=np.int32)
-    sched = np.empty((n_user + n_item, 4), dtype=np.int32)
+    cap = layout_capacity(n, n_user, n_item)
+    if out is not None:
+        ent_oid, ent_r, ent_src, sched = out
+        assert ent_oid.dtype == np.int32 and ent_r.dtype == np.float32 and ent_src.dtype == np.int32 and sched.dtype == np.int32
+        assert min(len(ent_oid), len(ent_r), len(ent_src)) >= cap and sched.shape == (n_user + n_item, 4)
+        assert all(a.flags['C_CONTIGUOUS'] for a in out)
+    else:
+        ent_oid = np.empty(cap, dtype=np.int32)
+        ent_r = np.empty(cap, dtype=np.float32)
+        ent_src = np.empty(cap, dtype=np.int32)
+        sched = np.empty((n_user + n_item, 4), dtype=np.int32)
     u_pos = np.empty(n, dtype=np.int32) if want_pos else None
     i_pos = np.empty(n, dtype=np.int32) if want_pos else None
     ns, na = _i64(), _i32()

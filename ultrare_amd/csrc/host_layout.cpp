@@ -180,13 +180,14 @@ int ure_host_partition(const int32_t *uid, const int32_t *iid, const double *rat
     return 0;
 }
 
-int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *rating, int64_t n, int32_t n_user, int32_t n_item,
-                          int32_t *ent_oid, float *ent_r, int32_t *ent_src, int32_t *sched,
-                          int64_t *n_slots, int32_t *n_active, int32_t *u_pos, int32_t *i_pos)
+}  // extern "C"
+
+// The slot layout of one shard (struct ure_shard) from its triples; ids / ratings in whatever width the caller holds them.
+template <typename IdT, typename RT>
+static int build_layout_t(const IdT *uid, const IdT *iid, const RT *rating, int64_t n, int32_t n_user, int32_t n_item,
+                          int32_t *ent_oid, float *ent_r, int32_t *ent_src, int32_t *sched, int32_t *row_slot,
+                          int64_t *n_slots, int32_t *n_active, int32_t *u_pos, int32_t *i_pos, bool packed)
 {
-    if (!uid || !iid || !rating || !ent_oid || !ent_r || !ent_src || !sched || !n_slots || !n_active ||
-        n <= 0 || n_user <= 0 || n_item <= 0)
-        return ure::fail(-1, "ure_host_build_layout: bad arguments");
     const int64_t n_rows = (int64_t)n_user + n_item;
     std::vector<int64_t> nnz(n_rows, 0);
     for (int64_t j = 0; j < n; ++j) {
@@ -203,22 +204,32 @@ int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *r
     for (int64_t v = 1; v <= max_nnz + 1; ++v) first[v] += first[v - 1];
     std::vector<int32_t> order(n_rows);
     for (int64_t r = 0; r < n_rows; ++r) order[first[max_nnz - nnz[r]]++] = (int32_t)r;
-    std::vector<int64_t> row_beg(n_rows);
     int64_t slots = 0;
+    for (int64_t r = 0; r < n_rows; ++r) slots += (nnz[r] + 7) / 8 * 8;
+    slots = std::max<int64_t>(slots, 8);
+    if (slots >= ((int64_t)1 << 31)) return ure::fail(-1, "ure_host_build_layout: shard too large for 32-bit slot indices");
+    if (packed) {
+        // one region: ent_oid [k] | ent_r [k] | ent_src [k] | sched [rows][4] | row_slot [rows], k = the slot count (known by now)
+        ent_r = reinterpret_cast<float *>(ent_oid + slots);
+        ent_src = ent_oid + 2 * slots;
+        sched = ent_oid + 3 * slots;
+        row_slot = sched + 4 * n_rows;
+    }
+    std::vector<int64_t> row_beg(n_rows);
+    int64_t at = 0;
     int32_t na = 0;
     for (int64_t q = 0; q < n_rows; ++q) {
         const int32_t r = order[q];
         const int64_t padded = (nnz[r] + 7) / 8 * 8;
-        row_beg[r] = slots;
+        row_beg[r] = at;
         sched[4 * q + 0] = r;
-        sched[4 * q + 1] = (int32_t)slots;
-        sched[4 * q + 2] = (int32_t)(slots + padded);
+        sched[4 * q + 1] = (int32_t)at;
+        sched[4 * q + 2] = (int32_t)(at + padded);
         sched[4 * q + 3] = (int32_t)nnz[r];
-        slots += padded;
+        at += padded;
         na += nnz[r] > 0;
+        if (row_slot) row_slot[r] = nnz[r] > 0 ? (int32_t)q : -1;      // active rows come first in the schedule: q < n_active
     }
-    slots = std::max<int64_t>(slots, 8);
-    if (slots >= ((int64_t)1 << 31)) return ure::fail(-1, "ure_host_build_layout: shard too large for 32-bit slot indices");
     *n_slots = slots;
     *n_active = na;
     std::memset(ent_oid, 0, sizeof(int32_t) * (size_t)slots);
@@ -228,11 +239,55 @@ int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *r
     std::vector<int64_t> cur(row_beg);
     for (int64_t j = 0; j < n; ++j) {
         const int64_t pu = cur[uid[j]]++, pi = cur[n_user + iid[j]]++;
-        ent_oid[pu] = iid[j]; ent_r[pu] = rating[j]; ent_src[pu] = (int32_t)j;
-        ent_oid[pi] = uid[j]; ent_r[pi] = rating[j]; ent_src[pi] = (int32_t)j;
+        const float rj = (float)rating[j];
+        ent_oid[pu] = (int32_t)iid[j]; ent_r[pu] = rj; ent_src[pu] = (int32_t)j;
+        ent_oid[pi] = (int32_t)uid[j]; ent_r[pi] = rj; ent_src[pi] = (int32_t)j;
         if (u_pos) u_pos[j] = (int32_t)pu;
         if (i_pos) i_pos[j] = (int32_t)pi;
     }
+    return 0;
+}
+
+extern "C" {
+
+int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *rating, int64_t n, int32_t n_user, int32_t n_item,
+                          int32_t *ent_oid, float *ent_r, int32_t *ent_src, int32_t *sched,
+                          int64_t *n_slots, int32_t *n_active, int32_t *u_pos, int32_t *i_pos)
+{
+    if (!uid || !iid || !rating || !ent_oid || !ent_r || !ent_src || !sched || !n_slots || !n_active ||
+        n <= 0 || n_user <= 0 || n_item <= 0)
+        return ure::fail(-1, "ure_host_build_layout: bad arguments");
+    return build_layout_t(uid, iid, rating, n, n_user, n_item, ent_oid, ent_r, ent_src, sched, nullptr, n_slots, n_active, u_pos, i_pos, false);
+}
+
+int ure_host_build_layouts(int n_shards, const int64_t *const *uid, const int64_t *const *iid, const double *const *rating, const int64_t *n,
+                           int32_t n_user, int32_t n_item, int32_t *const *region, int64_t *n_slots, int32_t *n_active, int n_threads)
+{
+    if (n_shards <= 0 || !uid || !iid || !rating || !n || !region || !n_slots || !n_active || n_user <= 0 || n_item <= 0)
+        return ure::fail(-1, "ure_host_build_layouts: bad arguments");
+    for (int s = 0; s < n_shards; ++s)
+        if (!uid[s] || !iid[s] || !rating[s] || !region[s] || n[s] <= 0) return ure::fail(-1, "ure_host_build_layouts: shard %d: bad arguments", s);
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    nt = std::max(1, std::min(nt, n_shards));
+    std::atomic<int> next{0}, rc{0};
+    // (ure::fail keeps its message per thread: a worker's failure is re-reported on the calling thread below)
+    std::vector<int> bad(n_shards, 0);
+    auto work = [&]() {
+        for (int s = next.fetch_add(1); s < n_shards; s = next.fetch_add(1)) {
+            const int r = build_layout_t(uid[s], iid[s], rating[s], n[s], n_user, n_item, region[s], (float *)nullptr, (int32_t *)nullptr,
+                                         (int32_t *)nullptr, (int32_t *)nullptr, n_slots + s, n_active + s, (int32_t *)nullptr, (int32_t *)nullptr, true);
+            if (r) { bad[s] = r; rc.store(r); }
+        }
+    };
+    if (nt == 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t) pool.emplace_back(work);
+        for (auto &th : pool) th.join();
+    }
+    if (rc.load())
+        for (int s = 0; s < n_shards; ++s)
+            if (bad[s]) return ure::fail(bad[s], "ure_host_build_layouts: shard %d has an id outside [0,%d) x [0,%d) or is too large", s, n_user, n_item);
     return 0;
 }
 

@@ -255,9 +255,12 @@ __device__ __forceinline__ void top_k_positions(const float *__restrict__ val, i
 template <int K>
 __device__ __forceinline__ void top_k_in_registers(float val, int cnt, int lane, int (&top)[K])
 {
+    // entry t is broadcast through a scalar register (v_readlane: t is wave-uniform) -- a ds_bpermute per entry, as __shfl
+    // compiles to, sends all 64 lanes through the LDS crossbar for it (eval_users: 125 -> 7x us per series call, r3)
     int rank = 0;
+    const int vi = __builtin_bit_cast(int, val);
     for (int t = 0; t < cnt; ++t) {
-        const float ov = __shfl(val, t, kWave);
+        const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, t));
         rank += key_gt(ov, t, val, lane) ? 1 : 0;
     }
 #pragma unroll
@@ -291,6 +294,17 @@ __device__ __forceinline__ void top_k_multi(const float (&val)[kRegItems], int c
     }
 }
 
+// One rotation of a 16-lane row by N lanes (DPP row_ror): a VALU move, no LDS crossbar.  The entry's position travels with
+// its value, so nothing here depends on the direction of the rotation.
+template <int N>
+__device__ __forceinline__ void quarter_rank_steps(const int vi, const int s, const int cnt, const float val, int &rank)
+{
+    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x120 + N, 0xF, 0xF, false));
+    const int ot = __builtin_amdgcn_update_dpp(0, s, 0x120 + N, 0xF, 0xF, false);
+    rank += (ot < cnt && key_gt(ov, ot, val, s)) ? 1 : 0;
+    if constexpr (N < 15) quarter_rank_steps<N + 1>(vi, s, cnt, val, rank);
+}
+
 // Rank of every entry of a segment of at most 16 entries held one per lane by a quarter wave (lanes 16 g .. 16 g + 15):
 // the in-register selection of top_k_in_registers at width 16, four users per wavefront.
 template <int K>
@@ -298,11 +312,7 @@ __device__ __forceinline__ void top_k_quarter(float val, int cnt, int lane, int 
 {
     const int g16 = lane & ~15, s = lane & 15;
     int rank = 0;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const float ov = __shfl(val, g16 + t, kWave);
-        rank += (t < cnt && key_gt(ov, t, val, s)) ? 1 : 0;
-    }
+    quarter_rank_steps<1>(__builtin_bit_cast(int, val), s, cnt, val, rank);      // all 15 other lanes of the row, one rotation each
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const unsigned long long m = __ballot(s < cnt && rank == k);

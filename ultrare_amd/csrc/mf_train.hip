@@ -477,17 +477,21 @@ __device__ __forceinline__ bool touch_window_start(const ure_shard_t &S, const s
     return true;
 }
 
-template <int LPR>
-__global__ __launch_bounds__(kBlock) void touch_prep_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, int phase,
-                                                            int piece_blocks)
+// (the phase is a template parameter so that a kernel trace tells the two launches apart)
+template <int LPR, int PHASE>
+__global__ __launch_bounds__(kBlock) void touch_prep_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, int piece_blocks)
 {
     __shared__ unsigned long long wg_mask[kBlock];
     const ure_shard_t &S = shards[blockIdx.y];
     const shard_aux &A = aux[blockIdx.y];
     TouchPos P;
     if (!touch_window_start(S, A, tick, &P)) return;
-    if (phase == 1) {
+    if (PHASE == 1) {
         if ((int)blockIdx.x < touch_piece_blocks<LPR>(S.n_units, S.n_active, S.n_multi)) touch_build_masks<LPR>(S, A, P, (int)blockIdx.x, wg_mask);
+    } else if (PHASE == 3) {      // -DURE_TOUCH_SPLIT (profiling only): the two halves of launch C as launches of their own
+        touch_mark_tags<LPR>(S, A, P, (int)blockIdx.x);
+    } else if (PHASE == 4) {
+        touch_advance_rows(S, A, P, (int)blockIdx.x, (int)gridDim.x);
     } else if ((int)blockIdx.x < piece_blocks) touch_mark_tags<LPR>(S, A, P, (int)blockIdx.x);
     else touch_advance_rows(S, A, P, (int)blockIdx.x - piece_blocks, (int)gridDim.x - piece_blocks);
 }
@@ -520,8 +524,13 @@ static void launch_touch_prep(const ure_job *job, int64_t tick, hipStream_t st)
     int pieces = 1;
     for (const ure_shard_t &S : job->host) pieces = std::max(pieces, touch_piece_blocks<LPR>(S.n_units, S.n_active, S.n_multi));
     const unsigned adv_b = (unsigned)std::max<int64_t>(1, std::min<int64_t>((job->max_active4 + kBlock - 1) / kBlock, 8192));
-    hipLaunchKernelGGL((touch_prep_kernel<LPR>), dim3((unsigned)pieces, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, 1, pieces);
-    hipLaunchKernelGGL((touch_prep_kernel<LPR>), dim3((unsigned)pieces + adv_b, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, 2, pieces);
+    hipLaunchKernelGGL((touch_prep_kernel<LPR, 1>), dim3((unsigned)pieces, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, pieces);
+#ifdef URE_TOUCH_SPLIT
+    hipLaunchKernelGGL((touch_prep_kernel<LPR, 3>), dim3((unsigned)pieces, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, pieces);
+    hipLaunchKernelGGL((touch_prep_kernel<LPR, 4>), dim3(adv_b, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, pieces);
+#else
+    hipLaunchKernelGGL((touch_prep_kernel<LPR, 2>), dim3((unsigned)pieces + adv_b, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, pieces);
+#endif
 }
 
 template <int LPR, int V4>

@@ -29,6 +29,16 @@ TOUCH_MAX_STEPS = 32000              # kTouchMaxSteps of csrc/mf_touch.h (epochs
 TOUCH_MIN_TABLE_BYTES = 256 << 20    # auto rule: the job's live rows (w, m, second buffer) exceed the Infinity Cache
 
 
+# Host timeline of a call (URE_HOST_TRACE=1): (label, seconds) marks that tools/profile_e2e.py prints; off by default.
+HOST_TRACE = [] if os.environ.get('URE_HOST_TRACE', '0') == '1' else None
+
+
+def mark(label):
+    if HOST_TRACE is not None:
+        import time
+        HOST_TRACE.append((label, time.perf_counter()))
+
+
 def pad_dim(d):
     """Table width used on the device: next power of two >= max(d, 4).  Padding
     columns are zero at init; their gradient and decay keep them exactly zero."""
@@ -46,15 +56,20 @@ def _device():
     return torch.device('cuda', torch.cuda.current_device())
 
 
-class ShardData:
-    """One shard's interactions laid out for the step kernel: every destination row
-    (users, then items) owns an 8-aligned, padded segment of one slot array; segments
-    follow the row schedule (heaviest first)."""
-
-    def __init__(self, uid, iid, rating, n_user, n_item, device=None, keep_positions=False):
-        uid = np.ascontiguousarray(uid, dtype=np.int32)
-        iid = np.ascontiguousarray(iid, dtype=np.int32)
-        rating = np.ascontiguousarray(rating, dtype=np.float32)
+def build_shards(triples, n_user, n_item, device=None, keep_positions=False):
+    """The HBM layouts of the shards of one call: triples = [(uid, iid, rating)] -> [ShardData].
+    ONE native call builds every layout, side by side on host threads, packed into one pinned staging buffer (pooled);
+    each goes up in one asynchronous copy on the current stream into its part of one device allocation, and the
+    engine-side scratch of all shards (batch tags, inverse-permutation stages) comes from two fills.  From pageable numpy
+    arrays, shard after shard, the same 22 MB of a 5-shard ml-1m call took 9-10 ms of a 20 ms Sisa.learn (profiles/r03/NOTES.md)."""
+    from . import rng
+    n_user, n_item = int(n_user), int(n_item)
+    dev = device or _device()
+    on_gpu = torch.device(dev).type == 'cuda'
+    rows = n_user + n_item
+    cols = []
+    for uid, iid, rating in triples:
+        uid, iid, rating = np.asarray(uid), np.asarray(iid), np.asarray(rating)
         n = len(uid)
         if n == 0:
             raise ValueError('a shard needs at least one interaction')
@@ -62,38 +77,82 @@ class ShardData:
             raise ValueError('uid / iid / rating lengths differ')
         if uid.min() < 0 or uid.max() >= n_user or iid.min() < 0 or iid.max() >= n_item:
             raise ValueError('user or item id outside [0, n_user) x [0, n_item)')
-        self.N, self.n_user, self.n_item = n, int(n_user), int(n_item)
-        self.device = device or _device()
-        lay = nv.build_layout(uid, iid, rating, n_user, n_item, want_pos=keep_positions)
-        ent_oid, ent_r, ent_src, sched = lay['ent_oid'], lay['ent_r'], lay['ent_src'], lay['sched']
-        u_pos, i_pos = lay['u_pos'], lay['i_pos']
-        self.n_slots, self.n_active = lay['n_slots'], lay['n_active']
-        self.max_row = int(sched[0, 3])
-        dev = self.device
-        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        self.ent_oid, self.ent_r = to(ent_oid), to(ent_r)
-        self.ent_src = to(ent_src)
-        self.u_pos, self.i_pos = u_pos, i_pos                                              # host copies (tests, tools)
-        self.ent_tag = torch.full((2, self.n_slots), -1, dtype=torch.int16, device=dev)   # 0xFFFF: matches no batch
-        self.file_tag = torch.full((n,), -1, dtype=torch.int16, device=dev)
-        ranges = (n + 2047) // 2048
-        self.inv_stage = torch.zeros(n, dtype=torch.int32, device=dev)
-        self.inv_off = torch.zeros(max(ranges * (ranges + 1), 1) if ranges <= 1024 else 1, dtype=torch.int32, device=dev)
-        self.sched = to(sched)
-        self._sched_host = sched
-        self._units = {}
-        self._row_slot = None
-        ShardData.built += 1
+        cols.append((uid, iid, rating))
+    S = len(cols)
+    al = lambda x: (x + 7) // 8 * 8                              # every array starts on a 32-byte boundary
+    words = [al(nv.layout_region_words(len(c[0]), n_user, n_item)) for c in cols]
+    stage = rng.STAGING.take((sum(words),), torch.int32)
+    host = stage.numpy()
+    off = np.concatenate([[0], np.cumsum(words)]).astype(np.int64)
+    n_slots, n_active = nv.build_layouts(cols, n_user, n_item, [host[off[s]:off[s + 1]] for s in range(S)], threads=min(S, rng.host_cpus()))
+    used = [al(3 * int(k) + 5 * rows) for k in n_slots]
+    d_off = np.concatenate([[0], np.cumsum(used)]).astype(np.int64)
+    blob = torch.empty(int(d_off[-1]), dtype=torch.int32, device=dev)
+    pinned = stage.is_pinned() and on_gpu
+    for s in range(S):
+        blob[d_off[s]:d_off[s] + used[s]].copy_(stage[off[s]:off[s] + used[s]], non_blocking=pinned)
+    # engine-side scratch: batch tags (0xFFFF matches no batch) and the stages of the inverse permutation
+    t_words = [(al(2 * int(k)), al(len(c[0]))) for k, c in zip(n_slots, cols)]
+    z_words = [(al(len(c[0])), al(max(((len(c[0]) + 2047) // 2048) * ((len(c[0]) + 2047) // 2048 + 1), 1) if (len(c[0]) + 2047) // 2048 <= 1024 else 1))
+               for c in cols]
+    tags = torch.full((sum(a + b for a, b in t_words),), -1, dtype=torch.int16, device=dev)
+    zeros = torch.zeros(sum(a + b for a, b in z_words), dtype=torch.int32, device=dev)
+    out, t_at, z_at = [], 0, 0
+    for s, (uid, iid, rating) in enumerate(cols):
+        sh = object.__new__(ShardData)
+        n, k = len(uid), int(n_slots[s])
+        sh.N, sh.n_user, sh.n_item, sh.device = n, n_user, n_item, dev
+        sh.n_slots, sh.n_active = k, int(n_active[s])
+        part = blob[d_off[s]:d_off[s] + used[s]]
+        sh._blob = blob
+        sh.ent_oid, sh.ent_r, sh.ent_src = part[:k], part[k:2 * k].view(torch.float32), part[2 * k:3 * k]
+        sh.sched = part[3 * k:3 * k + 4 * rows].view(rows, 4)
+        sh._row_slot = part[3 * k + 4 * rows:3 * k + 5 * rows]
+        sh._sched_host = host[off[s] + 3 * k:off[s] + 3 * k + 4 * rows].reshape(rows, 4).copy()
+        sh.max_row = int(sh._sched_host[0, 3])
+        sh.u_pos = sh.i_pos = None
+        if keep_positions:                                        # host copies of every interaction's two slots (tests, tools)
+            lay = nv.build_layout(np.ascontiguousarray(uid, dtype=np.int32), np.ascontiguousarray(iid, dtype=np.int32),
+                                  np.ascontiguousarray(rating, dtype=np.float32), n_user, n_item, want_pos=True)
+            sh.u_pos, sh.i_pos = lay['u_pos'], lay['i_pos']
+        a, b = t_words[s]
+        sh.ent_tag = tags[t_at:t_at + 2 * k].view(2, k)
+        sh.file_tag = tags[t_at + a:t_at + a + n]
+        t_at += a + b
+        a, b = z_words[s]
+        sh.inv_stage = zeros[z_at:z_at + n]
+        sh.inv_off = zeros[z_at + a:z_at + a + b]
+        z_at += a + b
+        sh._units = {}
+        out.append(sh)
+    # whoever trains on a layout from another stream (layouts may be built on a worker thread, whose current stream is the
+    # device's default stream) waits for this event first: TrainJob does
+    ready = None
+    if on_gpu:
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+    rng.STAGING.give(stage, ready if pinned else None)
+    for sh in out:
+        sh.ready = ready
+    with ShardData._count_lock:
+        ShardData.built += S
+    return out
 
+
+class ShardData:
+    """One shard's interactions laid out for the step kernel: every destination row
+    (users, then items) owns an 8-aligned, padded segment of one slot array; segments
+    follow the row schedule (heaviest first).  Built by build_shards()."""
+
+    def __init__(self, uid, iid, rating, n_user, n_item, device=None, keep_positions=False):
+        self.__dict__.update(build_shards([(uid, iid, rating)], n_user, n_item, device, keep_positions)[0].__dict__)
+
+    _count_lock = __import__('threading').Lock()
     built = 0            # layouts built (and uploaded) by this process: lets a measurement show that its timed call paid for them
 
     def row_slot(self):
         """Device int32 [n_user + n_item]: a row's index in the schedule when it is one of the n_active rows with
         interactions in this shard (the rows a compact snapshot stores), -1 otherwise."""
-        if self._row_slot is None:
-            slot = np.full(self.n_user + self.n_item, -1, dtype=np.int32)
-            slot[self._sched_host[:self.n_active, 0]] = np.arange(self.n_active, dtype=np.int32)
-            self._row_slot = torch.from_numpy(slot).to(self.device)
         return self._row_slot
 
     def units(self, d, touch=False):
@@ -121,9 +180,21 @@ class ShardData:
                    (self.ent_oid, self.ent_r, self.ent_tag, self.ent_src, self.file_tag, self.sched))
 
 
+_CLOSED_FORM = {}
+
+
 def closed_form_scalars(lr_host, steps, lam, mu):
     """a_e with w = a_e * w0 after epoch e for a row that only decays: the optimizer's recurrence
     g = lam*w; m = mu*m + g (m = g on the first step); w -= lr*m, in float64 (as ure_job_materialize)."""
+    key = (np.asarray(lr_host, dtype=np.float32).tobytes(), int(steps), float(lam), float(mu))
+    if key not in _CLOSED_FORM:
+        if len(_CLOSED_FORM) > 256:
+            _CLOSED_FORM.clear()
+        _CLOSED_FORM[key] = _closed_form_scalars(lr_host, steps, lam, mu)
+    return _CLOSED_FORM[key].copy()
+
+
+def _closed_form_scalars(lr_host, steps, lam, mu):
     a, b, out, t = 1.0, 0.0, [], 0
     for e in range(len(lr_host)):
         lr = float(lr_host[e])
@@ -172,6 +243,9 @@ class TrainJob:
         self.state = []
         self._chunks = []        # per shard whose permutations are uploaded in chunks: [(first epoch after the chunk, event), ...]
         descs = (nv.UreShard * len(shards))()
+        for sh in shards:
+            if sh.ready is not None:
+                torch.cuda.current_stream(dev).wait_event(sh.ready)
         for s, (sh, (U0, V0), perm) in enumerate(zip(shards, inits, perms)):
             for t in (U0, V0):
                 if getattr(t, '_ure_event', None) is not None:          # uploaded on a side stream (rng.shard_draws_async)

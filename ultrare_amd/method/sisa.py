@@ -62,15 +62,27 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
         torch.set_rng_state(end)
         mine = [pos for pos in range(len(ids)) if owner[pos] == rank]
         per_call = max(2, PERM_THREADS // max(len(mine), 1))
+        # every owned shard's model init starts on its worker at once; the permutation expansion (36 ms of CPU time for a
+        # 5-shard, 50-epoch call) waits behind `gate` until the HBM layouts -- which training needs first -- are built:
+        # one native call for all of them, side by side on host threads into pinned staging, uploaded asynchronously
+        # (a layout a loader already holds is returned as it is)
+        import threading
+        from ..read import shard_layouts
+        gate = threading.Event()
+        own_ids = [i for pos, i in enumerate(ids) if owner[pos] == rank]
         futures = {}
-        for pos, i in enumerate(ids):
-            loader = as_loader(train_dlist[i])
-            if owner[pos] == rank:
-                futures[i] = rng.shard_draws_async(starts[pos], n_user, n_item, k, epochs, True, len(loader.dataset), loader.shuffle,
-                                                   threads=per_call, device=engine._device())
-            elif foreign_u0 is not None:
-                futures[i] = rng.shard_draws_async(starts[pos], n_user, n_item, k, epochs, True, 0, False, want_perms=False)
-        shards = {i: as_loader(train_dlist[i]).shard_data(n_user, n_item) for pos, i in enumerate(ids) if owner[pos] == rank}
+        try:
+            for pos, i in enumerate(ids):
+                loader = as_loader(train_dlist[i])
+                if owner[pos] == rank:
+                    futures[i] = rng.shard_draws_async(starts[pos], n_user, n_item, k, epochs, True, len(loader.dataset), loader.shuffle,
+                                                       threads=per_call, device=engine._device(), gate=gate)
+                elif foreign_u0 is not None:
+                    futures[i] = rng.shard_draws_async(starts[pos], n_user, n_item, k, epochs, True, 0, False, want_perms=False)
+            shards = dict(zip(own_ids, shard_layouts([as_loader(train_dlist[i]) for i in own_ids], n_user, n_item, engine._device())))
+        finally:
+            gate.set()
+        engine.mark('layouts')
         for pos, i in enumerate(ids):
             if i not in futures:
                 continue
@@ -78,6 +90,7 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
                 prepared[i] = (shards[i], futures[i].init(), futures[i].perms())     # the permutations may still be arriving (chunks)
             else:
                 foreign_u0[i] = futures[i].init()[0]
+        engine.mark('inits')
         return prepared
     for pos, i in enumerate(ids):
         if owner[pos] == rank:
@@ -192,6 +205,7 @@ class Sisa(Scratch):
         that epoch) are computed afterwards, so log{id}.npy carries the same series as a
         sequential run."""
         seed_all(self.seed)
+        engine.mark('start')
         dist = _dist()
         world = dist.get_world_size() if dist else 1
         rank = dist.get_rank() if dist else 0
@@ -218,7 +232,9 @@ class Sisa(Scratch):
                                   [prepared[i][2] for i in mine], self.k, batch, self.epochs, self.lr, self.lam,
                                   self.momentum, self.lr_decay, snapshots=snap_mode if keep_logs else False)
             from .. import rng
+            engine.mark('job_created')
             job.run()
+            engine.mark('launched')
             for i in mine:
                 rng.release(prepared[i][2])                 # uploaded: host buffers go back to the pool
             for pos, i in enumerate(mine):
@@ -245,6 +261,7 @@ class Sisa(Scratch):
         out = {i: MF.from_tables(*models[i]) for i in ids}
 
         # ---- logs, shard after shard in the reference's order (one dict for all shards)
+        engine.mark('models')
         logs, queued = {}, {}
         for i in mine:                # every shard's two test series are queued first; results are read once, below
             if keep_logs:
@@ -265,6 +282,7 @@ class Sisa(Scratch):
                 job.evaluate_series(pos, test_ev, before, res[0])
                 job.evaluate_series(pos, total_ev, before, res[1])
                 queued[i] = res
+        engine.mark('series_queued')
         for pos, i in enumerate(mine):
             entry = {'train_loss': [float(x) for x in np.sqrt(job.epoch_sse(pos) / prepared[i][0].N)]}
             if keep_logs:
@@ -278,6 +296,7 @@ class Sisa(Scratch):
                 for key in ('test_rmse', 'test_ndcg', 'test_hr', 'total_rmse', 'total_ndcg', 'total_hr'):
                     entry[key] = list(nan)
             logs[i] = entry
+        engine.mark('logs_read')
         if job is not None:
             job.close()
         if dist:

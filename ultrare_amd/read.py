@@ -129,18 +129,34 @@ class ShardLoader:
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
 
-    def shard_data(self, n_user, n_item):
-        from .engine import ShardData
-        key = ('train', n_user, n_item)
-        if key not in self._cache:
-            self._cache[key] = ShardData(*self.dataset.triples(), n_user, n_item)
-        return self._cache[key]
+    def shard_data(self, n_user, n_item, device=None):
+        """The shard's HBM layout (built and uploaded on first use, then kept on the loader)."""
+        return shard_layouts([self], n_user, n_item, device)[0]
 
     def eval_set(self):
         from .engine import EvalSet
         if 'eval' not in self._cache:
             self._cache['eval'] = EvalSet(*self.dataset.triples())
         return self._cache['eval']
+
+
+def shard_layouts(loaders, n_user, n_item, device=None):
+    """The HBM layouts of several shards' loaders; the missing ones are built together (engine.build_shards: one native
+    call for all of them) and kept on their loaders.  device: required when called from a worker thread, whose current HIP
+    device is not the caller's."""
+    from .engine import build_shards
+    key = ('train', n_user, n_item)
+    todo = [l for l in loaders if key not in l._cache]
+    if todo:
+        raw = [(l.dataset.users, l.dataset.items, l.dataset.ratings) for l in todo]
+        if device is not None and torch.device(device).type == 'cuda':
+            with torch.cuda.device(device):
+                built = build_shards(raw, n_user, n_item, device)
+        else:
+            built = build_shards(raw, n_user, n_item, device)
+        for l, sh in zip(todo, built):
+            l._cache[key] = sh
+    return [l._cache[key] for l in loaders]
 
 
 def as_loader(obj):

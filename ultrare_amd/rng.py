@@ -24,6 +24,23 @@ def host_cpus():
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
+    # a container's CPU quota (cgroup v2 cpu.max, v1 cfs_quota_us / cfs_period_us): the 1-GPU boxes of the pool this was
+    # measured on show 256 CPUs and grant 16; threads beyond the quota only get throttled (tools/probe_host.py)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+                quota = int(f.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                period = int(f.read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
     return max(1, n // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1)))
 
 
@@ -32,7 +49,7 @@ def perm_threads():
     (250 Fisher-Yates permutations of 0.5 ms each are half of a 5-shard, 50-epoch call's wall time on 16 threads)."""
     import os
     env = os.environ.get('URE_PERM_THREADS')
-    return max(1, int(env)) if env else min(64, host_cpus())
+    return max(1, int(env)) if env else min(64, 2 * host_cpus())      # (2 x: measured best on a 16-CPU quota, 2.3 vs 3.0 ms per 250 permutations)
 
 
 def fill_draws(n):
@@ -134,32 +151,41 @@ class _HostPool:
     training costs device time, so buffers are kept and handed out again."""
 
     def __init__(self):
-        self.free = []
+        self.free = []          # [(buffer, event or None)]: a buffer whose last copy is still in flight is not handed out
         self.lent = {}
+        self.lock = threading.Lock()
 
     def take(self, shape, dtype):
         need = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
-        best = None
-        for i, b in enumerate(self.free):
-            if b.numel() >= need and (best is None or b.numel() < self.free[best].numel()):
-                best = i
-        if best is not None:
-            buf = self.free.pop(best)
-        else:
+        with self.lock:
+            best = None
+            for i, (b, ev) in enumerate(self.free):
+                if b.numel() >= need and (best is None or b.numel() < self.free[best][0].numel()) and (ev is None or ev.query()):
+                    best = i
+            buf = self.free.pop(best)[0] if best is not None else None
+        if buf is None:
+            # size classes (steps of 1/8 of the power of two below the size, at least 1 MiB): the shards of consecutive requests
+            # differ by a few rows -- another deletion set -- and must find the buffers of the previous request large enough;
+            # allocating 36 MB of pinned memory costs more host time than expanding the permutations that go into it
             size = max(need, 1)
-            size = (size + (1 << 20) - 1) >> 20 << 20
+            step = max(1 << 20, 1 << max(size.bit_length() - 4, 0))
+            size = (size + step - 1) // step * step
             buf = torch.empty(size, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
         view = buf[:need].view(dtype).view(shape)
-        self.lent[view.data_ptr()] = buf
+        with self.lock:
+            self.lent[view.data_ptr()] = buf
         return view
 
-    def give(self, view):
-        buf = self.lent.pop(view.data_ptr(), None)
-        if buf is not None:
-            self.free.append(buf)
+    def give(self, view, event=None):
+        """Hand a buffer back; with `event` (recorded after the last copy that reads it) it is reused only once that is done."""
+        with self.lock:
+            buf = self.lent.pop(view.data_ptr(), None)
+            if buf is not None:
+                self.free.append((buf, event))
 
 
-POOL = _HostPool()
+POOL = _HostPool()           # the epoch permutations
+STAGING = _HostPool()        # layout staging (engine.build_shards): its own pool, so that a 23 MB request never takes a 36 MB permutation buffer
 
 
 def release(perms):
@@ -285,20 +311,28 @@ class ShardDraws:
         return self.init(), self.perms()
 
 
+def worker_pool():
+    """The host workers of a SISA call (per-shard draws, layout builds): they spend their time inside native calls and
+    copies that release the GIL.  Two per shard of a call up to 64 (8 workers -- round 2 -- left half of a 16-shard call's
+    draws waiting behind the other half)."""
+    global _SHARD_POOL
+    if _SHARD_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _SHARD_POOL = ThreadPoolExecutor(max_workers=max(4, min(64, 2 * host_cpus())), thread_name_prefix='ure-shard')
+    return _SHARD_POOL
+
+
 def shard_draws_async(start_state, n_user, n_item, k, epochs, with_total_test, n_rows, shuffle, threads=0, device=None, want_perms=True,
-                      chunk_epochs=8):
+                      chunk_epochs=8, gate=None):
     """Everything random of ONE Scratch.train call, taken on a worker thread from its own generator positioned at
     `start_state` (shard_streams): the model init (utils.py:31-40), the per-epoch seeds and the expanded
     permutations.  The shards of a SISA call are independent streams once their start states are known, so their
     draws run side by side instead of one after the other.  With a HIP `device` the init tables and the permutations
     are uploaded on a side stream, the permutations in chunks of epochs so that training starts on the first epochs
-    while the later ones are still being expanded.  -> ShardDraws."""
-    global _SHARD_POOL
-    if _SHARD_POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        # one worker per shard of a call up to 64: a worker spends its time inside native calls that release the GIL
-        # (8 workers -- round 2 -- left half of a 16-shard call's draws waiting behind the other half)
-        _SHARD_POOL = ThreadPoolExecutor(max_workers=max(2, min(64, 2 * host_cpus())), thread_name_prefix='ure-shard')
+    while the later ones are still being expanded.  gate (threading.Event): the permutation expansion -- the bulk of the
+    CPU work -- starts only once it is set, so that whatever the caller needs first (the layouts) gets the cores first.
+    -> ShardDraws."""
+    worker_pool()
     from . import _native as nv
     nv.lib()
     big = n_rows >= (2 ** 32 - 1) // 20
@@ -353,6 +387,8 @@ def shard_draws_async(start_state, n_user, n_item, k, epochs, with_total_test, n
             return init, None
         if not shuffle:
             return init, torch.arange(n_rows, dtype=torch.int32).repeat(epochs, 1)
+        if gate is not None:
+            gate.wait()
         if host is None:
             return init, epoch_perms(seeds, n_rows, threads)
         sd = np.asarray(seeds, dtype=np.uint64).astype(np.int64)
