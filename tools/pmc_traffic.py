@@ -42,7 +42,8 @@ def main():
     shards = opt('--shards', '5' if workload == 'ml1m' else '32')
     d = opt('--d', '32' if workload == 'ml1m' else '128')
     batch = opt('--batch', '30000')
-    cmd_tail = ['python3', os.path.join(ROOT, 'bench.py')] + bench_args + ['--no-cpu-baseline', '--no-unlearn', '--steps', '5', '--warmup', '1']
+    tail = ['--no-cpu-baseline', '--no-unlearn'] + ([] if '--steps' in bench_args else ['--steps', '5']) + ([] if '--warmup' in bench_args else ['--warmup', '1'])
+    cmd_tail = ['python3', os.path.join(ROOT, 'bench.py')] + bench_args + tail
     env = dict(os.environ, TMPDIR='/tmp')
     sums = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     dur = defaultdict(lambda: [0.0, 0])
@@ -88,7 +89,7 @@ def main():
         e['mean_us_under_profiler'] = round(dur[k][0] / max(dur[k][1], 1), 2)
         kernels[k] = e
     res = {'command': 'python tools/pmc_traffic.py ... -- ' + ' '.join(bench_args) + '   (rocprofv3 --pmc <GROUP> --kernel-trace --output-format csv -- ' +
-                      ' '.join(['python3', 'bench.py'] + bench_args + ['--no-cpu-baseline', '--no-unlearn', '--steps', '5', '--warmup', '1']) +
+                      ' '.join(['python3', 'bench.py'] + bench_args + tail) +
                       '; one pass per counter group: ' + ' | '.join(GROUPS) + ')',
            'unit_note': 'FETCH_SIZE / WRITE_SIZE in KiB per dispatch; gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) reads '
                         '(MI355X_MICROARCH.md, HBM section): read bytes = 2 * FETCH_SIZE * 1024',

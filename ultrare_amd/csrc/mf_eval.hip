@@ -321,37 +321,49 @@ __device__ __forceinline__ void top_k_quarter(float val, int cnt, int lane, int 
     }
 }
 
-// HR@10 / NDCG@10 of one user from the two top-10 position lists (utils.py:172-184, 190-210); one lane per user.
+// HR@10 / NDCG@10 of one user from the two top-10 position lists (utils.py:172-184, 190-210).  The ten rank positions are
+// worked on by ten lanes side by side -- lane j of the user's lane group (the whole wave, or a quarter of it: QUARTER) looks
+// up rating[top_pred[j]], tests the threshold and the membership in top_rating, and divides by log2(j + 1) -- and the
+// group's first lane adds the ten terms in numpy's order.  (One lane doing all ten -- nine dependent float64 divisions,
+// ten dependent gathers, with the other 63 lanes idle -- was most of eval_users_kernel's time: 114 -> us per series call, r3.)
+template <bool QUARTER>
 __device__ __forceinline__ void user_metrics(const float *__restrict__ rating, int beg, int cnt, const int (&tp)[10], const int (&tr)[10],
-                                             const double *__restrict__ log2_tab, int32_t *hits_out, double *ndcg_out)
+                                             const double *__restrict__ log2_tab, int lane, bool have, int32_t *hits_out, double *ndcg_out)
 {
     constexpr int K = 10;
+    const int base = QUARTER ? (lane & ~15) : 0;
+    const int j = lane - base;
     const int n_top = cnt < K ? cnt : K;
-    double val[K];
-    int n_hit = 0;
+    int tpj = -1, trj = -1;
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        val[j] = 0.0;
-        if (j < n_top && tp[j] >= 0) {                                // (a position is always found; the guard keeps a bad input from reading out of bounds)
-            const double rel = (double)rating[beg + tp[j]];          // float32 widened (utils.py:132,153)
-            const bool hit = rel >= (4.0 / 5.0);                     // utils.py:175
-            n_hit += hit ? 1 : 0;
-            bool common = false;                                     // np.in1d(top_rating, top_pred)[j]
-#pragma unroll
-            for (int q = 0; q < K; ++q) common = common || (q < n_top && tr[j] >= 0 && tp[q] == tr[j]);
-            val[j] = (hit && common) ? rel : 0.0;
-        }
+    for (int k = 0; k < K; ++k) {
+        tpj = j == k ? tp[k] : tpj;
+        trj = j == k ? tr[k] : trj;
     }
-    // computeDCG (utils.py:209-210): r[0] + np.sum(r[1:] / log2(2..10)); np.sum of 9
-    // float64 = numpy pairwise: 8 lanes combined as a tree, then the 9th added.
-    // The ideal DCG, computeDCG(np.ones(10)), is a constant: the host evaluates it with numpy
-    // itself and passes it as log2_tab[9].
-    double a[K - 1];
+    double val = 0.0;
+    bool hit = false;
+    if (have && j < n_top && tpj >= 0) {                             // (a position is always found; the guard keeps a bad input from reading out of bounds)
+        const double rel = (double)rating[beg + tpj];                // float32 widened (utils.py:132,153)
+        hit = rel >= (4.0 / 5.0);                                    // utils.py:175
+        bool common = false;                                         // np.in1d(top_rating, top_pred)[j]
 #pragma unroll
-    for (int j = 0; j < K - 1; ++j) a[j] = val[j + 1] / log2_tab[j];
-    const double dcg = val[0] + ((((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + a[8]);
-    *hits_out = n_hit;
-    *ndcg_out = dcg / log2_tab[K - 1];
+        for (int q = 0; q < K; ++q) common = common || (q < n_top && trj >= 0 && tp[q] == trj);
+        val = (hit && common) ? rel : 0.0;
+    }
+    const unsigned long long votes = __ballot(hit);
+    const int n_hit = __popcll((votes >> base) & 0x3FFull);
+    // computeDCG (utils.py:209-210): r[0] + np.sum(r[1:] / log2(2..10)); np.sum of 9 float64 = numpy pairwise: 8 terms
+    // combined as a tree, then the 9th added.  The ideal DCG, computeDCG(np.ones(10)), is a constant: the host evaluates
+    // it with numpy itself and passes it as log2_tab[9].
+    const double term = (j >= 1 && j < K) ? val / log2_tab[j - 1] : val;
+    double t[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) t[k] = __shfl(term, base + k, kWave);
+    if (have && j == 0) {
+        const double dcg = t[0] + ((((t[1] + t[2]) + (t[3] + t[4])) + ((t[5] + t[6]) + (t[7] + t[8]))) + t[9]);
+        *hits_out = n_hit;
+        *ndcg_out = dcg / log2_tab[K - 1];
+    }
 }
 
 // Positions of the top-10 of `val` over the segment [beg, beg + cnt) of a wave-per-user segment (any length).
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__res
         } else {
             rank_wide<false>(rating, beg, cnt, lane, tr);
         }
-        if (lane == 0) user_metrics(rating, beg, cnt, tp, tr, log2_tab, hits + user, ndcg + user);
+        user_metrics<false>(rating, beg, cnt, tp, tr, log2_tab, lane, true, hits + user, ndcg + user);
         return;
     }
     const int user = n_wide + (wave - n_wide) * 4 + (lane >> 4);
@@ -440,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__res
         const float rv = s < cnt ? rating[beg + s] : 0.f;
         top_k_quarter<K>(rv, cnt, lane, tr);
     }
-    if (have && s == 0) user_metrics(rating, beg, cnt, tp, tr, log2_tab, hits + user, ndcg + user);
+    user_metrics<true>(rating, beg, cnt, tp, tr, log2_tab, lane, have, hits + (have ? user : 0), ndcg + (have ? user : 0));
 }
 
 // utils.py:163-184 tail: rmse = sqrt(sse / n_rows), ndcg = mean(ndcg), hr = mean(hits / 10), reduced on

@@ -160,8 +160,12 @@ __device__ __forceinline__ void touch_build_masks(const ure_shard_t &S, const sh
         }
         return;
     }
-    // work units: the units of a row sit side by side in this workgroup; the row's first unit combines them
+    // work units: the units of a row sit side by side in this workgroup; the row's first unit combines them.  The unit's OWN
+    // mask is kept as well: in a step that trains the row through other units only, this unit has nothing to scan -- with 750
+    // steps per epoch (full MF at 25 M rows) a unit of 128 slots has an interaction in one step of six, and the scan of all the
+    // others was 450 MB of tag / id / rating loads per step
     const int leader = uw & 0xFFFF, count = (uw >> 16) & 0x3FFF;
+    if (pc.x >= 0 && sub == 0) stg(A.unit_own + pc.w, mk);
     if (sub == 0) wg_mask[local] = mk;
     __syncthreads();
     if (pc.x >= 0 && sub == 0 && local == leader) {
@@ -244,7 +248,7 @@ __device__ __forceinline__ void touch_advance_rows(const ure_shard_t &S, const s
 // count << 16 | multi << 30}, mk = the row's step mask, hit = the row is trained in step s (lane-group uniform).
 template <int LPR, int V4>
 __device__ __forceinline__ void touch_process(const ure_shard_t &S, const shard_aux &A, const int4 du, const unsigned long long mk, const bool hit,
-                                              const int local, const TouchPos &P, const float lr, int *qo, float *qr,
+                                              const bool scan, const int local, const TouchPos &P, const float lr, int *qo, float *qr,
                                               float (*q_r)[kQueue], float4 (*part_acc)[V4][LPR])
 {
     const int epoch = P.epoch, s = P.s;
@@ -277,7 +281,7 @@ __device__ __forceinline__ void touch_process(const ure_shard_t &S, const shard_
     const float *__restrict__ other1 = other_tab[1];
     int *gq = qo + grp * CAP;
     float *gr = qr + grp * CAP;
-    const int beg = du.y, end = hit ? du.z : du.y;
+    const int beg = du.y, end = (hit && scan) ? du.z : du.y;      // scan: this unit's own slots have an interaction in the step
     for (int seg = beg;; seg += CAP) {
         if (!__any(seg < end)) break;
         const int p0 = seg + sub * kSegPerLane;
@@ -439,10 +443,11 @@ __device__ __forceinline__ void mf_touch_step(const ure_shard_t *__restrict__ sh
         const size_t u = (size_t)wg * UPB + local;
         const int4 du = ldg_i4(S.units + 4 * u);
         const unsigned long long mk = ldg(A.unit_mask + u);
+        const unsigned long long own = ldg(A.unit_own + u);
         const bool hit = du.x >= 0 && ((mk >> P.sl) & 1ull);
         const bool multi = (du.w >> 30) & 1;
         if (!multi && !__any(hit)) return;
-        touch_process<LPR, V4>(S, A, du, mk, hit, local, P, lr, qo, qr, q_r, part_acc);
+        touch_process<LPR, V4>(S, A, du, mk, hit, (own >> P.sl) & 1ull, local, P, lr, qo, qr, q_r, part_acc);
         return;
     }
     if (wg < nbU + nbC) {
@@ -476,7 +481,7 @@ __device__ __forceinline__ void mf_touch_step(const ure_shard_t *__restrict__ sh
             unsigned long long rm = 0ull;
             if (have) { du = cand_row[e]; rm = cand_mask[e]; }
             du.w = local | (1 << 16);                          // its own leader, one unit, no partial sums to combine
-            touch_process<LPR, V4>(S, A, du, rm, have, local, P, lr, qo, qr, q_r, part_acc);
+            touch_process<LPR, V4>(S, A, du, rm, have, true, local, P, lr, qo, qr, q_r, part_acc);
         }
         return;
     }

@@ -669,12 +669,13 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             // the masks once more in work order: per work unit (multi-pass rows) and per single-pass row of the schedule
             const size_t n_um = (size_t)std::max(shards[k].n_units, 1), n_sm = (size_t)std::max(shards[k].n_active - shards[k].n_multi, 1);
             void *wm = nullptr;
-            e = hipMalloc(&wm, (n_um + n_sm) * sizeof(unsigned long long));
+            e = hipMalloc(&wm, (2 * n_um + n_sm) * sizeof(unsigned long long));
             if (e != hipSuccess) break;
             job->touch_mem.push_back(wm);
-            e = hipMemset(wm, 0, (n_um + n_sm) * sizeof(unsigned long long));
+            e = hipMemset(wm, 0, (2 * n_um + n_sm) * sizeof(unsigned long long));
             job->aux_host[k].unit_mask = static_cast<unsigned long long *>(wm);
-            job->aux_host[k].sched_mask = static_cast<unsigned long long *>(wm) + n_um;
+            job->aux_host[k].unit_own = static_cast<unsigned long long *>(wm) + n_um;
+            job->aux_host[k].sched_mask = static_cast<unsigned long long *>(wm) + 2 * n_um;
         }
     }
     if (e == hipSuccess) e = hipMalloc(&job->dev_aux, sizeof(shard_aux) * n_shards);

@@ -188,6 +188,7 @@ struct shard_aux {
     unsigned long long *mask[2];   // [n_user + n_item] steps of the window in which the row is trained (bit = step - 64 w), by global window parity
     const float4 *ptab;            // [epochs][65] A_e^j = {p11, p12, p21, p22}: j optimizer steps without a gradient at epoch e's lr
     unsigned long long *unit_mask; // [n_units] the current window's mask of each work unit's row
+    unsigned long long *unit_own;  // [n_units] the steps of the window in which the UNIT's own slots have interactions (a subset of its row's)
     unsigned long long *sched_mask;// [n_active - n_multi] the same for the single-pass rows, in schedule order
 };
 
