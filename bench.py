@@ -326,7 +326,8 @@ def cpu_baseline_of(a, leg, d, batch):
     shard_of, _ = synth.uniform_shards(spec['n_user'], len(leg['all_sizes']))
     part0 = synth.split_shards(data['train'], shard_of, len(leg['all_sizes']))[0]
     test0 = synth.split_shards(data['test'], shard_of, len(leg['all_sizes']))[0]
-    ncpu = os.cpu_count() or 1
+    from ultrare_amd import rng
+    ncpu = rng.host_cpus()          # the CPUs this container may really use (cgroup quota), not the host's count
     # ---- arithmetic only (pre-batched tensors): sweep the intra-op thread count, keep the best
     sweep = {}
     for t in [x for x in (1, 4, 8, 16, 32, 64) if x <= ncpu]:
@@ -344,7 +345,7 @@ def cpu_baseline_of(a, leg, d, batch):
                                                             workers=workers, budget_s=budget * 0.4)
     n0 = len(part0[0])
     return {'value': round(seen / spent, 1), 'unit': 'interactions/s', 'cores': min(ncpu, workers + best_t), 'kind': 'port',
-            'threads': best_t, 'workers': workers, 'host_cpus': ncpu,
+            'threads': best_t, 'workers': workers, 'host_cpus': ncpu, 'machine_cpus': os.cpu_count(),
             'sample': f'shard 0 ({n0} rows), {seen // n0} epoch(s) = {seen} interactions in {spent:.1f}s; '
                       f'per-sample Dataset + DataLoader({workers} worker processes) + nn.Embedding + SGD with {best_t} torch threads',
             'prebatched_value': sweep[best_t], 'prebatched_thread_sweep': sweep,

@@ -108,6 +108,10 @@ typedef struct ure_shard {
      * Every other row of the tables is a_e * w0 by construction and is rebuilt where it is read
      * (ure_eval_series_compact).  At BASELINE.json configs[3] a shard has 60.8 k active rows of 222 k.   */
     float       *snap;      /* [epochs][n_active][d]                                 */
+    const int32_t *row_slot;/* [n_user + n_item] row id -> its index in the schedule when it is one of the n_active rows, -1
+                             * otherwise (ure_host_build_layouts writes it).  With it (and without touch_mode) the step kernel
+                             * writes a row's compact snapshot itself in the last step of an epoch -- every active row is
+                             * rewritten in every step -- and no snapshot launch is needed; NULL: a copy kernel per epoch end. */
     /* per-epoch inputs / outputs */
     const int32_t *perm;    /* [epochs][N] the epoch permutations (RandomSampler)   */
     const float   *lr;      /* [epochs] learning rate of each epoch (StepLR)        */

@@ -26,7 +26,7 @@ class UreShard(ctypes.Structure):
         ('sched', _vp), ('units', _vp), ('n_units', _i32), ('n_active', _i32), ('n_slots', _i64),
         ('U', _vp * 2), ('V', _vp * 2), ('mU', _vp), ('mV', _vp),
         ('U0', _vp), ('V0', _vp), ('lr_host', _vp), ('lazy_rows', _i32),
-        ('snapU', _vp), ('snapV', _vp), ('snap_a', _vp), ('snap', _vp),
+        ('snapU', _vp), ('snapV', _vp), ('snap_a', _vp), ('snap', _vp), ('row_slot', _vp),
         ('perm', _vp), ('lr', _vp), ('sse', _vp),
         ('N', _i32), ('n_user', _i32), ('n_item', _i32), ('d', _i32),
         ('batch', _i32), ('epochs', _i32),

@@ -183,7 +183,7 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
 
     // torch.optim.SGD single-tensor path: g = g + lam*w ; buf = mu*buf + g (buf = g on the
     // first step) ; w = w - lr*buf.   Writes buf and the step-(t+1) weights of one row slice.
-    auto sgd_update = [&](const Row &wr, const Row &mr, const Row &ar, float *mom_row, float *next_row) {
+    auto sgd_update = [&](const Row &wr, const Row &mr, const Row &ar, float *mom_row, float *next_row, float *snap_row) {
         Row gr, nr;
 #pragma unroll
         for (int i = 0; i < V4; ++i) {
@@ -202,6 +202,7 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
         }
         row_store<LPR, V4>(mom_row, sub, gr);
         row_store<LPR, V4>(next_row, sub, nr);
+        if (snap_row) row_store<LPR, V4>(snap_row, sub, nr);
     };
 
     // Workgroup ranges of a shard:
@@ -251,6 +252,11 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
     // the momentum row is requested together with the weights: its latency hides behind the scan and the gathers
     // instead of forming a memory level of its own in front of the update (bench: 12.6 -> 12.5 us per launch)
     if (owner && !first) m4 = row_load<LPR, V4>((is_user ? S.mU : S.mV) + row_off, sub);
+    // compact end-of-epoch snapshots written by the owners themselves (every active row is rewritten in every step, so the
+    // last step of an epoch writes them all): the row's place in the snapshot is requested here, with the row
+    const bool snap_here = S.snap != nullptr && S.row_slot != nullptr && s == steps - 1;
+    int snap_slot = -1;
+    if (snap_here && owner) snap_slot = ldg(S.row_slot + du.x);
     float sse = 0.f;
     URE_STAMP(2);     // unit descriptor and own row arrived
     if (!dense_only) {
@@ -359,7 +365,8 @@ __device__ __forceinline__ void mf_step(const ure_shard_t *__restrict__ shards, 
         }
     }
     if (owner) {
-        sgd_update(w, m4, acc, (is_user ? S.mU : S.mV) + row_off, (is_user ? S.U[cur ^ 1] : S.V[cur ^ 1]) + row_off);
+        sgd_update(w, m4, acc, (is_user ? S.mU : S.mV) + row_off, (is_user ? S.U[cur ^ 1] : S.V[cur ^ 1]) + row_off,
+                   snap_slot >= 0 ? S.snap + ((size_t)epoch * S.n_active + snap_slot) * D : nullptr);
         // train loss (utils.py:82): each user row adds its own squared errors to its own slot of
         // the epoch -- owner-only read-modify-write, so no atomics and a reproducible sum
         if (is_user && sub == 0 && sse != 0.f) {
@@ -398,6 +405,7 @@ __global__ __launch_bounds__(kBlock) void snapshot_kernel(const ure_shard_t *__r
     const unsigned long long *__restrict__ row_mask = nullptr;
     const bool compact = S.snap != nullptr;
     if (!compact && (!S.snapU || !S.snapV)) return;
+    if (compact && !S.touch_mode && S.row_slot) return;                 // written by the step kernel's owners
     const int steps = shard_steps(S);
     if (ticks_done > (int64_t)steps * S.epochs || ticks_done % steps != 0) return;   // only at an epoch end of this shard
     const int epoch = (int)(ticks_done / steps) - 1;
@@ -758,7 +766,8 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
             bool epoch_end = false;
             for (const ure_shard_t &S : job->host) {
                 const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
-                if ((S.snapU || S.snap) && t + 1 <= steps * S.epochs && (t + 1) % steps == 0) { epoch_end = true; break; }
+                const bool by_kernel = S.snapU || (S.snap && (S.touch_mode || !S.row_slot));      // otherwise the step kernel's owners wrote it
+                if (by_kernel && t + 1 <= steps * S.epochs && (t + 1) % steps == 0) { epoch_end = true; break; }
             }
             if (epoch_end)
                 hipLaunchKernelGGL(snapshot_kernel, dim3(job->snap_blocks, (unsigned)job->host.size()), dim3(kBlock), 0, st, job->dev, job->dev_aux, t + 1);

@@ -39,6 +39,22 @@ def mark(label):
         HOST_TRACE.append((label, time.perf_counter()))
 
 
+def to_device_async(arr, dev):
+    """A small host array -> device tensor without stalling the host: through a pooled pinned buffer and an asynchronous
+    copy (from pageable memory `.to(device)` waits until the stream has reached and finished the copy)."""
+    from . import rng
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    if torch.device(dev).type != 'cuda' or t.numel() == 0:
+        return t.to(dev)
+    stage = rng.SMALL.take(tuple(t.shape), t.dtype)
+    stage.numpy()[...] = t.numpy()                       # (a plain memcpy: torch's copy_ would go through its intra-op thread pool)
+    out = stage.to(dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    rng.SMALL.give(stage, ev)
+    return out
+
+
 def pad_dim(d):
     """Table width used on the device: next power of two >= max(d, 4).  Padding
     columns are zero at init; their gradient and decay keep them exactly zero."""
@@ -170,7 +186,7 @@ class ShardData:
             u = nv.build_units(self._sched_host, n_rows, d)
             if len(u) == 0:
                 u = np.zeros((1, 4), dtype=np.int32)[:0]
-            dev_u = torch.from_numpy(np.ascontiguousarray(u if len(u) else np.full((1, 4), -1, np.int32))).to(self.device)
+            dev_u = to_device_async(u if len(u) else np.full((1, 4), -1, np.int32), self.device)
             self._units[key] = (dev_u, len(u), n_rows)
         dev_u, n_units, n_rows = self._units[key]
         return (dev_u, n_units, n_rows) if touch else dev_u
@@ -239,7 +255,7 @@ class TrainJob:
         # end-of-epoch snapshots: 'compact' keeps the n_active rows with interactions only (every other row is a_e * w0 and is
         # rebuilt where it is read: ure_eval_series_compact; needs lazy_rows), True / 'full' keeps complete tables
         self.snapshots = ('compact' if self.lazy_rows else 'full') if snapshots == 'compact' else ('full' if snapshots else False)
-        self.lr = torch.from_numpy(lr_host).to(dev)
+        self.lr = to_device_async(lr_host, dev)
         self.state = []
         self._chunks = []        # per shard whose permutations are uploaded in chunks: [(first epoch after the chunk, event), ...]
         descs = (nv.UreShard * len(shards))()
@@ -290,13 +306,13 @@ class TrainJob:
             D.touch_mode = int(self.touch)
             if self.snapshots:
                 steps = (sh.N + self.batch - 1) // self.batch
-                snap_a = torch.from_numpy(closed_form_scalars(lr_host, steps, float(np.float32(lam)), float(np.float32(momentum)))).to(dev)
+                snap_a = to_device_async(closed_form_scalars(lr_host, steps, float(np.float32(lam)), float(np.float32(momentum))), dev)
                 self.state[-1].update(snap_a=snap_a)
                 D.snap_a = nv.ptr(snap_a)
                 if self.snapshots == 'compact':
                     snap = torch.empty(self.epochs, sh.n_active, self.d, dtype=torch.float32, device=dev)
                     self.state[-1].update(snap=snap)
-                    D.snap = nv.ptr(snap)
+                    D.snap, D.row_slot = nv.ptr(snap), nv.ptr(sh.row_slot())
                 else:
                     snapU = torch.empty(self.epochs, sh.n_user, self.d, dtype=torch.float32, device=dev)
                     snapV = torch.empty(self.epochs, sh.n_item, self.d, dtype=torch.float32, device=dev)
@@ -329,6 +345,11 @@ class TrainJob:
                 st = stream if stream is not None else torch.cuda.current_stream(self.device)
                 horizon = self.epochs
                 def wait(chunk):                                        # host: until the worker queued the upload; device: until it is done
+                    if HOST_TRACE is not None and not chunk[1].is_set():
+                        import time
+                        t0 = time.perf_counter()
+                        chunk[1].wait()
+                        self.chunk_wait_s = getattr(self, 'chunk_wait_s', 0.0) + time.perf_counter() - t0
                     chunk[1].wait()
                     if chunk[2][0] is None:
                         raise nv.NativeError('the permutation worker failed before this chunk was uploaded')
@@ -588,7 +609,7 @@ class EvalSet:
 
 def merge_rows(dst, src, rows, stream=None):
     """dst[rows] = src[rows] on the device (sisa.py:55-56)."""
-    rows = torch.as_tensor(np.asarray(rows, dtype=np.int64)).to(dst.device)
+    rows = to_device_async(np.asarray(rows, dtype=np.int64), dst.device)
     assert dst.is_contiguous() and src.is_contiguous() and dst.shape == src.shape
     nv.check(nv.lib().ure_merge_rows(nv.ptr(dst), nv.ptr(src), nv.ptr(rows), rows.numel(), dst.shape[1],
                                      nv.stream_handle(stream)), 'ure_merge_rows')

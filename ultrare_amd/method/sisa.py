@@ -234,7 +234,7 @@ class Sisa(Scratch):
             from .. import rng
             engine.mark('job_created')
             job.run()
-            engine.mark('launched')
+            engine.mark(f'launched (waited {getattr(job, "chunk_wait_s", 0.0) * 1e3:.2f} ms for permutation chunks)')
             for i in mine:
                 rng.release(prepared[i][2])                 # uploaded: host buffers go back to the pool
             for pos, i in enumerate(mine):
@@ -346,14 +346,13 @@ class Sisa(Scratch):
         assert len(train_dlist) == self.n_group
         assert len(test_dlist) == self.n_group
 
-        # find deletion (sisa.py:76-81)
-        member = [set(int(u) for u in g) for g in self.group_index]
-        retrain_gid = set()
-        for user in del_user:
-            for i in range(self.n_group):
-                if int(user) in member[i]:
-                    retrain_gid.add(i)
-                    break
+        # find deletion (sisa.py:76-81: the first group that lists the user)
+        first_group = np.full(max(self.n_user, 1 + max((int(max(g)) for g in self.group_index if len(g)), default=0)), -1, dtype=np.int64)
+        for i in reversed(range(self.n_group)):
+            first_group[np.asarray(self.group_index[i], dtype=np.int64)] = i
+        users = np.asarray(list(del_user), dtype=np.int64).reshape(-1)
+        users = users[(users >= 0) & (users < len(first_group))]
+        retrain_gid = set(int(g) for g in np.unique(first_group[users]) if g >= 0)
 
         model_before_unlearn = model_list[0]
         merged = model_before_unlearn.user_mat.weight.detach().clone().contiguous()

@@ -44,12 +44,29 @@ def host_cpus():
     return max(1, n // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1)))
 
 
+def limit_torch_threads():
+    """torch sizes its intra-op thread pool by the machine's CPU count and knows nothing of a container's CPU quota: on a
+    256-CPU host that grants this container 16, every CPU-side torch op (a normal_() fill, a copy) woke 256 OpenMP threads,
+    whose spinning used the cgroup's quota up and got the whole process throttled for the rest of the 100 ms period --
+    50-80 ms stalls in the middle of a 15 ms Sisa.learn (cpu.stat: 28 of 285 periods throttled; profiles/r03/NOTES.md).
+    The pool is capped at the CPUs this rank may really use (host_cpus()); URE_TORCH_THREADS=0 leaves torch alone,
+    URE_TORCH_THREADS=n sets n."""
+    import os
+    env = os.environ.get('URE_TORCH_THREADS', '')
+    if env == '0':
+        return torch.get_num_threads()
+    want = int(env) if env else min(torch.get_num_threads(), host_cpus())
+    if want >= 1 and want != torch.get_num_threads():
+        torch.set_num_threads(want)
+    return torch.get_num_threads()
+
+
 def perm_threads():
     """Host threads of the permutation expander per SISA call: URE_PERM_THREADS, else every CPU of the rank up to 64
     (250 Fisher-Yates permutations of 0.5 ms each are half of a 5-shard, 50-epoch call's wall time on 16 threads)."""
     import os
     env = os.environ.get('URE_PERM_THREADS')
-    return max(1, int(env)) if env else min(64, 2 * host_cpus())      # (2 x: measured best on a 16-CPU quota, 2.3 vs 3.0 ms per 250 permutations)
+    return max(1, int(env)) if env else min(64, host_cpus())
 
 
 def fill_draws(n):
@@ -150,7 +167,8 @@ class _HostPool:
     unmapping that much pageable memory per call costs more host time than the whole
     training costs device time, so buffers are kept and handed out again."""
 
-    def __init__(self):
+    def __init__(self, min_step=1 << 20):
+        self.min_step = min_step
         self.free = []          # [(buffer, event or None)]: a buffer whose last copy is still in flight is not handed out
         self.lent = {}
         self.lock = threading.Lock()
@@ -168,7 +186,7 @@ class _HostPool:
             # differ by a few rows -- another deletion set -- and must find the buffers of the previous request large enough;
             # allocating 36 MB of pinned memory costs more host time than expanding the permutations that go into it
             size = max(need, 1)
-            step = max(1 << 20, 1 << max(size.bit_length() - 4, 0))
+            step = max(self.min_step, 1 << max(size.bit_length() - 4, 0))
             size = (size + step - 1) // step * step
             buf = torch.empty(size, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
         view = buf[:need].view(dtype).view(shape)
@@ -185,6 +203,7 @@ class _HostPool:
 
 
 POOL = _HostPool()           # the epoch permutations
+SMALL = _HostPool(1 << 14)   # small descriptors on their way to the device (engine.to_device_async)
 STAGING = _HostPool()        # layout staging (engine.build_shards): its own pool, so that a 23 MB request never takes a 36 MB permutation buffer
 
 
