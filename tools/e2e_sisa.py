@@ -74,11 +74,14 @@ def measure(shards=5, k=32, epochs=50, parallel=1, delper=2.0, data=None, reps=3
     n_learn = len(data['train'][0]) * a.epochs
     n_un = int(keep.sum()) * a.epochs if len(s2.retrained) == a.shards else None
     nan_shards = int(sum(1 for m in s2.model_list if not bool(torch.isfinite(m.item_mat.weight).all())))
+    series = {k: np.asarray(v, dtype=np.float64) for k, v in sisa.log.items() if k != 'time'}
+    epoch_logs = {'entries_per_series': int(len(series['total_rmse'])), 'finite_fraction': {k: round(float(np.isfinite(v).mean()), 4) for k, v in series.items()},
+                  'first_epoch': {k: float(v[0]) for k, v in series.items() if len(v)}, 'last_epoch': {k: float(v[-1]) for k, v in series.items() if len(v)}}
     out.update(learn_s=round(t_learn, 4), unlearn_s=round(t_unlearn, 4), retrained_shards=len(s2.retrained), deleted_users=int(len(del_user)),
                deletion_set=f'RandomState({reps}).choice: a different 2 % in every repetition',
                layouts_built={'learn': built_learn, 'unlearn': built_unlearn},
                learn_interactions_per_s=round(n_learn / t_learn, 1), log0=sisa.log0, unlearn_log0=s2.log0,
-               unlearn_interactions=n_un, nan_shards=nan_shards)
+               unlearn_interactions=n_un, nan_shards=nan_shards, epoch_logs_learn=epoch_logs)
     return out
 
 

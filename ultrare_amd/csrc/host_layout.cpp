@@ -33,6 +33,7 @@
 
 namespace ure {
 int fail(int code, const char *fmt, ...);
+int host_threads();
 }
 
 namespace {
@@ -98,7 +99,7 @@ int ure_host_read_csv(const char *path, int32_t **uid, int32_t **iid, double **r
     const char *data = (const char *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (data == MAP_FAILED) return ure::fail(-1, "ure_host_read_csv: mmap failed for %s", path);
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int nt = n_threads > 0 ? n_threads : ure::host_threads();
     nt = std::max(1, std::min<int>(nt, (int)(size / (1 << 16)) + 1));
     std::vector<size_t> cut(nt + 1, size);
     cut[0] = 0;
@@ -267,7 +268,7 @@ int ure_host_build_layouts(int n_shards, const int64_t *const *uid, const int64_
         return ure::fail(-1, "ure_host_build_layouts: bad arguments");
     for (int s = 0; s < n_shards; ++s)
         if (!uid[s] || !iid[s] || !rating[s] || !region[s] || n[s] <= 0) return ure::fail(-1, "ure_host_build_layouts: shard %d: bad arguments", s);
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int nt = n_threads > 0 ? n_threads : ure::host_threads();
     nt = std::max(1, std::min(nt, n_shards));
     std::atomic<int> next{0}, rc{0};
     // (ure::fail keeps its message per thread: a worker's failure is re-reported on the calling thread below)

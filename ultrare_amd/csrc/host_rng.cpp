@@ -20,6 +20,7 @@
 
 namespace ure {
 int fail(int code, const char *fmt, ...);
+int host_threads();
 }
 
 namespace {
@@ -125,7 +126,7 @@ extern "C" int ure_host_randperm(const int64_t *seeds, int n_perms, int64_t n, i
     if (!seeds || !out || n_perms < 0 || n < 0) return ure::fail(-1, "ure_host_randperm: bad arguments");
     if (n >= (int64_t)(0xffffffffu / 20)) return ure::fail(-1, "ure_host_randperm: n=%lld uses ATen's large-n branch, not restated", (long long)n);
     if (n_perms == 0 || n == 0) return 0;
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int nt = n_threads > 0 ? n_threads : ure::host_threads();
     nt = nt < 1 ? 1 : (nt > n_perms ? n_perms : nt);
     std::atomic<int> next{0};
     auto work = [&]() {

@@ -41,6 +41,7 @@
 
 namespace ure {
 int fail(int code, const char *fmt, ...);
+int host_threads();
 }
 
 namespace {
@@ -65,7 +66,7 @@ constexpr int kMaxHostThreads = 64;      // (round 2 stopped at 16: on a 256-CPU
 template <typename F>
 static void parallel_ranges(int64_t n, int64_t grain, F &&body)
 {
-    int nt = (int)std::min<int64_t>(std::max(1u, std::min((unsigned)kMaxHostThreads, std::thread::hardware_concurrency())), (n + grain - 1) / grain);
+    int nt = (int)std::min<int64_t>(std::max(1u, std::min((unsigned)kMaxHostThreads, (unsigned)ure::host_threads())), (n + grain - 1) / grain);
     if (nt <= 1) { body(0, n, 0); return; }
     std::vector<std::thread> pool;
     for (int t = 0; t < nt; ++t) pool.emplace_back([&, t]() { body(n * t / nt, n * (t + 1) / nt, t); });

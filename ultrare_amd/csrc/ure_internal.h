@@ -24,6 +24,7 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 
 char *err_buf();                     // thread-local message buffer (1 KiB)
 int fail(int code, const char *fmt, ...);
+int host_threads();                 // CPUs this process may really use (affinity and the container's CPU quota)
 
 #define URE_HIP(call)                                                                         \
     do {                                                                                      \
