@@ -63,5 +63,7 @@ fi
 if has big; then
   # BASELINE.json configs[3] through the operator surface: per-epoch logs from compact snapshots (round 2: NaN beyond 8 GiB of full ones)
   timeout -k 10 900 python3 "$ROOT/tools/e2e_sisa.py" --workload ml25m --shards 32 --k 128 --epochs 5 --reps 1 > "$OUT/e2e_sisa_ml25m_s32_k128_e5.json" 2> "$OUT/e2e_sisa_ml25m.err"; echo "e2e ml25m rc=$?"
+  # the same at the reference's default width k = 16 (config.py:19), where the arithmetic stays finite
+  timeout -k 10 900 python3 "$ROOT/tools/e2e_sisa.py" --workload ml25m --shards 32 --k 16 --epochs 5 --reps 1 > "$OUT/e2e_sisa_ml25m_s32_k16_e5.json" 2>> "$OUT/e2e_sisa_ml25m.err"; echo "e2e ml25m k16 rc=$?"
 fi
 ls -la "$OUT"

@@ -54,22 +54,25 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
     table of such a shard is its exchanged own rows + the closed form of U0 elsewhere)."""
     from .. import rng
     prepared = {}
+    # the HBM layouts of the owned shards -- which training needs first -- are built at once on a worker: ONE native call for
+    # all of them, side by side on host threads into pinned staging, uploaded asynchronously, plus the work units of this
+    # table width (a layout a loader already holds is returned as it is)
+    layouts = None
+    own_ids = [i for pos, i in enumerate(ids) if owner[pos] == rank]
+    if on_device:
+        from ..read import shard_layouts
+        layouts = rng.worker_pool().submit(shard_layouts, [as_loader(train_dlist[i]) for i in own_ids], n_user, n_item, engine._device(), k)
     streams = rng.shard_streams(len(ids), n_user, n_item, k, epochs, True) if on_device else None
     if streams is not None:
-        # every shard's start state by skip-ahead, then each owned shard's draws (init, seeds, permutations, upload)
-        # on its own worker thread while this thread builds / fetches the HBM layouts
+        # every shard's start state by skip-ahead, then each owned shard's draws (init, seeds, permutations, upload) on its own
+        # worker thread.  The model inits start at once; the permutation expansion (36 ms of CPU time for a 5-shard, 50-epoch
+        # call) waits behind `gate` until the layouts are there, so that they get the cores first
+        import threading
         starts, end = streams
         torch.set_rng_state(end)
         mine = [pos for pos in range(len(ids)) if owner[pos] == rank]
         per_call = max(2, PERM_THREADS // max(len(mine), 1))
-        # every owned shard's model init starts on its worker at once; the permutation expansion (36 ms of CPU time for a
-        # 5-shard, 50-epoch call) waits behind `gate` until the HBM layouts -- which training needs first -- are built:
-        # one native call for all of them, side by side on host threads into pinned staging, uploaded asynchronously
-        # (a layout a loader already holds is returned as it is)
-        import threading
-        from ..read import shard_layouts
         gate = threading.Event()
-        own_ids = [i for pos, i in enumerate(ids) if owner[pos] == rank]
         futures = {}
         try:
             for pos, i in enumerate(ids):
@@ -79,7 +82,7 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
                                                        threads=per_call, device=engine._device(), gate=gate)
                 elif foreign_u0 is not None:
                     futures[i] = rng.shard_draws_async(starts[pos], n_user, n_item, k, epochs, True, 0, False, want_perms=False)
-            shards = dict(zip(own_ids, shard_layouts([as_loader(train_dlist[i]) for i in own_ids], n_user, n_item, engine._device())))
+            shards = dict(zip(own_ids, layouts.result()))
         finally:
             gate.set()
         engine.mark('layouts')
@@ -92,6 +95,8 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
                 foreign_u0[i] = futures[i].init()[0]
         engine.mark('inits')
         return prepared
+    if layouts is not None:
+        layouts.result()                # (tables too small to skip ahead in the stream: the draws below run one after the other)
     for pos, i in enumerate(ids):
         if owner[pos] == rank:
             if on_device:

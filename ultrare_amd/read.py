@@ -140,23 +140,25 @@ class ShardLoader:
         return self._cache['eval']
 
 
-def shard_layouts(loaders, n_user, n_item, device=None):
+def shard_layouts(loaders, n_user, n_item, device=None, units_for=None):
     """The HBM layouts of several shards' loaders; the missing ones are built together (engine.build_shards: one native
     call for all of them) and kept on their loaders.  device: required when called from a worker thread, whose current HIP
-    device is not the caller's."""
-    from .engine import build_shards
+    device is not the caller's.  units_for: a table width k whose work units are prepared right away as well."""
+    import contextlib
+    from .engine import build_shards, pad_dim
     key = ('train', n_user, n_item)
     todo = [l for l in loaders if key not in l._cache]
-    if todo:
-        raw = [(l.dataset.users, l.dataset.items, l.dataset.ratings) for l in todo]
-        if device is not None and torch.device(device).type == 'cuda':
-            with torch.cuda.device(device):
-                built = build_shards(raw, n_user, n_item, device)
-        else:
-            built = build_shards(raw, n_user, n_item, device)
-        for l, sh in zip(todo, built):
-            l._cache[key] = sh
-    return [l._cache[key] for l in loaders]
+    on = torch.cuda.device(device) if device is not None and torch.device(device).type == 'cuda' else contextlib.nullcontext()
+    with on:
+        if todo:
+            raw = [(l.dataset.users, l.dataset.items, l.dataset.ratings) for l in todo]
+            for l, sh in zip(todo, build_shards(raw, n_user, n_item, device)):
+                l._cache[key] = sh
+        out = [l._cache[key] for l in loaders]
+        if units_for is not None:
+            for sh in out:
+                sh.units(pad_dim(int(units_for)))
+    return out
 
 
 def as_loader(obj):
