@@ -272,6 +272,18 @@ int ure_eval_series_compact(const float *const *U_fixed, const float *const *V_f
                             const int32_t *off, int32_t n_users, const double *log2_tab, float *base, float *pred, double *sse,
                             int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide, void *stream);
 
+/* The same series in two halves, so that the first can run beside training.  ure_score_own_compact: own[e][j] = the score of
+ * pair j under the shard's own model after epoch e alone, for n_series consecutive epochs whose compact snapshots exist (snap,
+ * snap_a and own point at the first of them) -- queued by the host on a second stream as training proceeds.
+ * ure_eval_series_own: the rest, once the fixed models are final -- pred = (sum of the fixed models' scores + own) / (n_fixed + 1)
+ * with the additions in ure_eval_series' order, ranking, metrics.  Results are identical to ure_eval_series_compact.    */
+int ure_score_own_compact(const float *snap, int64_t stride, const int32_t *row_slot, const float *U0, const float *V0, const float *snap_a,
+                          int32_t n_user_rows, int n_series, const int32_t *uid, const int32_t *iid, int64_t n, int d, float *own, void *stream);
+int ure_eval_series_own(const float *const *U_fixed, const float *const *V_fixed, int n_fixed, const float *own, int n_series, const int32_t *uid,
+                        const int32_t *iid, const float *rating, int64_t n, int d, const int32_t *off, int32_t n_users, const double *log2_tab,
+                        float *base, float *pred, double *sse, int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide,
+                        void *stream);
+
 /* sisa.py:55-56,110-111: dst[rows[t]][:] = src[rows[t]][:]. */
 int ure_merge_rows(float *dst, const float *src, const int64_t *rows, int64_t n_rows, int d, void *stream);
 

@@ -372,3 +372,35 @@ def test_compact_snapshots_need_lazy_rows(toy):
     U, V = job.padded_tables(0)
     assert torch.equal(job.snapshot(0, 1)[0], U) and torch.equal(job.snapshot(0, 1)[1], V)
     job.close()
+
+
+def test_early_own_scores_give_the_same_series(toy):
+    """The two-halves form of a series (TrainJob.early_scores: the shard's own scores on a second stream while training runs,
+    finish_series: fixed models + ranking afterwards) against evaluate_series on the same compact snapshots: identical, with and
+    without fixed models, for shards whose epochs end on different ticks, in both kernels."""
+    from ultrare_amd import engine, rng
+    from oracle import cpu_ref as O
+    train, test = toy
+    S, k, E, B = 3, 16, 11, 900
+    parts = O.partition(*train, O.uniform_groups(N_USER, S))
+    tests = O.partition(*test, O.uniform_groups(N_USER, S))
+    torch.manual_seed(4)
+    inits = [rng.mf_init(N_USER, N_ITEM, k) for _ in parts]
+    perms = [rng.epoch_perms(rng.epoch_seeds(E, True), len(p[0])) for p in parts]
+    shards = [engine.ShardData(*p, N_USER, N_ITEM) for p in parts]
+    total = engine.EvalSet(*test)
+    own_sets = [engine.EvalSet(*t) for t in tests]
+    fixed = [tuple(torch.randn(n, engine.pad_dim(k), device=total.device) * 0.3 for n in (N_USER, N_ITEM)) for _ in range(2)]
+    for touch in (False, True):
+        job = engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, snapshots='compact', touch=touch)
+        handles = [(job.early_scores(s, own_sets[s]), job.early_scores(s, total)) for s in range(S)]
+        assert all(h is not None for pair in handles for h in pair)
+        job.run()
+        for s in range(S):
+            for before in ([], fixed):
+                for h, ev in zip(handles[s], (own_sets[s], total)):
+                    got = job.finish_series(h, before, torch.zeros(E, 3, dtype=torch.float64, device=total.device))
+                    want = job.evaluate_series(s, ev, before, torch.zeros(E, 3, dtype=torch.float64, device=total.device))
+                    torch.cuda.synchronize()
+                    assert torch.isfinite(want).all() and torch.equal(got, want), (touch, s, len(before))
+        job.close()

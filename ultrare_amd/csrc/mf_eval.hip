@@ -206,6 +206,83 @@ __global__ __launch_bounds__(kBlock) void score_series_compact_kernel(const floa
     for (int t = gridDim.x + threadIdx.x; blockIdx.x == 0 && t < URE_SCORE_PARTIALS; t += kBlock) sse[t] = 0.0;
 }
 
+// The shard's OWN half of a series, ahead of the rest: own[e][j] = <row_e(uid[j]), row_e(n_user_rows + iid[j])> from compact snapshots,
+// for the epochs whose snapshots exist already -- queued on a second stream while training continues.  The other half needs the
+// final models of the shards trained before this one (scratch.py:83-86) and follows in series_combine_kernel.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void score_own_compact_kernel(const float *__restrict__ snap, int64_t stride, const int32_t *__restrict__ row_slot,
+                                                                    const float *__restrict__ U0, const float *__restrict__ V0,
+                                                                    const float *__restrict__ snap_a, int n_user_rows,
+                                                                    const int32_t *__restrict__ uid, const int32_t *__restrict__ iid, int64_t n,
+                                                                    float *__restrict__ own)
+{
+    constexpr int D = LPR * 4;
+    constexpr int G = kWave / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (LPR - 1), grp = lane / LPR;
+    const int64_t wave_id = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+    snap += (size_t)blockIdx.y * stride;
+    const float a_e = snap_a[blockIdx.y];
+    own += (size_t)blockIdx.y * n;
+    for (int64_t j0 = wave_id * G; j0 < n; j0 += n_waves * G) {
+        const int64_t j = j0 + grp;
+        const bool act = j < n;
+        const int u = act ? uid[j] : 0, i = act ? iid[j] : 0;
+        const int su = row_slot[u], si = row_slot[n_user_rows + i];
+        float4 a = *reinterpret_cast<const float4 *>((su >= 0 ? snap + (size_t)su * D : U0 + (size_t)u * D) + sub * 4);
+        float4 b = *reinterpret_cast<const float4 *>((si >= 0 ? snap + (size_t)si * D : V0 + (size_t)i * D) + sub * 4);
+        if (su < 0) a = make_float4(a_e * a.x, a_e * a.y, a_e * a.z, a_e * a.w);
+        if (si < 0) b = make_float4(a_e * b.x, a_e * b.y, a_e * b.z, a_e * b.w);
+        float p = a.x * b.x;
+        p = fmaf(a.y, b.y, p);
+        p = fmaf(a.z, b.z, p);
+        p = fmaf(a.w, b.w, p);
+        p = group_sum<LPR>(p);
+        if (act && sub == 0) own[j] = p;
+    }
+}
+
+// pred[e][j] = (base[j] + own[e][j]) / n_total and the squared-error partials of member e: the additions, the division AND the
+// order in which score_series_compact_kernel sums the squared errors (same grid, one lane per lane group of that kernel works),
+// so that both forms of a series agree to the last bit.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void series_combine_kernel(const float *__restrict__ own, int n_total, const float *__restrict__ rating, int64_t n,
+                                                                const float *__restrict__ base, float *__restrict__ pred, double *__restrict__ sse)
+{
+    constexpr int G = kWave / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (LPR - 1), grp = lane / LPR;
+    const int64_t wave_id = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+    own += (size_t)blockIdx.y * n;
+    pred += (size_t)blockIdx.y * n;
+    sse += (size_t)blockIdx.y * URE_SCORE_PARTIALS;
+    float sq = 0.f;
+    for (int64_t j0 = wave_id * G; j0 < n; j0 += n_waves * G) {
+        const int64_t j = j0 + grp;
+        if (j < n && sub == 0) {
+            float acc = base ? base[j] : 0.f;
+            acc += own[j];
+            acc = acc / (float)n_total;
+            const float e = acc - rating[j];
+            sq = fmaf(e, e, sq);
+            pred[j] = acc;
+        }
+    }
+    __shared__ float part[kWavesPerBlock];
+    sq = wave_sum(sq);
+    if (lane == 0) part[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < kWavesPerBlock; ++k) t += (double)part[k];
+        sse[blockIdx.x] = t;
+    }
+    for (int t = gridDim.x + threadIdx.x; blockIdx.x == 0 && t < URE_SCORE_PARTIALS; t += kBlock) sse[t] = 0.0;
+}
+
 // (value, position) keys ordered lexicographically; "better" = later in a stable
 // ascending argsort, i.e. earlier in its reverse (utils.py:169-170).
 __device__ __forceinline__ bool key_gt(float v, int i, float bv, int bi) { return v > bv || (v == bv && i > bi); }
@@ -684,6 +761,76 @@ int ure_eval_series_compact(const float *const *U_fixed, const float *const *V_f
         default: return fail(-1, "ure_eval_series_compact: unsupported d=%d", d);
     }
 #undef URE_SERIES_COMPACT
+    if (n_users > 0)
+        hipLaunchKernelGGL(eval_users_kernel, dim3(eval_user_blocks(n_users, n_wide), (unsigned)n_series), dim3(kBlock), 0, st, off, n_users, n_wide,
+                           pred, rating, top_rating, log2_tab, hits, ndcg, n);
+    hipLaunchKernelGGL(eval_reduce_kernel, dim3((unsigned)n_series), dim3(1024), 0, st, hits, ndcg, n_users, sse, n, out);
+    URE_HIP(hipGetLastError());
+    return 0;
+}
+
+int ure_score_own_compact(const float *snap, int64_t stride, const int32_t *row_slot, const float *U0, const float *V0, const float *snap_a,
+                          int32_t n_user_rows, int n_series, const int32_t *uid, const int32_t *iid, int64_t n, int d, float *own, void *stream)
+{
+    URE_ARG(snap && row_slot && U0 && V0 && snap_a && n_user_rows > 0 && stride >= 0 && n_series > 0 && n_series <= 65535);
+    URE_ARG(uid && iid && own && n > 0 && pow2(d) && d >= 4 && d <= 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define URE_OWN(L)                                                                                                                      \
+    do {                                                                                                                                \
+        constexpr int G = kWave / L;                                                                                                    \
+        const int64_t waves = (n + G - 1) / G;                                                                                          \
+        const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, URE_SCORE_PARTIALS)); \
+        hipLaunchKernelGGL(score_own_compact_kernel<L>, dim3(blocks, (unsigned)n_series), dim3(kBlock), 0, st, snap, stride, row_slot, U0, V0, snap_a,   \
+                           n_user_rows, uid, iid, n, own);                                                                              \
+    } while (0)
+    switch (d / 4) {
+        case 1: URE_OWN(1); break;
+        case 2: URE_OWN(2); break;
+        case 4: URE_OWN(4); break;
+        case 8: URE_OWN(8); break;
+        case 16: URE_OWN(16); break;
+        case 32: URE_OWN(32); break;
+        case 64: URE_OWN(64); break;
+        default: return fail(-1, "ure_score_own_compact: unsupported d=%d", d);
+    }
+#undef URE_OWN
+    URE_HIP(hipGetLastError());
+    return 0;
+}
+
+int ure_eval_series_own(const float *const *U_fixed, const float *const *V_fixed, int n_fixed, const float *own, int n_series, const int32_t *uid,
+                        const int32_t *iid, const float *rating, int64_t n, int d, const int32_t *off, int32_t n_users, const double *log2_tab,
+                        float *base, float *pred, double *sse, int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide,
+                        void *stream)
+{
+    URE_ARG(n_wide >= 0 && n_wide <= n_users);
+    URE_ARG(n_fixed >= 0 && (n_fixed == 0 || (U_fixed && V_fixed && base)) && own && n_series > 0 && n_series <= 65535);
+    URE_ARG(uid && iid && rating && n > 0 && pow2(d) && d >= 4 && d <= 256 && off && n_users >= 0 && log2_tab && pred && sse && hits &&
+            ndcg && out);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int c0 = 0; c0 < n_fixed; c0 += URE_MAX_MODELS_PER_CALL) {
+        const int c = std::min(n_fixed - c0, URE_MAX_MODELS_PER_CALL);
+        if (int rc = ure_score(U_fixed + c0, V_fixed + c0, c, n_fixed + 1, c0 == 0, 0, uid, iid, rating, n, d, base, nullptr, stream)) return rc;
+    }
+#define URE_COMBINE(L)                                                                                                                  \
+    do {                                                                                                                                \
+        constexpr int G = kWave / L;                                                                                                    \
+        const int64_t waves = (n + G - 1) / G;                                                                                          \
+        const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, URE_SCORE_PARTIALS)); \
+        hipLaunchKernelGGL(series_combine_kernel<L>, dim3(blocks, (unsigned)n_series), dim3(kBlock), 0, st, own, n_fixed + 1, rating, n,              \
+                           n_fixed ? base : nullptr, pred, sse);                                                                        \
+    } while (0)
+    switch (d / 4) {
+        case 1: URE_COMBINE(1); break;
+        case 2: URE_COMBINE(2); break;
+        case 4: URE_COMBINE(4); break;
+        case 8: URE_COMBINE(8); break;
+        case 16: URE_COMBINE(16); break;
+        case 32: URE_COMBINE(32); break;
+        case 64: URE_COMBINE(64); break;
+        default: return fail(-1, "ure_eval_series_own: unsupported d=%d", d);
+    }
+#undef URE_COMBINE
     if (n_users > 0)
         hipLaunchKernelGGL(eval_users_kernel, dim3(eval_user_blocks(n_users, n_wide), (unsigned)n_series), dim3(kBlock), 0, st, off, n_users, n_wide,
                            pred, rating, top_rating, log2_tab, hits, ndcg, n);

@@ -26,6 +26,7 @@ SCORE_PARTIALS = 2048     # URE_SCORE_PARTIALS of the C ABI
 SERIES_SCRATCH_BYTES = 256 << 20     # prediction scratch of one ure_eval_series call
 LAZY_ROWS = os.environ.get('URE_LAZY_ROWS', '1') != '0'
 TOUCH_MAX_STEPS = 32000              # kTouchMaxSteps of csrc/mf_touch.h (epochs longer than 64 steps run in windows of 64)
+EARLY_SCORE_EPOCHS = 8               # TrainJob.early_scores: epochs per batch handed to the second stream
 TOUCH_MIN_TABLE_BYTES = 256 << 20    # auto rule: the job's live rows (w, m, second buffer) exceed the Infinity Cache
 
 
@@ -259,6 +260,7 @@ class TrainJob:
         self.state = []
         self._chunks = []        # per shard whose permutations are uploaded in chunks: [(first epoch after the chunk, event), ...]
         descs = (nv.UreShard * len(shards))()
+        mark('job: start')
         for sh in shards:
             if sh.ready is not None:
                 torch.cuda.current_stream(dev).wait_event(sh.ready)
@@ -324,7 +326,9 @@ class TrainJob:
                 D.U0, D.V0, D.lr_host, D.lazy_rows = nv.ptr(U0d), nv.ptr(V0d), lr_host.ctypes.data, 1
         self._descs = descs
         self._job = ctypes.c_void_p()
+        mark('job: tables allocated, descriptors filled')
         nv.check(nv.lib().ure_job_create(descs, len(shards), ctypes.byref(self._job)), 'ure_job_create')
+        mark('job: ure_job_create')
         self.ticks = int(nv.lib().ure_job_ticks(self._job))
         self.shard_steps = [int(nv.lib().ure_job_shard_steps(self._job, s)) for s in range(len(shards))]
         self.done = 0
@@ -337,6 +341,9 @@ class TrainJob:
         t1 = self.ticks if n_ticks is None else min(self.ticks, self.done + int(n_ticks))
         while t1 > self.done:
             t_next = t1
+            if getattr(self, '_early', None):
+                # early own scores (early_scores): hand the second stream a batch of finished epochs every few epochs
+                t_next = min(t1, self.done + EARLY_SCORE_EPOCHS * max(self.steps_per_epoch(s) for s in range(len(self.shards))))
             if self._chunks:
                 # the launches of tick t read the permutation of the epoch AFTER the one a shard is in (the batch tags are
                 # prepared one epoch ahead): wait for the chunk that holds it, and launch only up to where the next one is needed
@@ -364,9 +371,11 @@ class TrainJob:
                             ch.pop(0)
                 self._chunks = [ch for ch in self._chunks if ch]
                 if horizon < self.epochs:
-                    t_next = min(t1, max(self.done + 1, (horizon - 1) * min_steps))
+                    t_next = min(t_next, max(self.done + 1, (horizon - 1) * min_steps))
             nv.check(nv.lib().ure_job_train(self._job, self.done, t_next, nv.stream_handle(stream)), 'ure_job_train')
             self.done = t_next
+            if getattr(self, '_early', None):
+                self._score_finished_epochs(stream)
         return self.done
 
     def run_profiled(self, n_ticks, stream=None):
@@ -401,6 +410,52 @@ class TrainJob:
         """All end-of-epoch tables of shard s: (U [epochs, n_user, d], V [epochs, n_item, d]) (full snapshots)."""
         st = self.state[s]
         return st['snapU'], st['snapV']
+
+    # ---- the own half of a series beside training (ure_score_own_compact / ure_eval_series_own)
+    def early_scores(self, s, eval_set):
+        """Register shard s's per-epoch series on `eval_set` for early scoring: as run() proceeds, the scores of the shard's own
+        model after every finished epoch are computed on a second stream from the compact snapshots (the half of a series that
+        does not depend on other shards); finish_series() adds the fixed models and ranks.  Call before run().  -> handle, or
+        None when the job keeps no compact snapshots (evaluate_series then does everything afterwards)."""
+        if self.snapshots != 'compact' or eval_set.n == 0 or self.done != 0:
+            return None
+        if not hasattr(self, '_early'):
+            self._early = []
+            self._side = torch.cuda.Stream(self.device)
+        own = torch.empty(self.epochs, eval_set.n, dtype=torch.float32, device=self.device)
+        own.record_stream(self._side)
+        h = {'s': s, 'ev': eval_set, 'own': own, 'scored': 0, 'event': None}
+        self._early.append(h)
+        return h
+
+    def _score_finished_epochs(self, stream=None):
+        main = stream if stream is not None else torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._side.wait_event(ready)
+        L, st = nv.lib(), nv.stream_handle(self._side)
+        for h in self._early:
+            s, ev = h['s'], h['ev']
+            e_done = min(self.epochs, self.done // self.steps_per_epoch(s))
+            e0 = h['scored']
+            if e_done <= e0:
+                continue
+            state, sh = self.state[s], self.shards[s]
+            snap = state['snap']
+            nv.check(L.ure_score_own_compact(nv.ptr(snap[e0]), snap.stride(0), nv.ptr(sh.row_slot()), nv.ptr(state['U0']), nv.ptr(state['V0']),
+                                             nv.ptr(state['snap_a'][e0:]), sh.n_user, e_done - e0, nv.ptr(ev.uid), nv.ptr(ev.iid), ev.n, self.d,
+                                             nv.ptr(h['own'][e0]), st), 'ure_score_own_compact')
+            h['scored'] = e_done
+            h['event'] = torch.cuda.Event()
+            h['event'].record(self._side)
+
+    def finish_series(self, h, fixed, out, stream=None):
+        """The rest of a series registered with early_scores(): out [epochs, 3] (device float64) = (rmse, ndcg, hr) of every epoch's
+        ensemble `fixed` + the shard's model of that epoch.  Identical to evaluate_series()."""
+        assert h['scored'] == self.epochs, 'finish_series: the job has not run to its end'
+        main = stream if stream is not None else torch.cuda.current_stream(self.device)
+        main.wait_event(h['event'])
+        return h['ev'].evaluate_series_own(fixed, h['own'], self.d, out, stream)
 
     def evaluate_series(self, s, eval_set, fixed, out, stream=None):
         """scratch.py:83-97 for every epoch of shard s on `eval_set`: member e = the ensemble `fixed` + the shard's model
@@ -598,6 +653,24 @@ class EvalSet:
                                                self.n, d, nv.ptr(self.off), self.n_users, nv.ptr(self.log2), nv.ptr(b['base']), nv.ptr(b['pred']),
                                                nv.ptr(b['sse']), nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating),
                                                self.n_wide, st), 'ure_eval_series_compact')
+        return out
+
+    def evaluate_series_own(self, fixed, own, d, out, stream=None):
+        """The second half of a series whose own scores own [E, n] exist (ure_eval_series_own)."""
+        E = int(own.shape[0])
+        assert out.shape == (E, 3) and out.dtype == torch.float64 and out.is_contiguous() and own.is_contiguous() and own.shape[1] == self.n
+        L, st = nv.lib(), nv.stream_handle(stream)
+        b, per_call = self._series_buffers(E)
+        for U, V in fixed:
+            assert U.is_contiguous() and V.is_contiguous() and U.shape[1] == d and V.shape[1] == d
+        Up = (ctypes.c_void_p * max(len(fixed), 1))(*[U.data_ptr() for U, _ in fixed])
+        Vp = (ctypes.c_void_p * max(len(fixed), 1))(*[V.data_ptr() for _, V in fixed])
+        for e0 in range(0, E, per_call):
+            m = min(per_call, E - e0)
+            nv.check(L.ure_eval_series_own(Up, Vp, len(fixed), nv.ptr(own[e0]), m, nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating), self.n, d,
+                                           nv.ptr(self.off), self.n_users, nv.ptr(self.log2), nv.ptr(b['base']), nv.ptr(b['pred']), nv.ptr(b['sse']),
+                                           nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating), self.n_wide, st),
+                     'ure_eval_series_own')
         return out
 
     def predictions(self):

@@ -116,10 +116,16 @@ class Scratch(object):
         res = torch.zeros(self.epochs, 2, 3, dtype=torch.float64, device=shard.device) if queued else None
         times = []
         if series:
+            sets = (test_ev, total_ev if has_total else test_ev)
+            # URE_EARLY_SCORES=1: the shard's own half of both series beside training (engine.TrainJob.early_scores; off by default)
+            early = [job.early_scores(0, ev) if os.environ.get('URE_EARLY_SCORES', '0') == '1' else None for ev in sets]
             job.run()
             res = torch.zeros(2, self.epochs, 3, dtype=torch.float64, device=shard.device)
-            job.evaluate_series(0, test_ev, before, res[0])
-            job.evaluate_series(0, total_ev if has_total else test_ev, before, res[1])
+            for which, ev in enumerate(sets):
+                if early[which] is not None:
+                    job.finish_series(early[which], before, res[which])
+                else:
+                    job.evaluate_series(0, ev, before, res[which])
             res = res.transpose(0, 1).contiguous()
             times = ['00:00:00'] * self.epochs
         for t in range(0 if not series else self.epochs, self.epochs):
