@@ -56,6 +56,34 @@ def to_device_async(arr, dev):
     return out
 
 
+def upload_many(arrays, dev):
+    """Several small host arrays -> device tensors through ONE pinned staging buffer and ONE asynchronous copy (each array
+    starts on a 64-byte boundary of one device allocation).  A request of 16 shards sends ~50 such descriptors (work units,
+    row lists, schedules of scalars): one by one they cost 0.1-0.2 ms of host time each."""
+    from . import rng
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    if torch.device(dev).type != 'cuda':
+        return [torch.from_numpy(a.copy()).to(dev) for a in arrays]
+    offs, at = [], 0
+    for a in arrays:
+        offs.append(at)
+        at += (a.nbytes + 63) // 64 * 64
+    if at == 0:
+        return [torch.from_numpy(a.copy()).to(dev) for a in arrays]
+    stage = rng.SMALL.take((at,), torch.uint8)
+    host = stage.numpy()
+    for a, o in zip(arrays, offs):
+        host[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+    blob = stage.to(dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    rng.SMALL.give(stage, ev)
+    out = []
+    for a, o in zip(arrays, offs):
+        out.append(blob[o:o + a.nbytes].view(torch.from_numpy(np.empty(0, dtype=a.dtype)).dtype).view(a.shape))
+    return out
+
+
 def pad_dim(d):
     """Table width used on the device: next power of two >= max(d, 4).  Padding
     columns are zero at init; their gradient and decay keep them exactly zero."""
@@ -178,19 +206,21 @@ class ShardData:
         compaction of the rows that are trained in it (csrc/mf_touch.h)."""
         key = (d, bool(touch))
         if key not in self._units:
-            n_rows = self.n_active
-            if touch:
-                lanes = d // 4 if d <= 32 else d // 8
-                seg = self._sched_host[:self.n_active, 2] - self._sched_host[:self.n_active, 1]
-                n_rows = int(np.count_nonzero(seg > 8 * lanes))
-                assert n_rows == 0 or (seg[:n_rows] > 8 * lanes).all()          # the schedule is heaviest first
-            u = nv.build_units(self._sched_host, n_rows, d)
-            if len(u) == 0:
-                u = np.zeros((1, 4), dtype=np.int32)[:0]
-            dev_u = to_device_async(u if len(u) else np.full((1, 4), -1, np.int32), self.device)
-            self._units[key] = (dev_u, len(u), n_rows)
+            u, n_units, n_rows = self.units_host(d, touch)
+            self._units[key] = (to_device_async(u, self.device), n_units, n_rows)
         dev_u, n_units, n_rows = self._units[key]
         return (dev_u, n_units, n_rows) if touch else dev_u
+
+    def units_host(self, d, touch=False):
+        """The host half of units(): -> (int32 [max(n_units, 1), 4] array to upload, n_units, rows covered)."""
+        n_rows = self.n_active
+        if touch:
+            lanes = d // 4 if d <= 32 else d // 8
+            seg = self._sched_host[:self.n_active, 2] - self._sched_host[:self.n_active, 1]
+            n_rows = int(np.count_nonzero(seg > 8 * lanes))
+            assert n_rows == 0 or (seg[:n_rows] > 8 * lanes).all()          # the schedule is heaviest first
+        u = nv.build_units(self._sched_host, n_rows, d)
+        return (u if len(u) else np.full((1, 4), -1, np.int32)), len(u), n_rows
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in
@@ -256,7 +286,10 @@ class TrainJob:
         # end-of-epoch snapshots: 'compact' keeps the n_active rows with interactions only (every other row is a_e * w0 and is
         # rebuilt where it is read: ure_eval_series_compact; needs lazy_rows), True / 'full' keeps complete tables
         self.snapshots = ('compact' if self.lazy_rows else 'full') if snapshots == 'compact' else ('full' if snapshots else False)
-        self.lr = to_device_async(lr_host, dev)
+        steps_of = [(sh.N + self.batch - 1) // self.batch for sh in shards]
+        small = [lr_host] + ([closed_form_scalars(lr_host, st_, float(np.float32(lam)), float(np.float32(momentum))) for st_ in steps_of] if self.snapshots else [])
+        small = upload_many(small, dev)                  # the learning rates and every shard's closed-form scalars: one copy
+        self.lr = small[0]
         self.state = []
         self._chunks = []        # per shard whose permutations are uploaded in chunks: [(first epoch after the chunk, event), ...]
         descs = (nv.UreShard * len(shards))()
@@ -264,6 +297,16 @@ class TrainJob:
         for sh in shards:
             if sh.ready is not None:
                 torch.cuda.current_stream(dev).wait_event(sh.ready)
+        # every float table of every shard from ONE zero-filled allocation (a request of 16 shards made ~130 small allocations
+        # and fills here: 8-12 ms of host time beside 16 busy worker threads), the snapshots from another
+        al = lambda x: (x + 63) // 64 * 64
+        d = self.d
+        sizes = [(2 * sh.n_user * d, 2 * sh.n_item * d, sh.n_user * d, sh.n_item * d, self.epochs * sh.n_user,
+                  sh.n_user * d if self.lazy_rows else 0, sh.n_item * d if self.lazy_rows else 0) for sh in shards]
+        pool = torch.zeros(sum(al(x) for sz in sizes for x in sz), dtype=torch.float32, device=dev)
+        snap_rows = [(sh.n_active if self.snapshots == 'compact' else sh.n_user + sh.n_item) if self.snapshots else 0 for sh in shards]
+        snap_pool = torch.empty(sum(al(self.epochs * r * d) for r in snap_rows), dtype=torch.float32, device=dev) if self.snapshots else None
+        at = snap_at = 0
         for s, (sh, (U0, V0), perm) in enumerate(zip(shards, inits, perms)):
             for t in (U0, V0):
                 if getattr(t, '_ure_event', None) is not None:          # uploaded on a side stream (rng.shard_draws_async)
@@ -272,13 +315,15 @@ class TrainJob:
             U0 = torch.as_tensor(U0, dtype=torch.float32)
             V0 = torch.as_tensor(V0, dtype=torch.float32)
             assert U0.shape == (sh.n_user, self.k) and V0.shape == (sh.n_item, self.k)
-            U = torch.zeros(2, sh.n_user, self.d, dtype=torch.float32, device=dev)
-            V = torch.zeros(2, sh.n_item, self.d, dtype=torch.float32, device=dev)
-            U[0, :, :self.k] = U0.to(dev)
+            views = []
+            for x in sizes[s]:
+                views.append(pool[at:at + x])
+                at += al(x)
+            U, V = views[0].view(2, sh.n_user, d), views[1].view(2, sh.n_item, d)
+            mU, mV = views[2].view(sh.n_user, d), views[3].view(sh.n_item, d)
+            U[0, :, :self.k] = U0.to(dev, non_blocking=True)
+            V[0, :, :self.k] = V0.to(dev, non_blocking=True)
             U0d, V0d = None, None
-            V[0, :, :self.k] = V0.to(dev)
-            mU = torch.zeros(sh.n_user, self.d, dtype=torch.float32, device=dev)
-            mV = torch.zeros(sh.n_item, self.d, dtype=torch.float32, device=dev)
             perm = torch.as_tensor(perm)
             if getattr(perm, '_ure_chunks', None) is not None:      # still arriving in chunks of epochs (rng.shard_draws_async)
                 self._chunks.append(list(perm._ure_chunks))
@@ -286,7 +331,7 @@ class TrainJob:
                 torch.cuda.current_stream(dev).wait_event(perm._ure_event)
             assert perm.shape == (self.epochs, sh.N), f'perm of shard {s} must be [epochs, N]'
             perm = perm.to(device=dev, dtype=torch.int32).contiguous()
-            sse = torch.zeros(self.epochs, sh.n_user, dtype=torch.float32, device=dev)
+            sse = views[4].view(self.epochs, sh.n_user)
             self.state.append({'U': U, 'V': V, 'mU': mU, 'mV': mV, 'perm': perm, 'sse': sse})
             D = descs[s]
             for name in ('ent_oid', 'ent_r', 'ent_tag', 'ent_src', 'file_tag', 'inv_stage', 'inv_off', 'sched'):
@@ -307,21 +352,24 @@ class TrainJob:
             D.lam, D.mu = float(lam), float(momentum)
             D.touch_mode = int(self.touch)
             if self.snapshots:
-                steps = (sh.N + self.batch - 1) // self.batch
-                snap_a = to_device_async(closed_form_scalars(lr_host, steps, float(np.float32(lam)), float(np.float32(momentum))), dev)
+                snap_a = small[1 + s]
                 self.state[-1].update(snap_a=snap_a)
                 D.snap_a = nv.ptr(snap_a)
                 if self.snapshots == 'compact':
-                    snap = torch.empty(self.epochs, sh.n_active, self.d, dtype=torch.float32, device=dev)
+                    snap = snap_pool[snap_at:snap_at + self.epochs * sh.n_active * d].view(self.epochs, sh.n_active, d)
                     self.state[-1].update(snap=snap)
                     D.snap, D.row_slot = nv.ptr(snap), nv.ptr(sh.row_slot())
                 else:
-                    snapU = torch.empty(self.epochs, sh.n_user, self.d, dtype=torch.float32, device=dev)
-                    snapV = torch.empty(self.epochs, sh.n_item, self.d, dtype=torch.float32, device=dev)
+                    nU = self.epochs * sh.n_user * d
+                    snapU = snap_pool[snap_at:snap_at + nU].view(self.epochs, sh.n_user, d)
+                    snapV = snap_pool[snap_at + nU:snap_at + nU + self.epochs * sh.n_item * d].view(self.epochs, sh.n_item, d)
                     self.state[-1].update(snapU=snapU, snapV=snapV)
                     D.snapU, D.snapV = nv.ptr(snapU), nv.ptr(snapV)
+                snap_at += al(self.epochs * snap_rows[s] * d)
             if self.lazy_rows:
-                U0d, V0d = U[0].clone(), V[0].clone()
+                U0d, V0d = views[5].view(sh.n_user, d), views[6].view(sh.n_item, d)
+                U0d.copy_(U[0])
+                V0d.copy_(V[0])
                 self.state[-1].update(U0=U0d, V0=V0d)
                 D.U0, D.V0, D.lr_host, D.lazy_rows = nv.ptr(U0d), nv.ptr(V0d), lr_host.ctypes.data, 1
         self._descs = descs
@@ -682,7 +730,9 @@ class EvalSet:
 
 def merge_rows(dst, src, rows, stream=None):
     """dst[rows] = src[rows] on the device (sisa.py:55-56)."""
-    rows = to_device_async(np.asarray(rows, dtype=np.int64), dst.device)
+    if not torch.is_tensor(rows):
+        rows = to_device_async(np.asarray(rows, dtype=np.int64), dst.device)
+    assert rows.dtype == torch.int64 and rows.device == dst.device
     assert dst.is_contiguous() and src.is_contiguous() and dst.shape == src.shape
     nv.check(nv.lib().ure_merge_rows(nv.ptr(dst), nv.ptr(src), nv.ptr(rows), rows.numel(), dst.shape[1],
                                      nv.stream_handle(stream)), 'ure_merge_rows')

@@ -64,26 +64,36 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
         layouts = rng.worker_pool().submit(shard_layouts, [as_loader(train_dlist[i]) for i in own_ids], n_user, n_item, engine._device(), k)
     streams = rng.shard_streams(len(ids), n_user, n_item, k, epochs, True) if on_device else None
     if streams is not None:
-        # every shard's start state by skip-ahead, then each owned shard's draws (init, seeds, permutations, upload) on its own
-        # worker thread.  The model inits start at once; the permutation expansion (36 ms of CPU time for a 5-shard, 50-epoch
-        # call) waits behind `gate` until the layouts are there, so that they get the cores first
+        # every shard's start state by skip-ahead, then the owned shards' draws (init, seeds, permutations, upload) on a few worker
+        # threads (rng.draws_batch_async): the model inits first, then the permutation chunks round robin
         import threading
         starts, end = streams
         torch.set_rng_state(end)
         mine = [pos for pos in range(len(ids)) if owner[pos] == rank]
-        per_call = max(2, PERM_THREADS // max(len(mine), 1))
+        # `gate` can hold the permutation expansion back until the layouts are built (URE_GATE=1).  Measured with the layouts as
+        # ONE native call on a worker (tools/ab_host.py, medians of 5 alternating runs): 5 shards 13.8 / 13.1 ms without the gate,
+        # 15.1 / 14.0 with it; 16 shards 24.6 / 22.5 against 24.1 / 20.9 (noise).  Open by default.
         gate = threading.Event()
-        if os.environ.get('URE_GATE', '1') == '0':
+        if os.environ.get('URE_GATE', '0') != '1':
             gate.set()
         futures = {}
         try:
+            specs, order = [], []
             for pos, i in enumerate(ids):
                 loader = as_loader(train_dlist[i])
+                base = dict(start_state=starts[pos], n_user=n_user, n_item=n_item, k=k, epochs=epochs, with_total_test=True)
                 if owner[pos] == rank:
-                    futures[i] = rng.shard_draws_async(starts[pos], n_user, n_item, k, epochs, True, len(loader.dataset), loader.shuffle,
-                                                       threads=per_call, device=engine._device(), gate=gate)
+                    specs.append(dict(base, n_rows=len(loader.dataset), shuffle=loader.shuffle, device=engine._device()))
+                    order.append(i)
                 elif foreign_u0 is not None:
-                    futures[i] = rng.shard_draws_async(starts[pos], n_user, n_item, k, epochs, True, 0, False, want_perms=False)
+                    specs.append(dict(base, n_rows=0, shuffle=False, want_perms=False))
+                    order.append(i)
+            # few workers, several shards each (rng.draws_batch_async): the expansion threads of a worker's native calls share
+            # the rank's CPUs
+            W = max(1, min(len(specs), int(os.environ.get('URE_DRAW_WORKERS', '0')) or max(2, rng.host_cpus() // 2)))
+            for sp in specs:
+                sp['threads'] = max(2, PERM_THREADS // W)
+            futures = dict(zip(order, rng.draws_batch_async(specs, W, gate)))
             shards = dict(zip(own_ids, layouts.result()))
         finally:
             gate.set()
@@ -197,11 +207,17 @@ class Sisa(Scratch):
     def _rows(self, i):
         return torch.as_tensor(np.asarray(self.group_index[i], dtype=np.int64))
 
+    def _rows_dev(self, i):
+        """group_index[i] as a device int64 tensor; all groups go up together, once per object."""
+        if getattr(self, '_group_rows', None) is None:
+            self._group_rows = engine.upload_many([np.asarray(g, dtype=np.int64) for g in self.group_index], engine._device())
+        return self._group_rows[i]
+
     def _merge(self, merged, ids):
         """sisa.py:52-58 / 107-113: merged[group_index[i]] = U_i[group_index[i]]."""
         for i in ids:
             src = self.model_list[i].user_mat.weight.detach().contiguous()
-            engine.merge_rows(merged, src, self.group_index[i])
+            engine.merge_rows(merged, src, self._rows_dev(i))
         for m in self.model_list:
             m.user_mat.weight = nn.Parameter(merged, requires_grad=False)
 
@@ -213,6 +229,18 @@ class Sisa(Scratch):
         sequential run."""
         seed_all(self.seed)
         engine.mark('start')
+        # The shards' worker threads (draws, permutation chunks, uploads) run short pieces of Python between native calls; with
+        # CPython's default switch interval (5 ms) this thread can wait that long for the GIL every time it comes back from a
+        # native call of its own -- 10 ms between two marks of a 16-shard call.  A short interval for the duration of the call.
+        import sys
+        switch = sys.getswitchinterval()
+        sys.setswitchinterval(float(os.environ.get('URE_SWITCH_INTERVAL', '2e-4')))
+        try:
+            return self._train_parallel_body(ids, train_dlist, test_dlist, test_data, verbose, save_dir, unlearning)
+        finally:
+            sys.setswitchinterval(switch)
+
+    def _train_parallel_body(self, ids, train_dlist, test_dlist, test_data, verbose, save_dir, unlearning):
         dist = _dist()
         world = dist.get_world_size() if dist else 1
         rank = dist.get_rank() if dist else 0
@@ -259,7 +287,7 @@ class Sisa(Scratch):
         if dist:
             # the only exchange of the path (sisa.py:52-58): own user rows + item table of every shard, one all-gather
             dev = engine._device()
-            rows = {i: self._rows(i).to(dev) for i in ids}
+            rows = {i: self._rows_dev(i) for i in ids}
             got = exchange_tables(models, ids, owner, rank, rows, self.n_item, self.k, dev, dist)
             batch = as_loader(train_dlist[ids[0]]).batch_size
             for pos, i in enumerate(ids):

@@ -156,9 +156,30 @@ def shard_layouts(loaders, n_user, n_item, device=None, units_for=None):
                 l._cache[key] = sh
         out = [l._cache[key] for l in loaders]
         if units_for is not None:
-            for sh in out:
-                sh.units(pad_dim(int(units_for)))
+            # the work units of this table width for every shard that lacks them: built side by side (native, outside the GIL),
+            # uploaded in one copy
+            from .engine import upload_many
+            d = pad_dim(int(units_for))
+            need = [sh for sh in out if (d, False) not in sh._units]
+            if need:
+                built = list(_unit_pool().map(lambda sh: sh.units_host(d), need)) if len(need) > 1 else [need[0].units_host(d)]
+                for sh, (u, n_units, n_rows), dev_u in zip(need, built, upload_many([b[0] for b in built], need[0].device)):
+                    sh._units[(d, False)] = (dev_u, n_units, n_rows)
     return out
+
+
+_UNIT_POOL = None
+
+
+def _unit_pool():
+    """Host threads for per-shard native calls made from inside a worker of rng.worker_pool() (a pool of its own: a task
+    that waited for tasks of its own pool could starve it)."""
+    global _UNIT_POOL
+    if _UNIT_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        from . import rng
+        _UNIT_POOL = ThreadPoolExecutor(max_workers=max(2, min(16, rng.host_cpus())), thread_name_prefix='ure-units')
+    return _UNIT_POOL
 
 
 def as_loader(obj):

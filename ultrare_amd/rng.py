@@ -66,6 +66,8 @@ def perm_threads():
     (250 Fisher-Yates permutations of 0.5 ms each are half of a 5-shard, 50-epoch call's wall time on 16 threads)."""
     import os
     env = os.environ.get('URE_PERM_THREADS')
+    # (the rank's CPUs, not more: with 32 threads on a 16-CPU grant the isolated expansion is faster -- 2.3 against 3.0 ms per 250
+    # permutations -- and the whole call slower, medians of 5 alternating runs: learn 17.3 against 15.2 ms; tools/ab_host.py)
     return max(1, int(env)) if env else min(64, host_cpus())
 
 
@@ -182,11 +184,11 @@ class _HostPool:
                     best = i
             buf = self.free.pop(best)[0] if best is not None else None
         if buf is None:
-            # size classes (steps of 1/8 of the power of two below the size, at least 1 MiB): the shards of consecutive requests
-            # differ by a few rows -- another deletion set -- and must find the buffers of the previous request large enough;
-            # allocating 36 MB of pinned memory costs more host time than expanding the permutations that go into it
+            # size classes (steps of a quarter of the power of two above the size, at least min_step): the shards of consecutive
+            # requests differ by a few rows -- another deletion set -- and must find the buffers of the previous request large
+            # enough; allocating 36 MB of pinned memory costs more host time than expanding the permutations that go into it
             size = max(need, 1)
-            step = max(self.min_step, 1 << max(size.bit_length() - 4, 0))
+            step = max(self.min_step, 1 << max(size.bit_length() - 2, 0))
             size = (size + step - 1) // step * step
             buf = torch.empty(size, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
         view = buf[:need].view(dtype).view(shape)
@@ -305,31 +307,6 @@ _SHARD_POOL = None
 _TEST_CHUNK_DELAY_S = 0.0      # tests only: the worker sleeps this long before every chunk (late arrivals must not change results)
 
 
-class ShardDraws:
-    """Handle of rng.shard_draws_async: init() blocks until the model init is there (on the device when a device was
-    given); perms() returns the permutations -- at once when they arrive in chunks (a device tensor whose `_ure_chunks`
-    = [(first epoch after the chunk, threading.Event set once the chunk's upload is queued, [its HIP event])] tell a
-    consumer when each part may be read: engine.TrainJob.run does), otherwise after the worker is done."""
-
-    def __init__(self, future, chunked):
-        self._future, self._chunked = future, chunked
-
-    def init(self):
-        return self._future.result()[0] if self._chunked is None else self._init_ready()
-
-    def _init_ready(self):
-        self._chunked._ure_init_done.wait()
-        if self._chunked._ure_error:
-            self._future.result()                       # re-raises the worker's exception
-        return self._chunked._ure_init
-
-    def perms(self):
-        return self._future.result()[1] if self._chunked is None else self._chunked
-
-    def result(self):
-        return self.init(), self.perms()
-
-
 def worker_pool():
     """The host workers of a SISA call (per-shard draws, layout builds): they spend their time inside native calls and
     copies that release the GIL.  Two per shard of a call up to 64 (8 workers -- round 2 -- left half of a 16-shard call's
@@ -341,57 +318,56 @@ def worker_pool():
     return _SHARD_POOL
 
 
-def shard_draws_async(start_state, n_user, n_item, k, epochs, with_total_test, n_rows, shuffle, threads=0, device=None, want_perms=True,
-                      chunk_epochs=8, gate=None):
-    """Everything random of ONE Scratch.train call, taken on a worker thread from its own generator positioned at
-    `start_state` (shard_streams): the model init (utils.py:31-40), the per-epoch seeds and the expanded
-    permutations.  The shards of a SISA call are independent streams once their start states are known, so their
-    draws run side by side instead of one after the other.  With a HIP `device` the init tables and the permutations
-    are uploaded on a side stream, the permutations in chunks of epochs so that training starts on the first epochs
-    while the later ones are still being expanded.  gate (threading.Event): the permutation expansion -- the bulk of the
-    CPU work -- starts only once it is set, so that whatever the caller needs first (the layouts) gets the cores first.
-    -> ShardDraws."""
-    worker_pool()
-    from . import _native as nv
-    nv.lib()
-    big = n_rows >= (2 ** 32 - 1) // 20
-    host = on_dev = ready = None
-    on_device = device is not None and torch.device(device).type == 'cuda'
-    if want_perms and shuffle and n_rows > 0 and epochs > 0 and not big:
-        host = POOL.take((epochs, n_rows), torch.int32)            # the pool is not thread safe: taken here
-        if on_device:
-            dev = torch.device(device)
-            on_dev = torch.empty((epochs, n_rows), dtype=torch.int32, device=dev)
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(dev))
-            on_dev._ure_host = host
-            on_dev._ure_chunks = [(min(epochs, c0 + chunk_epochs), threading.Event(), [None]) for c0 in range(0, epochs, chunk_epochs)]
-            on_dev._ure_init_done, on_dev._ure_init, on_dev._ure_error = threading.Event(), None, False
+class _DrawsTask:
+    """Everything random of ONE Scratch.train call as two pieces of work for a worker thread: init() -- the model init from a
+    generator positioned at the shard's start state, uploaded -- and chunks() -- the expanded permutations, one chunk of epochs
+    per step of the generator.  Buffers and events are created on the calling thread (the pool and the allocator see the
+    caller's current stream)."""
 
-    def work():
-        try:
-            return body()
-        except BaseException:
-            if on_dev is not None:                                   # never leave a consumer waiting on a chunk
-                on_dev._ure_error = True
-                on_dev._ure_init_done.set()
-                for _, flag, _ in on_dev._ure_chunks:
-                    flag.set()
-            raise
+    def __init__(self, start_state, n_user, n_item, k, epochs, with_total_test, n_rows, shuffle, threads, device, want_perms, chunk_epochs):
+        from . import _native as nv
+        nv.lib()
+        self.args = (start_state, n_user, n_item, k, epochs, with_total_test, n_rows, shuffle, int(threads or 0), want_perms)
+        self.device = torch.device(device) if device is not None and torch.device(device).type == 'cuda' else None
+        self.host = self.on_dev = self.ready = self.seeds = self.stream = None
+        self.init_value = self.perms_value = None
+        self.init_done, self.error = threading.Event(), None
+        big = n_rows >= (2 ** 32 - 1) // 20
+        if want_perms and shuffle and n_rows > 0 and epochs > 0 and not big:
+            self.host = POOL.take((epochs, n_rows), torch.int32)
+            if self.device is not None:
+                dev = self.device
+                self.on_dev = torch.empty((epochs, n_rows), dtype=torch.int32, device=dev)
+                self.ready = torch.cuda.Event()
+                self.ready.record(torch.cuda.current_stream(dev))
+                self.on_dev._ure_host = self.host
+                # chunks of at least chunk_epochs epochs and ~4 MB: every chunk costs its worker ~0.1 ms of Python (slices, a copy,
+                # an event) under the GIL, and a request of 16 small shards had 112 of them competing with the calling thread
+                chunk_epochs = max(int(chunk_epochs), -(-(4 << 20) // (4 * n_rows)))
+                self.on_dev._ure_chunks = [(min(epochs, c0 + chunk_epochs), threading.Event(), [None]) for c0 in range(0, epochs, chunk_epochs)]
 
-    def body():
+    def fail(self, exc):
+        """Never leave a consumer waiting: init() / the chunk flags are released, the exception is kept for result()."""
+        self.error = exc
+        self.init_done.set()
+        if self.on_dev is not None:
+            for _, flag, _ in self.on_dev._ure_chunks:
+                flag.set()
+
+    def init(self):
+        start_state, n_user, n_item, k, epochs, with_total_test = self.args[:6]
         g = torch.Generator()
         g.set_state(start_state)
         init = mf_init(n_user, n_item, k, generator=g)
-        seeds = epoch_seeds(epochs, with_total_test, generator=g)
-        st = None
-        if on_device:
+        self.seeds = epoch_seeds(epochs, with_total_test, generator=g)
+        if self.device is not None:
             # the init tables go up first, on a side stream of this worker
-            dev = torch.device(device)
+            dev = self.device
             with torch.cuda.device(dev):
                 st = _UPLOAD_STREAMS.get((dev, threading.get_ident()))
                 if st is None:
                     st = _UPLOAD_STREAMS[(dev, threading.get_ident())] = torch.cuda.Stream(dev)
+                self.stream = st
                 with torch.cuda.stream(st):
                     up = tuple(t.to(dev) for t in init)
                     ev0 = torch.cuda.Event()
@@ -399,39 +375,126 @@ def shard_draws_async(start_state, n_user, n_item, k, epochs, with_total_test, n
             for t in up:
                 t._ure_event = ev0
             init = up
-        if on_dev is not None:
-            on_dev._ure_init = init
-            on_dev._ure_init_done.set()
+        self.init_value = init
+        self.init_done.set()
+
+    def chunks(self):
+        """Generator: every step expands (and uploads) one chunk of epochs; the permutations are complete when it ends."""
+        from . import _native as nv
+        _, _, _, _, epochs, _, n_rows, shuffle, threads, want_perms = self.args
         if not want_perms:
-            return init, None
+            return
         if not shuffle:
-            return init, torch.arange(n_rows, dtype=torch.int32).repeat(epochs, 1)
-        if gate is not None:
-            gate.wait()
-        if host is None:
-            return init, epoch_perms(seeds, n_rows, threads)
-        sd = np.asarray(seeds, dtype=np.uint64).astype(np.int64)
-        if on_dev is None:
-            nv.check(nv.lib().ure_host_randperm(sd.ctypes.data, len(sd), n_rows, host.data_ptr(), int(threads or 0)), 'ure_host_randperm')
-            return init, host
-        dev = on_dev.device
-        with torch.cuda.device(dev):
-            st.wait_event(ready)
+            self.perms_value = torch.arange(n_rows, dtype=torch.int32).repeat(epochs, 1)
+            return
+        if self.host is None:
+            self.perms_value = epoch_perms(self.seeds, n_rows, threads)
+            return
+        sd = np.asarray(self.seeds, dtype=np.uint64).astype(np.int64)
+        L = nv.lib()
+        if self.on_dev is None:
+            nv.check(L.ure_host_randperm(sd.ctypes.data, len(sd), n_rows, self.host.data_ptr(), threads), 'ure_host_randperm')
+            self.perms_value = self.host
+            return
+        dev, st, on_dev, host = self.device, self.stream, self.on_dev, self.host
+        sd_ptr, host_ptr, row_bytes = sd.ctypes.data, host.data_ptr(), 4 * n_rows
+        self.perms_value = on_dev
+        first = True
         c0 = 0
         for c1, flag, slot in on_dev._ure_chunks:
             if _TEST_CHUNK_DELAY_S:
                 import time
                 time.sleep(_TEST_CHUNK_DELAY_S)
-            nv.check(nv.lib().ure_host_randperm(sd[c0:c1].ctypes.data, c1 - c0, n_rows, host[c0:c1].data_ptr(), int(threads or 0)), 'ure_host_randperm')
+            nv.check(L.ure_host_randperm(sd_ptr + 8 * c0, c1 - c0, n_rows, host_ptr + row_bytes * c0, threads), 'ure_host_randperm')
             with torch.cuda.device(dev), torch.cuda.stream(st):
+                if first:
+                    st.wait_event(self.ready)
+                    first = False
                 on_dev[c0:c1].copy_(host[c0:c1], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(st)
             slot[0] = ev
             flag.set()
             c0 = c1
-        return init, on_dev
-    return ShardDraws(_SHARD_POOL.submit(work), on_dev)
+            yield
+
+
+class ShardDraws:
+    """Handle of rng.shard_draws_async / draws_batch_async: init() blocks until the model init is there (on the device when a
+    device was given); perms() returns the permutations -- at once when they arrive in chunks (a device tensor whose
+    `_ure_chunks` = [(first epoch after the chunk, threading.Event set once the chunk's upload is queued, [its HIP event])]
+    tell a consumer when each part may be read: engine.TrainJob.run does), otherwise after the worker is done."""
+
+    def __init__(self, future, task):
+        self._future, self._task = future, task
+
+    def init(self):
+        self._task.init_done.wait()
+        if self._task.error is not None:
+            raise self._task.error
+        return self._task.init_value
+
+    def perms(self):
+        if self._task.on_dev is not None:
+            return self._task.on_dev
+        self._future.result()
+        if self._task.error is not None:
+            raise self._task.error
+        return self._task.perms_value
+
+    def result(self):
+        return self.init(), self.perms()
+
+
+def draws_batch_async(specs, n_workers=0, gate=None):
+    """shard_draws_async for the shards of one call on FEW worker threads: worker w takes the shards w, w + W, ... -- first
+    all their model inits, then (once `gate` is set) their permutation chunks round robin, so that the first chunk of every
+    shard arrives before anybody's second.  One thread per shard -- round 2 -- meant 16 Python threads taking turns on the GIL
+    with the calling thread for a 16-shard call (10 ms between two of its marks).  specs: list of dicts of shard_draws_async's
+    arguments.  -> [ShardDraws]."""
+    pool = worker_pool()
+    tasks = [_DrawsTask(sp['start_state'], sp['n_user'], sp['n_item'], sp['k'], sp['epochs'], sp['with_total_test'], sp.get('n_rows', 0),
+                        sp.get('shuffle', False), sp.get('threads', 0), sp.get('device'), sp.get('want_perms', True), sp.get('chunk_epochs', 8))
+             for sp in specs]
+    W = max(1, min(len(tasks), int(n_workers) if n_workers else max(2, host_cpus() // 2)))
+
+    def work(mine):
+        todo = list(mine)
+        try:
+            for t in mine:
+                t.init()
+            if gate is not None:
+                gate.wait()
+            gens = [(t, t.chunks()) for t in mine]
+            while gens:
+                for t, g in list(gens):
+                    try:
+                        next(g)
+                    except StopIteration:
+                        gens.remove((t, g))
+                        todo.remove(t)
+        except BaseException as e:
+            for t in todo:
+                t.fail(e)
+            raise
+
+    futures = [pool.submit(work, tasks[w::W]) for w in range(W)]
+    return [ShardDraws(futures[i % W], t) for i, t in enumerate(tasks)]
+
+
+def shard_draws_async(start_state, n_user, n_item, k, epochs, with_total_test, n_rows, shuffle, threads=0, device=None, want_perms=True,
+                      chunk_epochs=8, gate=None):
+    """Everything random of ONE Scratch.train call, taken on a worker thread from its own generator positioned at
+    `start_state` (shard_streams): the model init (utils.py:31-40), the per-epoch seeds and the expanded
+    permutations.  The shards of a SISA call are independent streams once their start states are known, so their
+    draws run side by side instead of one after the other (draws_batch_async).  With a HIP `device` the init tables and
+    the permutations are uploaded on a side stream, the permutations in chunks of epochs so that training starts on the first
+    epochs while the later ones are still being expanded.  gate (threading.Event): the permutation expansion -- the bulk of
+    the CPU work -- starts only once it is set, so that whatever the caller needs first (the layouts) gets the cores first.
+    -> ShardDraws."""
+    return draws_batch_async([dict(start_state=start_state, n_user=n_user, n_item=n_item, k=k, epochs=epochs, with_total_test=with_total_test,
+                                   n_rows=n_rows, shuffle=shuffle, threads=threads, device=device, want_perms=want_perms,
+                                   chunk_epochs=chunk_epochs)], 1, gate)[0]
 
 
 def seed_all(seed):
