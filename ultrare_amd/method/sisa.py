@@ -83,7 +83,8 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
                 loader = as_loader(train_dlist[i])
                 base = dict(start_state=starts[pos], n_user=n_user, n_item=n_item, k=k, epochs=epochs, with_total_test=True)
                 if owner[pos] == rank:
-                    specs.append(dict(base, n_rows=len(loader.dataset), shuffle=loader.shuffle, device=engine._device()))
+                    specs.append(dict(base, n_rows=len(loader.dataset), shuffle=loader.shuffle, device=engine._device(),
+                                      chunk_epochs=int(os.environ.get('URE_CHUNK_EPOCHS', '8'))))
                     order.append(i)
                 elif foreign_u0 is not None:
                     specs.append(dict(base, n_rows=0, shuffle=False, want_perms=False))

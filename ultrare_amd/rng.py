@@ -49,13 +49,15 @@ def limit_torch_threads():
     256-CPU host that grants this container 16, every CPU-side torch op (a normal_() fill, a copy) woke 256 OpenMP threads,
     whose spinning used the cgroup's quota up and got the whole process throttled for the rest of the 100 ms period --
     50-80 ms stalls in the middle of a 15 ms Sisa.learn (cpu.stat: 28 of 285 periods throttled; profiles/r03/NOTES.md).
-    The pool is capped at the CPUs this rank may really use (host_cpus()); URE_TORCH_THREADS=0 leaves torch alone,
-    URE_TORCH_THREADS=n sets n."""
+    The pool is capped at 4 threads (and at the CPUs this rank may really use, host_cpus()): the CPU-side torch ops of the path are
+    small (fills of ~200 k normals, copies) and run on several worker threads at once, where a wide intra-op pool only adds hand-offs
+    -- medians of alternating runs (tools/ab_host.py), learn / unlearn at 5 shards: 16.4 / 14.3 ms with 16 threads, 14.6 / 13.1 with 4,
+    15.2 / 14.0 with 1; at 16 shards 24.3 / 27.0, 27.6 / 24.8, 22.5 / 20.2.  URE_TORCH_THREADS=0 leaves torch alone, =n sets n."""
     import os
     env = os.environ.get('URE_TORCH_THREADS', '')
     if env == '0':
         return torch.get_num_threads()
-    want = int(env) if env else min(torch.get_num_threads(), host_cpus())
+    want = int(env) if env else min(torch.get_num_threads(), host_cpus(), 4)
     if want >= 1 and want != torch.get_num_threads():
         torch.set_num_threads(want)
     return torch.get_num_threads()
