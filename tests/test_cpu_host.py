@@ -605,3 +605,58 @@ def test_batched_layout_builder_equals_the_single_one(lib):
     with pytest.raises(lib.NativeError, match='shard 1'):
         bad = [raw[0], (raw[1][0], raw[1][1] + N_ITEM, raw[1][2]), raw[2]]
         lib.build_layouts(bad, N_USER, N_ITEM, regs, threads=2)
+
+
+def test_draws_of_a_call_on_few_workers_equal_the_sequential_stream():
+    """rng.draws_batch_async: the shards of a call on FEWER worker threads than shards (a worker takes several shards: all their
+    inits, then their permutation chunks round robin) give every shard the init and the permutations of its place in the one
+    sequential stream; a gate holds the permutations back; a failing worker never leaves a consumer waiting."""
+    import threading
+    from ultrare_amd import rng
+    S, n_user, n_item, k, E = 5, 37, 23, 8, 4
+    torch.manual_seed(11)
+    want = []
+    for i in range(S):
+        init = rng.mf_init(n_user, n_item, k)
+        want.append((init, rng.epoch_seeds(E, True)))
+    torch.manual_seed(11)
+    starts, _ = rng.shard_streams(S, n_user, n_item, k, E, True)
+    gate = threading.Event()
+    specs = [dict(start_state=starts[i], n_user=n_user, n_item=n_item, k=k, epochs=E, with_total_test=True, n_rows=300 + 10 * i, shuffle=True,
+                  threads=2) for i in range(S)]
+    specs[3].update(n_rows=0, shuffle=False, want_perms=False)         # a shard another rank owns: init only
+    draws = rng.draws_batch_async(specs, 2, gate)
+    for i, dr in enumerate(draws):                                     # the inits do not wait for the gate
+        init = dr.init()
+        assert torch.equal(init[0], want[i][0][0]) and torch.equal(init[1], want[i][0][1])
+    gate.set()
+    for i, dr in enumerate(draws):
+        perms = dr.perms()
+        if i == 3:
+            assert perms is None
+            continue
+        for e in range(E):
+            assert torch.equal(perms[e], rng.epoch_perm(want[i][1][e], 300 + 10 * i))
+        rng.release(perms)
+    bad = dict(specs[0], start_state=torch.zeros(3, dtype=torch.uint8))   # not a generator state: the worker raises
+    dr = rng.draws_batch_async([bad], 1)[0]
+    with pytest.raises(Exception):
+        dr.init()
+
+
+def test_host_cpus_respects_affinity_and_ranks(monkeypatch):
+    from ultrare_amd import rng
+    n = rng.host_cpus()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '2')
+    assert rng.host_cpus() == max(1, n // 2) or rng.host_cpus() == max(1, len(os.sched_getaffinity(0)) // 2)
+    monkeypatch.setenv('URE_PERM_THREADS', '3')
+    assert rng.perm_threads() == 3
+
+
+def test_upload_many_on_the_host_device():
+    from ultrare_amd import engine
+    arrs = [np.arange(7, dtype=np.int32), np.linspace(0, 1, 5, dtype=np.float32).reshape(5, 1), np.zeros((0, 4), dtype=np.int64)]
+    out = engine.upload_many(arrs, torch.device('cpu'))
+    for a, t in zip(arrs, out):
+        assert tuple(t.shape) == a.shape and np.array_equal(t.numpy(), a)

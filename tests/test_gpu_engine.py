@@ -334,7 +334,7 @@ def test_compact_snapshots_give_the_series_of_full_snapshots(toy, touch):
     perms = [rng.epoch_perms(rng.epoch_seeds(E, True), len(p[0])) for p in parts]
     shards = [engine.ShardData(*p, N_USER, N_ITEM) for p in parts]
     assert all(sh.n_active < 0.6 * (N_USER + N_ITEM) for sh in shards)
-    jobs = {m: engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, snapshots=m, touch=touch) for m in ('full', 'compact')}
+    jobs = {m: engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, snapshots=m, touch=touch, lazy_rows=True) for m in ('full', 'compact')}
     assert jobs['compact'].snapshots == 'compact' and jobs['full'].snapshots == 'full' and jobs['compact'].touch == touch
     for j in jobs.values():
         j.run()
@@ -392,7 +392,7 @@ def test_early_own_scores_give_the_same_series(toy):
     own_sets = [engine.EvalSet(*t) for t in tests]
     fixed = [tuple(torch.randn(n, engine.pad_dim(k), device=total.device) * 0.3 for n in (N_USER, N_ITEM)) for _ in range(2)]
     for touch in (False, True):
-        job = engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, snapshots='compact', touch=touch)
+        job = engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, snapshots='compact', touch=touch, lazy_rows=True)
         handles = [(job.early_scores(s, own_sets[s]), job.early_scores(s, total)) for s in range(S)]
         assert all(h is not None for pair in handles for h in pair)
         job.run()
@@ -404,3 +404,15 @@ def test_early_own_scores_give_the_same_series(toy):
                     torch.cuda.synchronize()
                     assert torch.isfinite(want).all() and torch.equal(got, want), (touch, s, len(before))
         job.close()
+
+
+def test_upload_many_on_the_device():
+    """Small descriptors through one pinned staging buffer and one asynchronous copy: values, shapes, dtypes and alignment."""
+    from ultrare_amd import engine
+    rs = np.random.RandomState(0)
+    arrs = [rs.randint(0, 99, (13, 4)).astype(np.int32), rs.rand(50).astype(np.float32), np.arange(377, dtype=np.int64), np.zeros((0, 4), dtype=np.int32),
+            rs.rand(3, 5).astype(np.float64)]
+    for _ in range(3):                                        # the staging buffer is reused once its copy is done
+        out = engine.upload_many(arrs, engine._device())
+        for a, t in zip(arrs, out):
+            assert tuple(t.shape) == a.shape and t.is_cuda and t.data_ptr() % 64 == 0 and np.array_equal(t.cpu().numpy(), a)
