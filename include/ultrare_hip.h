@@ -194,6 +194,10 @@ void ure_host_free(void *p);
 int ure_host_partition(const int32_t *uid, const int32_t *iid, const double *rating, int64_t n, const int32_t *shard_of_user,
                        int32_t n_user, int32_t n_shards, double max_rating, int64_t *counts, int32_t *out_uid,
                        int32_t *out_iid, float *out_rating, double *out_rating64);
+/* The same partition written as readRating returns it (read.py:9-70): shard s is the float64 block [3][counts[s]] at
+ * out + 3 * sum(counts[:s]) -- its uid row, its iid row, its rating / max_rating row.  out == NULL: counting pass only. */
+int ure_host_partition64(const int32_t *uid, const int32_t *iid, const double *rating, int64_t n, const int32_t *shard_of_user,
+                         int32_t n_user, int32_t n_shards, double max_rating, int64_t *counts, double *out);
 /* Builds the slot layout of struct ure_shard from a shard's triples: ent_oid / ent_r / ent_src
  * (capacity 2 n + 8 (n_user + n_item) slots, *n_slots receives the used count), sched
  * [n_user + n_item][4], the number of active rows, and optionally u_pos / i_pos [n] (slot of each

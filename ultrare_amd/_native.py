@@ -60,6 +60,7 @@ _PROTOTYPES = {
                                          ctypes.POINTER(_i64), ctypes.c_int]),
     'ure_host_free': (None, [_vp]),
     'ure_host_partition': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, ctypes.c_double, _vp, _vp, _vp, _vp, _vp]),
+    'ure_host_partition64': (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, ctypes.c_double, _vp, _vp]),
     'ure_host_build_layout': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp,
                                              ctypes.POINTER(_i64), ctypes.POINTER(_i32), _vp, _vp]),
     'ure_host_build_layouts': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i32, _i32,
@@ -179,16 +180,21 @@ def read_csv(path, threads=0):
     pu, pi, pr, n = _vp(), _vp(), _vp(), _i64()
     check(lib().ure_host_read_csv(os.fsencode(path), ctypes.byref(pu), ctypes.byref(pi), ctypes.byref(pr), ctypes.byref(n), threads),
           'ure_host_read_csv')
-    try:
-        m = n.value
-        u = np.ctypeslib.as_array(ctypes.cast(pu, ctypes.POINTER(ctypes.c_int32)), (max(m, 1),))[:m].copy()
-        i = np.ctypeslib.as_array(ctypes.cast(pi, ctypes.POINTER(ctypes.c_int32)), (max(m, 1),))[:m].copy()
-        r = np.ctypeslib.as_array(ctypes.cast(pr, ctypes.POINTER(ctypes.c_double)), (max(m, 1),))[:m].copy()
-    finally:
-        for p in (pu, pi, pr):
+    # the arrays own the library's buffers: they are freed when the last array is (no copy of 14 MB per file)
+    m = n.value
+    out = []
+    for p, ct in ((pu, ctypes.c_int32), (pi, ctypes.c_int32), (pr, ctypes.c_double)):
+        if not p or m == 0:
             if p:
                 lib().ure_host_free(p)
-    return u, i, r
+            out.append(np.zeros(0, dtype=np.dtype(ct)))
+            continue
+        buf = (ct * m).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=np.dtype(ct))
+        import weakref
+        weakref.finalize(buf, lib().ure_host_free, ctypes.c_void_p(p.value))
+        out.append(arr)
+    return tuple(out)
 
 
 def partition(uid, iid, rating, shard_of_user, n_shards, max_rating):
@@ -237,6 +243,23 @@ def build_layouts(triples, n_user, n_item, regions, threads=0):
 def layout_capacity(n, n_user, n_item):
     """Slots ure_host_build_layout may write for n interactions (every row's segment is padded to a multiple of 8)."""
     return 2 * n + 8 * (n_user + n_item) + 8
+
+
+def partition64(uid, iid, rating, shard_of_user, n_shards, max_rating):
+    """ure_host_partition64: one counting pass and one writing pass over the rows -> per shard the [3, N_s] float64 array
+    readRating returns (uid, iid, rating / max_rating; file order kept), views of one block."""
+    uid = np.ascontiguousarray(uid, dtype=np.int32)
+    iid = np.ascontiguousarray(iid, dtype=np.int32)
+    rating = np.ascontiguousarray(rating, dtype=np.float64)
+    shard_of_user = np.ascontiguousarray(shard_of_user, dtype=np.int32)
+    counts = np.zeros(n_shards, dtype=np.int64)
+    args = (uid.ctypes.data, iid.ctypes.data, rating.ctypes.data, len(uid), shard_of_user.ctypes.data, len(shard_of_user),
+            n_shards, float(max_rating), counts.ctypes.data)
+    check(lib().ure_host_partition64(*args, None), 'ure_host_partition64')
+    block = np.empty(3 * int(counts.sum()), dtype=np.float64)
+    check(lib().ure_host_partition64(*args, block.ctypes.data), 'ure_host_partition64')
+    off = np.concatenate([[0], np.cumsum(3 * counts)])
+    return [block[off[s]:off[s + 1]].reshape(3, int(counts[s])) for s in range(n_shards)]
 
 
 def build_layout(uid, iid, rating, n_user, n_item, want_pos=False, out=None):

@@ -251,6 +251,37 @@ static int build_layout_t(const IdT *uid, const IdT *iid, const RT *rating, int6
 
 extern "C" {
 
+int ure_host_partition64(const int32_t *uid, const int32_t *iid, const double *rating, int64_t n, const int32_t *shard_of_user,
+                         int32_t n_user, int32_t n_shards, double max_rating, int64_t *counts, double *out)
+{
+    if (!uid || !iid || !rating || !shard_of_user || !counts || n < 0 || n_user <= 0 || n_shards <= 0)
+        return ure::fail(-1, "ure_host_partition64: bad arguments");
+    std::fill(counts, counts + n_shards, (int64_t)0);
+    for (int64_t j = 0; j < n; ++j) {
+        const int32_t u = uid[j];
+        if (u < 0 || u >= n_user) return ure::fail(-1, "ure_host_partition64: user id %d outside [0, %d)", u, n_user);
+        const int32_t s = shard_of_user[u];
+        if (s >= n_shards) return ure::fail(-1, "ure_host_partition64: shard %d outside [0, %d)", s, n_shards);
+        if (s >= 0) ++counts[s];
+    }
+    if (!out) return 0;                           // counting pass only
+    // shard s is the block [3][counts[s]] at 3 * sum(counts[:s]): its uid row, its iid row, its rating row
+    std::vector<double *> row_u(n_shards), row_i(n_shards), row_r(n_shards);
+    double *at = out;
+    for (int s = 0; s < n_shards; ++s) {
+        row_u[s] = at; row_i[s] = at + counts[s]; row_r[s] = at + 2 * counts[s];
+        at += 3 * counts[s];
+    }
+    for (int64_t j = 0; j < n; ++j) {
+        const int32_t s = shard_of_user[uid[j]];
+        if (s < 0) continue;                      // deleted user / user of no group
+        *row_u[s]++ = (double)uid[j];
+        *row_i[s]++ = (double)iid[j];
+        *row_r[s]++ = rating[j] / max_rating;     // read.py:66 (float64 division)
+    }
+    return 0;
+}
+
 int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *rating, int64_t n, int32_t n_user, int32_t n_item,
                           int32_t *ent_oid, float *ent_r, int32_t *ent_src, int32_t *sched,
                           int64_t *n_slots, int32_t *n_active, int32_t *u_pos, int32_t *i_pos)

@@ -52,7 +52,8 @@ def readRating(dir, n_user, max_rating=5, del_user=[], del_rating=[], n_group=1,
             group_index = [org_index[i * group_len:(i + 1) * group_len] for i in range(n_group)]
     group_index = list(group_index)
 
-    uid, iid, raw = _read_csv(dir)
+    from . import _native as nv
+    uid, iid, raw = nv.read_csv(dir)               # int32 ids, float64 ratings (the library's threaded reader)
 
     if sort in ['d', 'a']:
         sorted_index = sort_group(order='a', group_index=group_index, var='count', ratings0=uid)   # read.py:45: always ascending
@@ -69,10 +70,7 @@ def readRating(dir, n_user, max_rating=5, del_user=[], del_rating=[], n_group=1,
         # one native pass over the rows (ure_host_partition): shard = group of the row's user, deleted users dropped
         if len(del_user):
             shard_of[np.asarray(list(del_user), dtype=np.int64)] = -1
-        from . import _native as nv
-        rating_lists = [np.vstack([u.astype(np.float64), i.astype(np.float64), r])
-                        for u, i, r in nv.partition(uid, iid, raw, shard_of, n_group, max_rating)]
-        return rating_lists, group_index
+        return nv.partition64(uid, iid, raw, shard_of, n_group, max_rating), group_index
 
     # general form of read.py:52-70 (a user listed in two groups, or single ratings deleted): boolean passes
     deleted = np.zeros(n_ids, dtype=bool)
