@@ -148,120 +148,86 @@ __global__ __launch_bounds__(kBlock) void score_series_kernel(const float *__res
     for (int t = gridDim.x + threadIdx.x; blockIdx.x == 0 && t < URE_SCORE_PARTIALS; t += kBlock) sse[t] = 0.0;
 }
 
-// The same on COMPACT snapshots (struct ure_shard: snap): member e's tables hold only the shard's active rows, in schedule
-// order; every other row is snap_a[e] * w0 by construction and is rebuilt here with the product the full snapshot stores
-// (snapshot_kernel: a * w0 per element), so both forms give identical predictions.
+// The scores of a shard's OWN model on a test set for a run of epochs, from compact snapshots (struct ure_shard: snap): member e's
+// tables hold only the shard's active rows, in schedule order; every other row is snap_a[e] * w0 by construction and is rebuilt here
+// with the product the full snapshot stores (snapshot_kernel: a * w0 per element), so both forms give identical predictions.  The
+// other half of a series -- the fixed models, the division, the squared errors -- follows in series_combine_kernel.
+// The epochs run INSIDE the pair's loop: a lane group keeps its pair for all members of the series, so a row that
+// is not stored in the snapshots (every user of another shard, four fifths of a total test set at five shards) is loaded ONCE -- as
+// w0 -- and only scaled per epoch; the stored rows are gathered per epoch as before.  score_series_compact_kernel fetched both rows
+// of every pair for every epoch (round 2 / early round 3: one grid row per epoch): 10.2 M row gathers per call on the total test set
+// of ml-1m, L2-bound.
 template <int LPR>
-__global__ __launch_bounds__(kBlock) void score_series_compact_kernel(const float *__restrict__ snap, int64_t stride, const int32_t *__restrict__ row_slot,
-                                                                       const float *__restrict__ U0, const float *__restrict__ V0,
-                                                                       const float *__restrict__ snap_a, int n_user_rows, int n_total,
-                                                                       const int32_t *__restrict__ uid, const int32_t *__restrict__ iid,
-                                                                       const float *__restrict__ rating, int64_t n,
-                                                                       const float *__restrict__ base, float *__restrict__ pred,
-                                                                       double *__restrict__ sse)
+__global__ __launch_bounds__(kBlock) void score_own_epochs_kernel(const float *__restrict__ snap, int64_t stride, const int32_t *__restrict__ row_slot,
+                                                                   const float *__restrict__ U0, const float *__restrict__ V0,
+                                                                   const float *__restrict__ snap_a, int n_user_rows, int n_series,
+                                                                   const int32_t *__restrict__ uid, const int32_t *__restrict__ iid, int64_t n,
+                                                                   float *__restrict__ own)
 {
     constexpr int D = LPR * 4;
     constexpr int G = kWave / LPR;
+    constexpr int kE = 4;                 // epochs in flight per pair
     const int lane = threadIdx.x & 63;
     const int sub = lane & (LPR - 1), grp = lane / LPR;
     const int64_t wave_id = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
-    snap += (size_t)blockIdx.y * stride;
-    const float a_e = snap_a[blockIdx.y];
-    pred += (size_t)blockIdx.y * n;
-    sse += (size_t)blockIdx.y * URE_SCORE_PARTIALS;
-    float sq = 0.f;
     for (int64_t j0 = wave_id * G; j0 < n; j0 += n_waves * G) {
         const int64_t j = j0 + grp;
         const bool act = j < n;
         const int u = act ? uid[j] : 0, i = act ? iid[j] : 0;
         const int su = row_slot[u], si = row_slot[n_user_rows + i];
-        float acc = (act && base) ? base[j] : 0.f;
-        float4 a = *reinterpret_cast<const float4 *>((su >= 0 ? snap + (size_t)su * D : U0 + (size_t)u * D) + sub * 4);
-        float4 b = *reinterpret_cast<const float4 *>((si >= 0 ? snap + (size_t)si * D : V0 + (size_t)i * D) + sub * 4);
-        if (su < 0) a = make_float4(a_e * a.x, a_e * a.y, a_e * a.z, a_e * a.w);
-        if (si < 0) b = make_float4(a_e * b.x, a_e * b.y, a_e * b.z, a_e * b.w);
-        float p = a.x * b.x;
-        p = fmaf(a.y, b.y, p);
-        p = fmaf(a.z, b.z, p);
-        p = fmaf(a.w, b.w, p);
-        acc += group_sum<LPR>(p);
-        acc = acc / (float)n_total;
-        if (act && sub == 0) {
-            const float e = acc - rating[j];
-            sq = fmaf(e, e, sq);
-            pred[j] = acc;
+        // rows that are not stored: w0, once
+        const float4 a0 = *reinterpret_cast<const float4 *>(U0 + (size_t)u * D + sub * 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(V0 + (size_t)i * D + sub * 4);
+        const float *pa = snap + (size_t)(su >= 0 ? su : 0) * D + sub * 4;
+        const float *pb = snap + (size_t)(si >= 0 ? si : 0) * D + sub * 4;
+        for (int e0 = 0; e0 < n_series; e0 += kE) {
+            float4 a[kE], b[kE];
+#pragma unroll
+            for (int k = 0; k < kE; ++k) {
+                const int e = min(e0 + k, n_series - 1);
+                a[k] = a0;
+                b[k] = b0;
+                if (su >= 0) a[k] = *reinterpret_cast<const float4 *>(pa + (size_t)e * stride);
+                if (si >= 0) b[k] = *reinterpret_cast<const float4 *>(pb + (size_t)e * stride);
+            }
+#pragma unroll
+            for (int k = 0; k < kE; ++k) {
+                const float ae = snap_a[min(e0 + k, n_series - 1)];
+                float4 x = a[k], y = b[k];
+                if (su < 0) x = make_float4(ae * x.x, ae * x.y, ae * x.z, ae * x.w);
+                if (si < 0) y = make_float4(ae * y.x, ae * y.y, ae * y.z, ae * y.w);
+                float p = x.x * y.x;
+                p = fmaf(x.y, y.y, p);
+                p = fmaf(x.z, y.z, p);
+                p = fmaf(x.w, y.w, p);
+                p = group_sum<LPR>(p);
+                if (act && sub == 0 && e0 + k < n_series) own[(size_t)(e0 + k) * n + j] = p;
+            }
         }
     }
-    __shared__ float part[kWavesPerBlock];
-    sq = wave_sum(sq);
-    if (lane == 0) part[threadIdx.x >> 6] = sq;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < kWavesPerBlock; ++k) t += (double)part[k];
-        sse[blockIdx.x] = t;
-    }
-    for (int t = gridDim.x + threadIdx.x; blockIdx.x == 0 && t < URE_SCORE_PARTIALS; t += kBlock) sse[t] = 0.0;
 }
 
-// The shard's OWN half of a series, ahead of the rest: own[e][j] = <row_e(uid[j]), row_e(n_user_rows + iid[j])> from compact snapshots,
-// for the epochs whose snapshots exist already -- queued on a second stream while training continues.  The other half needs the
-// final models of the shards trained before this one (scratch.py:83-86) and follows in series_combine_kernel.
+// pred[e][j] = (base[j] + own[e][j]) / n_total and the squared-error partials of member e -- the additions, the division AND the
+// order in which score_kernel sums the squared errors, so that a series member agrees with a single evaluation to the last bit.
+// score_kernel's order, for `blocks` workgroups of four waves of G = 64 / LPR lane groups: accumulator (wave w, group g) takes the pairs
+// (w G + g) + k (4 blocks G), k = 0, 1, ... in turn; a wave adds its G accumulators as an xor butterfly; a workgroup adds its four
+// waves in double, in order.  Here every THREAD is one such accumulator (consecutive threads = consecutive pairs: coalesced, where one
+// lane in LPR worked before: 49 -> us per call), G consecutive threads are a logical wave, 4 G a logical workgroup.
 template <int LPR>
-__global__ __launch_bounds__(kBlock) void score_own_compact_kernel(const float *__restrict__ snap, int64_t stride, const int32_t *__restrict__ row_slot,
-                                                                    const float *__restrict__ U0, const float *__restrict__ V0,
-                                                                    const float *__restrict__ snap_a, int n_user_rows,
-                                                                    const int32_t *__restrict__ uid, const int32_t *__restrict__ iid, int64_t n,
-                                                                    float *__restrict__ own)
-{
-    constexpr int D = LPR * 4;
-    constexpr int G = kWave / LPR;
-    const int lane = threadIdx.x & 63;
-    const int sub = lane & (LPR - 1), grp = lane / LPR;
-    const int64_t wave_id = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
-    snap += (size_t)blockIdx.y * stride;
-    const float a_e = snap_a[blockIdx.y];
-    own += (size_t)blockIdx.y * n;
-    for (int64_t j0 = wave_id * G; j0 < n; j0 += n_waves * G) {
-        const int64_t j = j0 + grp;
-        const bool act = j < n;
-        const int u = act ? uid[j] : 0, i = act ? iid[j] : 0;
-        const int su = row_slot[u], si = row_slot[n_user_rows + i];
-        float4 a = *reinterpret_cast<const float4 *>((su >= 0 ? snap + (size_t)su * D : U0 + (size_t)u * D) + sub * 4);
-        float4 b = *reinterpret_cast<const float4 *>((si >= 0 ? snap + (size_t)si * D : V0 + (size_t)i * D) + sub * 4);
-        if (su < 0) a = make_float4(a_e * a.x, a_e * a.y, a_e * a.z, a_e * a.w);
-        if (si < 0) b = make_float4(a_e * b.x, a_e * b.y, a_e * b.z, a_e * b.w);
-        float p = a.x * b.x;
-        p = fmaf(a.y, b.y, p);
-        p = fmaf(a.z, b.z, p);
-        p = fmaf(a.w, b.w, p);
-        p = group_sum<LPR>(p);
-        if (act && sub == 0) own[j] = p;
-    }
-}
-
-// pred[e][j] = (base[j] + own[e][j]) / n_total and the squared-error partials of member e: the additions, the division AND the
-// order in which score_series_compact_kernel sums the squared errors (same grid, one lane per lane group of that kernel works),
-// so that both forms of a series agree to the last bit.
-template <int LPR>
-__global__ __launch_bounds__(kBlock) void series_combine_kernel(const float *__restrict__ own, int n_total, const float *__restrict__ rating, int64_t n,
-                                                                const float *__restrict__ base, float *__restrict__ pred, double *__restrict__ sse)
+__global__ __launch_bounds__(kBlock) void series_combine_kernel(const float *own, int n_total, const float *__restrict__ rating, int64_t n,
+                                                                const float *__restrict__ base, float *pred, double *__restrict__ sse,
+                                                                int blocks)   // (own may be pred: in place)
 {
     constexpr int G = kWave / LPR;
-    const int lane = threadIdx.x & 63;
-    const int sub = lane & (LPR - 1), grp = lane / LPR;
-    const int64_t wave_id = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
     own += (size_t)blockIdx.y * n;
     pred += (size_t)blockIdx.y * n;
     sse += (size_t)blockIdx.y * URE_SCORE_PARTIALS;
+    const int64_t n_acc = (int64_t)blocks * kWavesPerBlock * G;          // accumulators = the stride of an accumulator's pairs
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;        // this thread's accumulator
     float sq = 0.f;
-    for (int64_t j0 = wave_id * G; j0 < n; j0 += n_waves * G) {
-        const int64_t j = j0 + grp;
-        if (j < n && sub == 0) {
+    if (q < n_acc) {
+        for (int64_t j = q; j < n; j += n_acc) {
             float acc = base ? base[j] : 0.f;
             acc += own[j];
             acc = acc / (float)n_total;
@@ -270,17 +236,21 @@ __global__ __launch_bounds__(kBlock) void series_combine_kernel(const float *__r
             pred[j] = acc;
         }
     }
-    __shared__ float part[kWavesPerBlock];
-    sq = wave_sum(sq);
-    if (lane == 0) part[threadIdx.x >> 6] = sq;
+    // the logical wave's butterfly over its G accumulators (the other lanes of score_kernel's wave hold zeros there)
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) sq += __shfl_xor(sq, o, kWave);
+    __shared__ float wave_tot[kBlock];
+    wave_tot[threadIdx.x] = sq;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    // the logical workgroup: its four waves, in double, in order
+    constexpr int kPerBlock = kWavesPerBlock * G;                        // threads of a logical workgroup
+    if (threadIdx.x % kPerBlock == 0 && q < n_acc) {
         double t = 0.0;
 #pragma unroll
-        for (int k = 0; k < kWavesPerBlock; ++k) t += (double)part[k];
-        sse[blockIdx.x] = t;
+        for (int k = 0; k < kWavesPerBlock; ++k) t += (double)wave_tot[threadIdx.x + k * G];
+        sse[q / kPerBlock] = t;
     }
-    for (int t = gridDim.x + threadIdx.x; blockIdx.x == 0 && t < URE_SCORE_PARTIALS; t += kBlock) sse[t] = 0.0;
+    for (int t = blocks + (int)threadIdx.x; blockIdx.x == 0 && t < URE_SCORE_PARTIALS; t += kBlock) sse[t] = 0.0;
 }
 
 // (value, position) keys ordered lexicographically; "better" = later in a stable
@@ -613,18 +583,6 @@ static void launch_score_series(const float *U, const float *V, int64_t su, int6
                        uid, iid, rating, n, base, pred, sse);
 }
 
-template <int LPR>
-static void launch_score_series_compact(const float *snap, int64_t stride, const int32_t *row_slot, const float *U0, const float *V0, const float *snap_a,
-                                        int n_user_rows, int n_series, int nt, const int32_t *uid, const int32_t *iid, const float *rating, int64_t n,
-                                        const float *base, float *pred, double *sse, hipStream_t st)
-{
-    constexpr int G = kWave / LPR;
-    const int64_t waves = (n + G - 1) / G;
-    const unsigned blocks = (unsigned)std::min<int64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, URE_SCORE_PARTIALS);
-    hipLaunchKernelGGL(score_series_compact_kernel<LPR>, dim3(blocks ? blocks : 1, (unsigned)n_series), dim3(kBlock), 0, st, snap, stride, row_slot, U0, V0,
-                       snap_a, n_user_rows, nt, uid, iid, rating, n, base, pred, sse);
-}
-
 }  // namespace ure
 
 using namespace ure;
@@ -659,6 +617,8 @@ int ure_score(const float *const *U_tables, const float *const *V_tables, int n_
     return 0;
 }
 
+// (A wave keeping its user(s) for a run of 5 members of a series -- segment bounds and rating ranks fetched once -- was measured:
+// 69 -> 82 us per series call; a fifth of the waves hides less latency than the saved loads cost.  One member per wave.)
 static unsigned eval_user_blocks(int32_t n_users, int32_t n_wide)
 {
     const int64_t waves = (int64_t)n_wide + ((int64_t)(n_users - n_wide) + 3) / 4;
@@ -737,36 +697,13 @@ int ure_eval_series_compact(const float *const *U_fixed, const float *const *V_f
                             const int32_t *off, int32_t n_users, const double *log2_tab, float *base, float *pred, double *sse,
                             int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide, void *stream)
 {
-    URE_ARG(n_wide >= 0 && n_wide <= n_users);
-    URE_ARG(n_fixed >= 0 && (n_fixed == 0 || (U_fixed && V_fixed && base)) && snap && row_slot && U0 && V0 && snap_a && n_user_rows > 0 &&
-            stride >= 0 && n_series > 0 && n_series <= 65535);
-    URE_ARG(uid && iid && rating && n > 0 && pow2(d) && d >= 4 && d <= 256 && off && n_users >= 0 && log2_tab && pred && sse && hits &&
-            ndcg && out);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    for (int c0 = 0; c0 < n_fixed; c0 += URE_MAX_MODELS_PER_CALL) {
-        const int c = std::min(n_fixed - c0, URE_MAX_MODELS_PER_CALL);
-        if (int rc = ure_score(U_fixed + c0, V_fixed + c0, c, n_fixed + 1, c0 == 0, 0, uid, iid, rating, n, d, base, nullptr, stream)) return rc;
-    }
-    const float *b = n_fixed ? base : nullptr;
-    const int nt = n_fixed + 1;
-#define URE_SERIES_COMPACT(L) launch_score_series_compact<L>(snap, stride, row_slot, U0, V0, snap_a, n_user_rows, n_series, nt, uid, iid, rating, n, b, pred, sse, st)
-    switch (d / 4) {
-        case 1: URE_SERIES_COMPACT(1); break;
-        case 2: URE_SERIES_COMPACT(2); break;
-        case 4: URE_SERIES_COMPACT(4); break;
-        case 8: URE_SERIES_COMPACT(8); break;
-        case 16: URE_SERIES_COMPACT(16); break;
-        case 32: URE_SERIES_COMPACT(32); break;
-        case 64: URE_SERIES_COMPACT(64); break;
-        default: return fail(-1, "ure_eval_series_compact: unsupported d=%d", d);
-    }
-#undef URE_SERIES_COMPACT
-    if (n_users > 0)
-        hipLaunchKernelGGL(eval_users_kernel, dim3(eval_user_blocks(n_users, n_wide), (unsigned)n_series), dim3(kBlock), 0, st, off, n_users, n_wide,
-                           pred, rating, top_rating, log2_tab, hits, ndcg, n);
-    hipLaunchKernelGGL(eval_reduce_kernel, dim3((unsigned)n_series), dim3(1024), 0, st, hits, ndcg, n_users, sse, n, out);
-    URE_HIP(hipGetLastError());
-    return 0;
+    URE_ARG(snap && row_slot && U0 && V0 && snap_a && n_user_rows > 0 && stride >= 0 && n_series > 0 && n_series <= 65535);
+    URE_ARG(uid && iid && n > 0 && pow2(d) && d >= 4 && d <= 256 && pred);
+    // the members' own scores, all epochs of a pair together, into pred; then the fixed models, the division, the squared errors
+    // and the ranking exactly as ure_eval_series_own does them (in place)
+    if (int rc = ure_score_own_compact(snap, stride, row_slot, U0, V0, snap_a, n_user_rows, n_series, uid, iid, n, d, pred, stream)) return rc;
+    return ure_eval_series_own(U_fixed, V_fixed, n_fixed, pred, n_series, uid, iid, rating, n, d, off, n_users, log2_tab, base, pred, sse, hits, ndcg,
+                               out, top_rating, n_wide, stream);
 }
 
 int ure_score_own_compact(const float *snap, int64_t stride, const int32_t *row_slot, const float *U0, const float *V0, const float *snap_a,
@@ -779,9 +716,9 @@ int ure_score_own_compact(const float *snap, int64_t stride, const int32_t *row_
     do {                                                                                                                                \
         constexpr int G = kWave / L;                                                                                                    \
         const int64_t waves = (n + G - 1) / G;                                                                                          \
-        const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, URE_SCORE_PARTIALS)); \
-        hipLaunchKernelGGL(score_own_compact_kernel<L>, dim3(blocks, (unsigned)n_series), dim3(kBlock), 0, st, snap, stride, row_slot, U0, V0, snap_a,   \
-                           n_user_rows, uid, iid, n, own);                                                                              \
+        const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, 16384)); \
+        hipLaunchKernelGGL(score_own_epochs_kernel<L>, dim3(blocks), dim3(kBlock), 0, st, snap, stride, row_slot, U0, V0, snap_a, n_user_rows,          \
+                           n_series, uid, iid, n, own);                                                                                 \
     } while (0)
     switch (d / 4) {
         case 1: URE_OWN(1); break;
@@ -816,9 +753,10 @@ int ure_eval_series_own(const float *const *U_fixed, const float *const *V_fixed
     do {                                                                                                                                \
         constexpr int G = kWave / L;                                                                                                    \
         const int64_t waves = (n + G - 1) / G;                                                                                          \
-        const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, URE_SCORE_PARTIALS)); \
-        hipLaunchKernelGGL(series_combine_kernel<L>, dim3(blocks, (unsigned)n_series), dim3(kBlock), 0, st, own, n_fixed + 1, rating, n,              \
-                           n_fixed ? base : nullptr, pred, sse);                                                                        \
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, URE_SCORE_PARTIALS));   \
+        const unsigned phys = (unsigned)(((int64_t)blocks * kWavesPerBlock * G + kBlock - 1) / kBlock);                                 \
+        hipLaunchKernelGGL(series_combine_kernel<L>, dim3(phys, (unsigned)n_series), dim3(kBlock), 0, st, own, n_fixed + 1, rating, n,  \
+                           n_fixed ? base : nullptr, pred, sse, blocks);                                                                \
     } while (0)
     switch (d / 4) {
         case 1: URE_COMBINE(1); break;
