@@ -209,7 +209,7 @@ def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_st
     job, shards = None, []
     if mine:
         shards = [engine.ShardData(*parts[s], spec['n_user'], spec['n_item']) for s in mine]
-        job = engine.TrainJob(shards, inits, perms, d, batch, epochs, 1e-3, 0.1, 0.9, 0.95)
+        job = engine.TrainJob(shards, inits, perms, d, batch, epochs, 1e-3, 0.1, 0.9, 0.95, final_only=True)     # (as Sisa runs it: tables read at the end)
     del perms, parts
 
     if job is not None:

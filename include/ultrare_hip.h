@@ -127,7 +127,11 @@ typedef struct ure_shard {
      * epochs longer than 64 steps are worked off in windows of 64).
      * For jobs whose tables do not fit the caches (BASELINE.json configs[3], full MF at 25 M rows).  The
      * tables can then be read (ure_job_materialize, snapshots) at the shard's epoch boundaries only.   */
-    int32_t touch_mode;
+    int32_t touch_mode;     /* 0 off | 1 as above | 2 "masks one epoch ahead" (at most 63 steps per epoch, compact snapshots only): the
+                             * batch tags are prepared two epochs ahead (ent_tag then holds THREE buffers, [3][n_slots]), a row's owner
+                             * advances it across the epoch boundary at its last own step, and the dense pass at every epoch start of
+                             * mode 1 is gone; the tables are readable (ure_job_materialize) only once training has finished, epoch
+                             * ends through `snap`.  Same results as mode 1, bit for bit.                                        */
     /* touch mode: the first n_multi rows of the schedule are longer than one scan pass (8 * lanes slots)
      * and `units` covers exactly those; the rows [n_multi, n_active) fit in one pass and are worked off
      * from a per-step compaction of the rows that have interactions in the step.                  */

@@ -258,3 +258,65 @@ def test_touch_mode_windows_match_the_default_kernel_epoch_by_epoch():
         assert rel(U1, U0) < 1e-5 and rel(V1, V0) < 1e-5, e
     for j in jobs:
         j.close()
+
+
+# ---------------------------------------------------------------- touch_mode 2: masks one epoch ahead (round 3)
+@pytest.mark.parametrize('S,k,B,E', [(1, 16, 3000, 3), (3, 32, 700, 5), (2, 64, 1500, 53), (2, 128, 600, 2), (3, 8, 450, 4), (2, 16, 9000, 3)])
+def test_touch_ahead_mode_equals_mode_1_bit_for_bit(S, k, B, E):
+    """touch_mode 2 (no dense pass at the epoch starts: a row's owner carries it across the epoch boundary at its last step, with
+    the next epoch's masks built one epoch ahead from tags prepared two ahead) applies the same table entries to the same values as
+    mode 1, so the final tables, the training losses and every compact end-of-epoch snapshot agree to the last bit -- across the
+    StepLR boundary (E = 53), for shards whose epochs end on different ticks, with standalone tag preparation (B = 9000: two
+    steps per epoch, no riders) and with rows that have no step in an epoch (orphans).  And both agree with the C oracle."""
+    from ultrare_amd import engine
+    parts, inits, perms, shards = _setup(S, k, B, E)
+    if k > 64:
+        inits = [tuple(t * 0.3 for t in init) for init in inits]
+    jobs = {}
+    for ahead in (False, True):
+        job = engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=True, snapshots='compact', final_only=ahead)
+        assert job.touch and job.ahead == ahead
+        job.run()
+        jobs[ahead] = job
+    for s, p in enumerate(parts):
+        (U1, V1), (U2, V2) = jobs[False].tables(s), jobs[True].tables(s)
+        assert torch.equal(U1, U2) and torch.equal(V1, V2), s
+        assert torch.equal(jobs[False].state[s]['snap'], jobs[True].state[s]['snap']), s
+        assert np.array_equal(jobs[False].epoch_sse(s), jobs[True].epoch_sse(s))
+        if E <= 5:
+            st = O.MFState(inits[s][0].numpy().copy(), inits[s][1].numpy().copy())
+            for t in range(E):
+                O.train_epoch(st, p, perms[s][t].numpy(), B, 1e-3, 0.1, 0.9)
+            assert rel(U2, st.U) < 2e-5 and rel(V2, st.V) < 2e-5
+    for j in jobs.values():
+        j.close()
+
+
+def test_touch_ahead_mode_orphans_and_table_reads():
+    """Rows without a step in an epoch: with small batches out of a shard most light rows skip whole epochs (orphans), and are
+    carried over by launch B.  Tables cannot be read before the end in this mode; the snapshots can."""
+    from ultrare_amd import _native as nv
+    from ultrare_amd import engine
+    k, B, E = 16, 400, 4
+    parts, inits, perms, shards = _setup(2, k, B, E, seed=9)
+    # keep the first 1,500 interactions of each shard only: 4 steps per epoch, most rows idle in most epochs
+    from ultrare_amd import rng
+    parts = [tuple(x[:1500] for x in p) for p in parts]
+    shards = [engine.ShardData(*p, N_USER, N_ITEM) for p in parts]
+    torch.manual_seed(2)
+    perms = [rng.epoch_perms(rng.epoch_seeds(E, True), 1500) for _ in parts]
+    jobs = {a: engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=True, snapshots='compact', final_only=a) for a in (False, True)}
+    jobs[True].run(4)                                  # the end of epoch 0 of both shards (4 steps per epoch)
+    with pytest.raises(nv.NativeError, match='touch_mode 2'):
+        jobs[True].tables(0)
+    jobs[True].run()
+    jobs[False].run()
+    for s, p in enumerate(parts):
+        assert torch.equal(jobs[False].tables(s)[0], jobs[True].tables(s)[0]) and torch.equal(jobs[False].tables(s)[1], jobs[True].tables(s)[1])
+        assert torch.equal(jobs[False].state[s]['snap'], jobs[True].state[s]['snap'])
+        st = O.MFState(inits[s][0].numpy().copy(), inits[s][1].numpy().copy())
+        for t in range(E):
+            O.train_epoch(st, p, perms[s][t].numpy(), B, 1e-3, 0.1, 0.9)
+        assert rel(jobs[True].tables(s)[0], st.U) < 2e-5 and rel(jobs[True].tables(s)[1], st.V) < 2e-5
+    for j in jobs.values():
+        j.close()

@@ -67,6 +67,32 @@ __device__ __forceinline__ unsigned long long mask_below(int s) { return s >= 64
 __device__ __forceinline__ int mask_rank_parity(unsigned long long mk, int s) { return __popcll(mk & mask_below(s)) & 1; }
 
 // (w, m) <- P (w, m), P = {p11, p12, p21, p22}
+// touch_mode 2 -- MASKS ONE EPOCH AHEAD (epochs of at most 63 steps, tables read at the end of training only).
+// The dense pass that brings every row to its first step of a new epoch (launch C, part 2: 6 % of the device time at configs[3])
+// disappears when a row's owner knows, at its LAST step of epoch e, the row's first step of epoch e + 1: it then advances the row
+// across the boundary itself -- to the epoch's end with epoch e's table (that value is the end-of-epoch snapshot), on to the next first
+// step with epoch e + 1's.  For that the batch tags are prepared TWO epochs ahead (tag_prep.h: three tag buffers), and at the start
+// of epoch e launch B builds the masks of epoch e + 1 (row order + work order, by epoch parity) and hands the owners of epoch e each
+// row's next first step; launch C marks the buffer bits of epoch e + 1's tags.  A row's weights are no longer normalised into buffer 0
+// at an epoch start: bit 63 of its mask word says in which buffer they are when the epoch starts (cumulative parity of its steps).
+// Rows without a step in epoch e ("orphans": 2 % at configs[3]) are valid at the END of e; launch B of that epoch start carries them on
+// to their first step of e + 1 (and writes their snapshot of e).  Only the very first epoch needs the dense pass.
+// The arithmetic is that of mode 1 -- the same two table entries applied to the same values -- so both modes agree to the last bit.
+constexpr unsigned long long kStartBit = 1ull << 63;
+constexpr unsigned long long kStepBits = ~kStartBit;
+constexpr int kAheadMaxSteps = 63;
+constexpr int kNoNext = 255;
+
+struct AheadWork {              // the work-order arrays of one epoch parity
+    unsigned long long *unit_mask, *unit_own, *sched_mask;
+};
+__device__ __forceinline__ AheadWork ahead_work(const shard_aux &A, int parity)
+{
+    unsigned long long *b = A.ahead_masks[parity & 1];
+    return AheadWork{b, b + A.n_um, b + 2 * (size_t)A.n_um};
+}
+__device__ __forceinline__ int ahead_buffer_at(unsigned long long word, int s) { return (int)(word >> 63) ^ (__popcll(word & kStepBits & mask_below(s)) & 1); }
+
 template <int V4>
 __device__ __forceinline__ void row_advance(RowVec<V4> &w, RowVec<V4> &m, const float4 P)
 {
@@ -212,6 +238,123 @@ __device__ __forceinline__ void touch_mark_tags(const ure_shard_t &S, const shar
     }
 }
 
+// ---- touch_mode 2, launch B at the start of epoch e = e_next - 1 (and once more at tick 0 for e_next = 0): the masks of epoch e_next
+// from its tags, the owners' hand-over for epoch e, the orphans of epoch e.  has_next = false: there is no epoch e_next.
+template <int LPR, int V4>
+__device__ __forceinline__ void touch_ahead_build(const ure_shard_t &S, const shard_aux &A, int e_next, bool has_next, int wg, unsigned long long *wg_mask)
+{
+    constexpr int CAP = kSegPerLane * LPR;
+    constexpr int UPB = kBlock / LPR;
+    constexpr int D = LPR * V4 * 4;
+    int si, uw = 0;
+    const int4 pc = touch_piece<LPR>(S, wg, &si, &uw);
+    const bool in_units = wg < S.n_units / UPB;              // workgroup-uniform
+    const int sub = threadIdx.x & (LPR - 1);
+    const int local = (int)threadIdx.x / LPR;
+    unsigned long long mk = 0;
+    if (has_next && pc.x >= 0) {
+        const uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, e_next);
+        for (int p0 = pc.y + sub * kSegPerLane; p0 < pc.z; p0 += CAP) {
+            const uint4 t4 = ldg_u4(ent_tag + p0);
+            const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned st = (tw[k >> 1] >> ((k & 1) * 16)) & kTagStep;      // (padding slots read 0x7FFF)
+                if (st < (unsigned)kAheadMaxSteps) mk |= 1ull << st;
+            }
+        }
+    }
+    mk = group_or<LPR>(mk);
+    const unsigned long long own = mk;
+    bool row_leader = pc.x >= 0;
+    if (in_units) {
+        const int leader = uw & 0xFFFF, count = (uw >> 16) & 0x3FFF;
+        if (sub == 0) wg_mask[local] = mk;
+        __syncthreads();
+        if (pc.x >= 0 && sub == 0 && local == leader) {
+            unsigned long long all = mk;
+            for (int k = 1; k < count; ++k) all |= wg_mask[leader + k];
+            wg_mask[leader] = all;
+        }
+        __syncthreads();
+        if (pc.x >= 0) mk = wg_mask[leader];
+        row_leader = pc.x >= 0 && local == leader;
+    }
+    if (pc.x < 0) return;
+    // the row's word of the epoch that starts now (e = e_next - 1): where its weights are, and whether it has a step in e at all
+    const unsigned long long prev = e_next >= 1 ? ldg(A.mask[(e_next - 1) & 1] + pc.x) : 0ull;
+    const int start_e = (int)(prev >> 63);
+    const bool orphan = e_next >= 1 && (prev & kStepBits) == 0;
+    const unsigned long long start_next = e_next >= 1 ? (unsigned long long)(start_e ^ (__popcll(prev & kStepBits) & 1)) : 0ull;
+    const unsigned long long word = mk | (start_next << 63);
+    const int nf = mk ? __ffsll((long long)mk) - 1 : kNoNext;
+    if (sub == 0) {
+        const AheadWork W = ahead_work(A, e_next);
+        if (row_leader) stg(A.mask[e_next & 1] + pc.x, word);
+        if (in_units) {
+            stg(W.unit_mask + pc.w, word);
+            stg(W.unit_own + pc.w, own);
+            stg(A.unit_nf + pc.w, (uint8_t)nf);
+        } else {
+            stg(W.sched_mask + si, word);
+            stg(A.sched_nf + si, (uint8_t)nf);
+        }
+    }
+    // an orphan of epoch e is valid at the END of e (whoever advanced it last found no step in e): that value is its snapshot of e,
+    // and it is carried on to its first step of e_next (or to e_next's end) here, in place -- nobody gathers it during e
+    if (orphan && row_leader) {
+        const bool is_user = pc.x < S.n_user;
+        const size_t off = (size_t)(is_user ? pc.x : pc.x - S.n_user) * D;
+        float *wrow = (is_user ? S.U[start_e] : S.V[start_e]) + off, *mrow = (is_user ? S.mU : S.mV) + off;
+        RowVec<V4> w = row_load<LPR, V4>(wrow, sub), m = row_load<LPR, V4>(mrow, sub);
+        if (S.snap && S.row_slot) {
+            const int slot = ldg(S.row_slot + pc.x);
+            if (slot >= 0) row_store<LPR, V4>(S.snap + ((size_t)(e_next - 1) * S.n_active + slot) * D, sub, w);
+        }
+        if (has_next) {
+            const int gap = mk ? nf : A.steps;
+            if (gap > 0) {
+                row_advance<V4>(w, m, A.ptab[(size_t)e_next * kTouchTab + gap]);
+                row_store<LPR, V4>(wrow, sub, w);
+                row_store<LPR, V4>(mrow, sub, m);
+            }
+        }
+    }
+}
+
+// ---- touch_mode 2, launch C: bit 15 of every tag of epoch e_next = the buffer the slot's OTHER row is in at the slot's step
+template <int LPR>
+__device__ __forceinline__ void touch_ahead_mark(const ure_shard_t &S, const shard_aux &A, int e_next, int wg)
+{
+    constexpr int CAP = kSegPerLane * LPR;
+    int si;
+    const int4 pc = touch_piece<LPR>(S, wg, &si);
+    if (pc.x < 0) return;
+    const int sub = threadIdx.x & (LPR - 1);
+    const unsigned long long *__restrict__ masks = A.mask[e_next & 1];
+    uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, e_next);
+    const int other_base = pc.x < S.n_user ? S.n_user : 0;
+    for (int p0 = pc.y + sub * kSegPerLane; p0 < pc.z; p0 += CAP) {
+        const uint4 t4 = ldg_u4(ent_tag + p0);
+        const int4 o0 = ldg_i4(S.ent_oid + p0), o1 = ldg_i4(S.ent_oid + p0 + 4);
+        const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+        const int ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+        unsigned out[8];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned tg = (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            const unsigned st = tg & kTagStep;
+            out[k] = tg;
+            if (st < (unsigned)kAheadMaxSteps) {
+                out[k] = st | ((unsigned)ahead_buffer_at(ldg(masks + other_base + ov[k]), (int)st) << 15);
+                any = true;
+            }
+        }
+        if (any) stg_u4(ent_tag + p0, make_uint4(out[0] | (out[1] << 16), out[2] | (out[3] << 16), out[4] | (out[5] << 16), out[6] | (out[7] << 16)));
+    }
+}
+
 // ---- window start, launch C, part 2: every active row from "valid at the window boundary" (buffer = parity of
 // its number of steps in the window that ended) to "valid at its first step of this window", in buffer 0.
 // One lane per float4 of a row.
@@ -248,10 +391,11 @@ __device__ __forceinline__ void touch_advance_rows(const ure_shard_t &S, const s
 // count << 16 | multi << 30}, mk = the row's step mask, hit = the row is trained in step s (lane-group uniform).
 template <int LPR, int V4>
 __device__ __forceinline__ void touch_process(const ure_shard_t &S, const shard_aux &A, const int4 du, const unsigned long long mk, const bool hit,
-                                              const bool scan, const int local, const TouchPos &P, const float lr, int *qo, float *qr,
+                                              const bool scan, const int nf, const int local, const TouchPos &P, const float lr, int *qo, float *qr,
                                               float (*q_r)[kQueue], float4 (*part_acc)[V4][LPR])
 {
     const int epoch = P.epoch, s = P.s;
+    const bool ahead = S.touch_mode == 2;        // [mode 2] bit 63 of mk = the buffer at the epoch's start, nf = the row's first step of epoch + 1
     constexpr int D = LPR * V4 * 4;
     using Row = RowVec<V4>;
     constexpr int G = kWave / LPR;
@@ -262,7 +406,7 @@ __device__ __forceinline__ void touch_process(const ure_shard_t &S, const shard_
     const float lam = S.lam, mu = S.mu;
     const int32_t *__restrict__ ent_oid = S.ent_oid;
     const float *__restrict__ ent_r = S.ent_r;
-    const uint16_t *__restrict__ ent_tag = S.ent_tag + (size_t)(epoch & 1) * S.n_slots;
+    const uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, epoch);
     const int leader = du.w & 0xFFFF, count = (du.w >> 16) & 0x3FFF;
     const bool multi = (du.w >> 30) & 1;
     const bool owner = hit && local == leader;
@@ -270,7 +414,8 @@ __device__ __forceinline__ void touch_process(const ure_shard_t &S, const shard_
     const int row = is_user ? du.x : du.x - S.n_user;
     const size_t row_off = (size_t)(hit ? row : 0) * D;
     // [touch] the row's k-th step of the window reads buffer k & 1 (next-touch form: w is valid for THIS step)
-    const int buf = mask_rank_parity(mk, P.sl);
+    const unsigned long long step_bits = ahead ? mk & kStepBits : mk;
+    const int buf = ahead ? ahead_buffer_at(mk, P.sl) : mask_rank_parity(mk, P.sl);
     Row w = row_zero<V4>(), acc = w, m4 = w;
     float *mom = (is_user ? S.mU : S.mV) + row_off;
     if (hit) w = row_load<LPR, V4>((is_user ? S.U[buf] : S.V[buf]) + row_off, sub);
@@ -382,9 +527,21 @@ __device__ __forceinline__ void touch_process(const ure_shard_t &S, const shard_
         }
         // [touch] bring the row to its next own step of the window (or to the window's end): the steps in between
         // apply weight decay and momentum only, one 2x2 map for all of them
-        const unsigned long long rest = P.sl + 1 < 64 ? mk >> (P.sl + 1) : 0ull;
+        const unsigned long long rest = P.sl + 1 < 64 ? step_bits >> (P.sl + 1) : 0ull;
         const int gap = rest ? __ffsll((long long)rest) - 1 : P.wlen - 1 - P.sl;
         if (gap > 0) row_advance<V4>(nr, gr2, A.ptab[(size_t)epoch * kTouchTab + gap]);
+        if (ahead && !rest) {
+            // [mode 2] the row's last step of the epoch: nr is now valid at the epoch's end -- its snapshot -- and goes on to its first
+            // step of the next epoch (none there: to that epoch's end, where launch B of its start picks it up as an orphan)
+            if (S.snap && S.row_slot) {
+                const int slot = ldg(S.row_slot + du.x);
+                if (slot >= 0) row_store<LPR, V4>(S.snap + ((size_t)epoch * S.n_active + slot) * D, sub, nr);
+            }
+            if (epoch + 1 < S.epochs) {
+                const int g2 = nf != kNoNext ? nf : A.steps;
+                if (g2 > 0) row_advance<V4>(nr, gr2, A.ptab[(size_t)(epoch + 1) * kTouchTab + g2]);
+            }
+        }
         row_store<LPR, V4>(mom, sub, gr2);
         row_store<LPR, V4>((is_user ? S.U[buf ^ 1] : S.V[buf ^ 1]) + row_off, sub, nr);
         if (is_user && sub == 0 && sse != 0.f) {
@@ -438,24 +595,33 @@ __device__ __forceinline__ void mf_touch_step(const ure_shard_t *__restrict__ sh
     const int nbU = S.n_units / UPB;
     const int n_single = S.n_active - S.n_multi;
     const int nbC = (n_single + kBlock - 1) / kBlock;
+    const bool ahead = S.touch_mode == 2;
+    // the masks in work order: mode 1 one set (the current window's), mode 2 one per epoch parity
+    const unsigned long long *__restrict__ unit_mask = A.unit_mask, *__restrict__ unit_own = A.unit_own, *__restrict__ sched_mask = A.sched_mask;
+    if (ahead) {
+        const AheadWork W = ahead_work(A, epoch);
+        unit_mask = W.unit_mask; unit_own = W.unit_own; sched_mask = W.sched_mask;
+    }
     if (wg < nbU) {
         // ---- multi-pass rows: the unit's mask sits next to its descriptor (no dependent load)
         const size_t u = (size_t)wg * UPB + local;
         const int4 du = ldg_i4(S.units + 4 * u);
-        const unsigned long long mk = ldg(A.unit_mask + u);
-        const unsigned long long own = ldg(A.unit_own + u);
+        const unsigned long long mk = ldg(unit_mask + u);
+        const unsigned long long own = ldg(unit_own + u);
+        const int nf = ahead ? (int)ldg(A.unit_nf + u) : 0;
         const bool hit = du.x >= 0 && ((mk >> P.sl) & 1ull);
         const bool multi = (du.w >> 30) & 1;
         if (!multi && !__any(hit)) return;
-        touch_process<LPR, V4>(S, A, du, mk, hit, (own >> P.sl) & 1ull, local, P, lr, qo, qr, q_r, part_acc);
+        touch_process<LPR, V4>(S, A, du, mk, hit, (own >> P.sl) & 1ull, nf, local, P, lr, qo, qr, q_r, part_acc);
         return;
     }
     if (wg < nbU + nbC) {
         // ---- candidates: one lane per row finds out whether the row is trained in this step ...
         const int rel = (wg - nbU) * kBlock + (int)threadIdx.x;
         // (the schedule entry is requested with the mask, not after it: one memory level, and both reads are coalesced)
-        const unsigned long long mk = rel < n_single ? ldg(A.sched_mask + rel) : 0ull;
-        const int4 sc = rel < n_single ? ldg_i4(S.sched + 4 * (size_t)(S.n_multi + rel)) : make_int4(-1, 0, 0, 0);
+        const unsigned long long mk = rel < n_single ? ldg(sched_mask + rel) : 0ull;
+        int4 sc = rel < n_single ? ldg_i4(S.sched + 4 * (size_t)(S.n_multi + rel)) : make_int4(-1, 0, 0, 0);
+        if (ahead && rel < n_single) sc.w = (int)ldg(A.sched_nf + rel);      // [mode 2] the row's first step of the next epoch rides with its entry
         const bool hit = (mk >> P.sl) & 1ull;
         const unsigned long long vote = __ballot(hit);
         if (lane == 0) cand_count[wave] = __popcll(vote);
@@ -480,18 +646,20 @@ __device__ __forceinline__ void mf_touch_step(const ure_shard_t *__restrict__ sh
             int4 du = make_int4(-1, 0, 0, 0);
             unsigned long long rm = 0ull;
             if (have) { du = cand_row[e]; rm = cand_mask[e]; }
+            const int nf = du.w;
             du.w = local | (1 << 16);                          // its own leader, one unit, no partial sums to combine
-            touch_process<LPR, V4>(S, A, du, rm, have, true, local, P, lr, qo, qr, q_r, part_acc);
+            touch_process<LPR, V4>(S, A, du, rm, have, true, nf, local, P, lr, qo, qr, q_r, part_acc);
         }
         return;
     }
     // ---- the tag riders of the next epoch, as in mf_step
-    const TagRide ride = tag_ride(A, s, epoch + 1 < S.epochs);
+    const int tgt = epoch + tag_ahead(S);                  // the epoch whose tags this one's steps prepare
+    const TagRide ride = tag_ride(A, s, tgt < S.epochs);
     const int rb = wg - nbU - nbC;
     if (rb >= ride.count) return;
-    if (ride.phase == 0) tag_partition(S, epoch + 1, ride.first + rb, lds_raw);
+    if (ride.phase == 0) tag_partition(S, tgt, ride.first + rb, lds_raw);
     else if (ride.phase == 1) tag_collect(S, ride.first + rb, lds_raw);
-    else tag_derive(S, epoch + 1, ride.first + rb, A.derive_blocks);
+    else tag_derive(S, tgt, ride.first + rb, A.derive_blocks);
 }
 
 // ---- reading the tables at an epoch boundary of the shard: the active rows' current w sits in the buffer
@@ -504,7 +672,8 @@ __device__ __forceinline__ void touch_collect_rows(const ure_shard_t &S, const s
     for (int64_t t = (int64_t)blk * kBlock + threadIdx.x; t < total; t += (int64_t)n_blk * kBlock) {
         const int idx = (int)(t / d4), c4 = (int)(t % d4);
         const int row_id = ldg(S.sched + 4 * (size_t)idx);
-        const int from = last_epoch < 0 ? 0 : (__popcll(ldg(mk + row_id)) & 1);
+        const unsigned long long word = last_epoch < 0 ? 0ull : ldg(mk + row_id);
+        const int from = last_epoch < 0 ? 0 : (S.touch_mode == 2 ? ahead_buffer_at(word, 64) : (__popcll(word) & 1));
         if (from == cur) continue;
         const bool is_user = row_id < S.n_user;
         const size_t o = (size_t)(is_user ? row_id : row_id - S.n_user) * S.d + (size_t)c4 * 4;

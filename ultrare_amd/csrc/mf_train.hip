@@ -405,7 +405,7 @@ __global__ __launch_bounds__(kBlock) void snapshot_kernel(const ure_shard_t *__r
     const unsigned long long *__restrict__ row_mask = nullptr;
     const bool compact = S.snap != nullptr;
     if (!compact && (!S.snapU || !S.snapV)) return;
-    if (compact && !S.touch_mode && S.row_slot) return;                 // written by the step kernel's owners
+    if (compact && S.touch_mode != 1 && S.row_slot) return;             // written by the step kernel's owners (touch_mode 2: and launch B)
     const int steps = shard_steps(S);
     if (ticks_done > (int64_t)steps * S.epochs || ticks_done % steps != 0) return;   // only at an epoch end of this shard
     const int epoch = (int)(ticks_done / steps) - 1;
@@ -504,6 +504,33 @@ __global__ __launch_bounds__(kBlock) void touch_prep_kernel(const ure_shard_t *_
     else touch_advance_rows(S, A, P, (int)blockIdx.x - piece_blocks, (int)gridDim.x - piece_blocks);
 }
 
+// touch_mode 2 (mf_touch.h): the two launches of an epoch start.  PHASE 1 = launch B (masks of the next epoch, hand-over to the owners,
+// orphans), PHASE 2 = launch C (buffer bits of the next epoch's tags).  boot = 1 (tick 0 only): the same for epoch 0 itself, whose
+// launch C also carries the one dense pass of the job (every row from the initial tables to its first step).
+template <int LPR, int V4, int PHASE>
+__global__ __launch_bounds__(kBlock) void touch_ahead_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, int boot,
+                                                             int piece_blocks)
+{
+    __shared__ unsigned long long wg_mask[kBlock];
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    if (tick >= (int64_t)A.steps * S.epochs) return;
+    const int epoch = (int)epoch_of(A, tick);
+    if (tick != (int64_t)epoch * A.steps) return;                       // not an epoch start of this shard
+    const int e_next = boot ? 0 : epoch + 1;
+    const bool has_next = e_next < S.epochs;
+    const int n_pieces = touch_piece_blocks<LPR>(S.n_units, S.n_active, S.n_multi);
+    if (PHASE == 1) {
+        if ((int)blockIdx.x < n_pieces) touch_ahead_build<LPR, V4>(S, A, e_next, has_next, (int)blockIdx.x, wg_mask);
+        return;
+    }
+    if ((int)blockIdx.x < piece_blocks) {
+        if (has_next && (int)blockIdx.x < n_pieces) touch_ahead_mark<LPR>(S, A, e_next, (int)blockIdx.x);
+    } else if (boot) {
+        touch_advance_rows(S, A, touch_pos(A, 0, 0), (int)blockIdx.x - piece_blocks, (int)gridDim.x - piece_blocks);
+    }
+}
+
 // Tables read at `ticks_done`: a shard must stand at one of its epoch boundaries (or have finished).
 __global__ __launch_bounds__(kBlock) void touch_collect_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t ticks_done)
 {
@@ -519,9 +546,25 @@ static bool touch_prep_needed(const ure_job *job, int64_t tick)
     if (!job->touch) return false;
     for (size_t k = 0; k < job->host.size(); ++k) {
         const int64_t steps = job->aux_host[k].steps;
-        if (tick < steps * job->host[k].epochs && (tick % steps) % kTouchWindow == 0) return true;
+        if (tick < steps * job->host[k].epochs && (tick % steps) % kTouchWindow == 0) return true;      // (mode 2: steps <= 63, one window)
     }
     return false;
+}
+
+// touch_mode 2: the launches of an epoch start (after the tags of the next epoch are complete)
+template <int LPR, int V4>
+static void launch_touch_ahead(const ure_job *job, int64_t tick, hipStream_t st)
+{
+    const unsigned n_sh = (unsigned)job->host.size();
+    int pieces = 1;
+    for (const ure_shard_t &S : job->host) pieces = std::max(pieces, touch_piece_blocks<LPR>(S.n_units, S.n_active, S.n_multi));
+    const unsigned adv_b = (unsigned)std::max<int64_t>(1, std::min<int64_t>((job->max_active4 + kBlock - 1) / kBlock, 8192));
+    if (tick == 0) {
+        hipLaunchKernelGGL((touch_ahead_kernel<LPR, V4, 1>), dim3((unsigned)pieces, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, 1, pieces);
+        hipLaunchKernelGGL((touch_ahead_kernel<LPR, V4, 2>), dim3((unsigned)pieces + adv_b, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, 1, pieces);
+    }
+    hipLaunchKernelGGL((touch_ahead_kernel<LPR, V4, 1>), dim3((unsigned)pieces, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, 0, pieces);
+    hipLaunchKernelGGL((touch_ahead_kernel<LPR, V4, 2>), dim3((unsigned)pieces, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, 0, pieces);
 }
 
 // the two launches of a window start in touch mode (an epoch start: after the epoch's batch tags are complete)
@@ -552,7 +595,7 @@ static void launch_step(const ure_job *job, int64_t tick, hipStream_t st)
         const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
         if (tick >= steps * S.epochs) continue;
         const int64_t epoch = tick / steps;
-        blocks = std::max(blocks, job->row_blocks[k] + tag_ride(job->aux_host[k], (int)(tick - epoch * steps), epoch + 1 < S.epochs).count);
+        blocks = std::max(blocks, job->row_blocks[k] + tag_ride(job->aux_host[k], (int)(tick - epoch * steps), epoch + tag_ahead(S) < S.epochs).count);
     }
     int shard_fast = job->shard_fast && blocks <= 65535;
     const unsigned n_sh = (unsigned)job->host.size();
@@ -626,10 +669,16 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
     for (int k = 0; k < n_shards; ++k) job->aux_host.push_back(make_shard_aux(shards[k]));
     // ---- touch mode: all shards of the job or none; masks and closed-form tables are library-owned
     for (int k = 0; k < n_shards; ++k) job->touch = job->touch || shards[k].touch_mode != 0;
+    job->ahead = shards[0].touch_mode == 2;
     if (job->touch) {
         for (int k = 0; k < n_shards; ++k) {
             const ure_shard_t &S = shards[k];
             const char *why = !S.touch_mode ? "every shard of a job must ask for it" :
+                              (S.touch_mode != 1 && S.touch_mode != 2) ? "touch_mode is 0, 1 or 2" :
+                              S.touch_mode != shards[0].touch_mode ? "every shard of a job must ask for the same touch mode" :
+                              (S.touch_mode == 2 && job->aux_host[k].steps > kAheadMaxSteps) ? "touch_mode 2 takes at most 63 steps per epoch (the mask word's top bit is the start buffer)" :
+                              (S.touch_mode == 2 && (S.snapU || S.snapV)) ? "touch_mode 2 writes compact snapshots only (snap + row_slot)" :
+                              (S.touch_mode == 2 && S.snap && !S.row_slot) ? "touch_mode 2 needs row_slot with snap" :
                               !S.lazy_rows ? "it needs lazy_rows" :
                               job->aux_host[k].steps > kTouchMaxSteps ? "more than 32000 steps per epoch (the step number shares the 16-bit batch tag with the buffer bit)" :
                               (S.epochs != shards[0].epochs || S.lam != shards[0].lam || S.mu != shards[0].mu ||
@@ -684,6 +733,25 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             job->aux_host[k].unit_mask = static_cast<unsigned long long *>(wm);
             job->aux_host[k].unit_own = static_cast<unsigned long long *>(wm) + n_um;
             job->aux_host[k].sched_mask = static_cast<unsigned long long *>(wm) + 2 * n_um;
+            job->aux_host[k].n_um = (int32_t)n_um;
+            job->aux_host[k].n_sm = (int32_t)n_sm;
+            if (job->ahead) {
+                // touch_mode 2: the work-order masks once per epoch parity (the first set is the one above), and the owners' hand-over
+                void *wm2 = nullptr, *nf = nullptr;
+                e = hipMalloc(&wm2, (2 * n_um + n_sm) * sizeof(unsigned long long));
+                if (e != hipSuccess) break;
+                job->touch_mem.push_back(wm2);
+                e = hipMemset(wm2, 0, (2 * n_um + n_sm) * sizeof(unsigned long long));
+                if (e != hipSuccess) break;
+                e = hipMalloc(&nf, n_um + n_sm);
+                if (e != hipSuccess) break;
+                job->touch_mem.push_back(nf);
+                e = hipMemset(nf, 0xFF, n_um + n_sm);
+                job->aux_host[k].ahead_masks[0] = static_cast<unsigned long long *>(wm);
+                job->aux_host[k].ahead_masks[1] = static_cast<unsigned long long *>(wm2);
+                job->aux_host[k].unit_nf = static_cast<uint8_t *>(nf);
+                job->aux_host[k].sched_nf = static_cast<uint8_t *>(nf) + n_um;
+            }
         }
     }
     if (e == hipSuccess) e = hipMalloc(&job->dev_aux, sizeof(shard_aux) * n_shards);
@@ -733,12 +801,25 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
     for (int64_t t = tick0; t < tick1; ++t) {
         // batch tags: the step kernel prepares the next epoch's itself (riders); epoch 0, shards with
         // fewer than 3 steps per epoch and very large shards get standalone launches here
-        if (tag_prep_needed(job, t)) {
+        if (const int passes = tag_prep_needed(job, t)) {
             if (int rc = mark(assign_ev)) return rc;
-            launch_tag_prep(job, t, st);
+            if (passes & 1) launch_tag_prep(job, t, st, 0);
+            if (passes & 2) launch_tag_prep(job, t, st, 1);
             if (int rc = mark(assign_ev)) return rc;
         }
-        if (touch_prep_needed(job, t)) {
+        if (job->ahead && touch_prep_needed(job, t)) {
+            if (int rc = mark(assign_ev)) return rc;
+            switch (job->d) {
+                case 4: launch_touch_ahead<1, 1>(job, t, st); break;
+                case 8: launch_touch_ahead<2, 1>(job, t, st); break;
+                case 16: launch_touch_ahead<4, 1>(job, t, st); break;
+                case 32: launch_touch_ahead<lanes_per_row(32), 32 / (4 * lanes_per_row(32))>(job, t, st); break;
+                case 64: launch_touch_ahead<8, 2>(job, t, st); break;
+                case 128: launch_touch_ahead<16, 2>(job, t, st); break;
+                default: launch_touch_ahead<32, 2>(job, t, st); break;
+            }
+            if (int rc = mark(assign_ev)) return rc;
+        } else if (touch_prep_needed(job, t)) {
             if (int rc = mark(assign_ev)) return rc;
             switch (lanes_per_row(job->d)) {
                 case 1: launch_touch_prep<1>(job, t, st); break;
@@ -766,7 +847,7 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
             bool epoch_end = false;
             for (const ure_shard_t &S : job->host) {
                 const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
-                const bool by_kernel = S.snapU || (S.snap && (S.touch_mode || !S.row_slot));      // otherwise the step kernel's owners wrote it
+                const bool by_kernel = S.snapU || (S.snap && (S.touch_mode == 1 || !S.row_slot));      // otherwise the step kernel's owners wrote it
                 if (by_kernel && t + 1 <= steps * S.epochs && (t + 1) % steps == 0) { epoch_end = true; break; }
             }
             if (epoch_end)
@@ -790,6 +871,8 @@ int ure_job_materialize(ure_job_t *j, int64_t ticks_done, void *stream)
             const int64_t steps = job->aux_host[k].steps;
             const int64_t T = std::min(ticks_done, steps * job->host[k].epochs);
             if (T % steps != 0) return fail(-1, "ure_job_materialize: touch mode: shard %d is inside an epoch at tick %lld (tables are readable at its epoch boundaries only)", (int)k, (long long)ticks_done);
+            if (job->ahead && T != 0 && T != steps * job->host[k].epochs)
+                return fail(-1, "ure_job_materialize: touch_mode 2: shard %d has not finished at tick %lld (rows are kept valid for their next step across epoch boundaries: tables are readable at the end of training, epoch ends through the compact snapshots)", (int)k, (long long)ticks_done);
         }
         const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((job->max_active4 + kBlock - 1) / kBlock, 8192));
         hipLaunchKernelGGL(touch_collect_kernel, dim3(blocks, (unsigned)n), dim3(kBlock), 0, st, job->dev, job->dev_aux, ticks_done);
@@ -835,7 +918,7 @@ int ure_job_touch_rows(ure_job_t *j, int64_t *pairs, int64_t *window_steps)
         host.resize((size_t)S.n_user + S.n_item);
         URE_HIP(hipMemcpy(host.data(), A.mask[(epoch * A.windows + win) & 1], host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         int64_t n = 0;
-        for (unsigned long long m : host) n += __builtin_popcountll(m);
+        for (unsigned long long m : host) n += __builtin_popcountll(job->ahead ? m & ~(1ull << 63) : m);
         pairs[k] = n;
         window_steps[k] = std::min<int64_t>(kTouchWindow, steps - win * kTouchWindow);
     }

@@ -151,12 +151,18 @@ __device__ inline void tag_collect(const ure_shard_t &S, int r, char *lds)
     for (int t = tid; t < kRange && j0 + t < n; t += kBlock) stg(file_tag + j0 + t, img[t]);
 }
 
+// Which half (third) of ent_tag holds an epoch's tags, and how far ahead of training they are prepared.  touch_mode 2 (mf_touch.h,
+// "masks one epoch ahead") needs the tags of epoch e + 1 complete when epoch e starts: they are prepared TWO epochs ahead, in three
+// buffers.  Everything else: one epoch ahead, two buffers.
+__host__ __device__ inline int tag_ahead(const ure_shard_t &S) { return S.touch_mode == 2 ? 2 : 1; }
+__host__ __device__ inline size_t tag_buffer(const ure_shard_t &S, int epoch) { return (size_t)(S.touch_mode == 2 ? epoch % 3 : (epoch & 1)) * (size_t)S.n_slots; }
+
 // Phase C, workgroup `blk` of `n_blk` (256 threads, eight slots per thread).
 __device__ inline void tag_derive(const ure_shard_t &S, int epoch, int blk, int n_blk)
 {
     const int32_t *__restrict__ ent_src = S.ent_src;
     const uint16_t *__restrict__ file_tag = S.file_tag;
-    uint16_t *__restrict__ ent_tag = S.ent_tag + (size_t)(epoch & 1) * S.n_slots;
+    uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, epoch);
     const int64_t n8 = S.n_slots / 8;
     for (int64_t q = (int64_t)blk * kBlock + threadIdx.x; q < n8; q += (int64_t)n_blk * kBlock) {
         const int4 s0 = ldg_i4(ent_src + q * 8);
@@ -189,6 +195,11 @@ struct shard_aux {
     const float4 *ptab;            // [epochs][65] A_e^j = {p11, p12, p21, p22}: j optimizer steps without a gradient at epoch e's lr
     unsigned long long *unit_mask; // [n_units] the current window's mask of each work unit's row
     unsigned long long *unit_own;  // [n_units] the steps of the window in which the UNIT's own slots have interactions (a subset of its row's)
+    // touch_mode 2 ("masks one epoch ahead"): the three work-order arrays once per epoch parity (an epoch's are written at the start of
+    // the epoch before it), and for the owners of the current epoch the row's first own step of the NEXT epoch (255: none)
+    unsigned long long *ahead_masks[2];   // [2 n_um + n_sm] each: unit_mask | unit_own | sched_mask
+    uint8_t *unit_nf, *sched_nf;          // [n_um], [n_sm]
+    int32_t n_um, n_sm;
     unsigned long long *sched_mask;// [n_active - n_multi] the same for the single-pass rows, in schedule order
 };
 

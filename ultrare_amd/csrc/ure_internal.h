@@ -63,6 +63,7 @@ struct ure_job {
     unsigned snap_blocks = 1;
     int64_t max_lazy = 0;                              // float4 slices of lazily advanced rows, max over shards
     bool touch = false;                                // touch mode (mf_touch.h): all shards of the job or none
+    bool ahead = false;                                // touch_mode 2 (masks one epoch ahead): all shards of the job or none
     std::vector<void *> touch_mem;                     // library-owned device memory of touch mode (masks, tables)
     int max_units = 0;                                 // work units of the largest shard
     int64_t max_active4 = 0;                           // float4 slices of active rows, max over shards
@@ -70,8 +71,8 @@ struct ure_job {
 };
 
 // tag_prep.hip: standalone per-epoch tag preparation (the step kernel carries the common case)
-bool tag_prep_needed(const ure_job *job, int64_t tick);
-void launch_tag_prep(const ure_job *job, int64_t tick, hipStream_t st);
+int tag_prep_needed(const ure_job *job, int64_t tick);                       // bit mask of the standalone passes needed (tag_prep.hip)
+void launch_tag_prep(const ure_job *job, int64_t tick, hipStream_t st, int pass);
 
 // Global-memory accessors.  A pointer that a kernel reads out of a descriptor in memory (struct
 // ure_shard) has no address space the compiler can see, so a plain dereference becomes a flat_*

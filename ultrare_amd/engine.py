@@ -27,6 +27,7 @@ SERIES_SCRATCH_BYTES = 256 << 20     # prediction scratch of one ure_eval_series
 LAZY_ROWS = os.environ.get('URE_LAZY_ROWS', '1') != '0'
 TOUCH_MAX_STEPS = 32000              # kTouchMaxSteps of csrc/mf_touch.h (epochs longer than 64 steps run in windows of 64)
 EARLY_SCORE_EPOCHS = 8               # TrainJob.early_scores: epochs per batch handed to the second stream
+TOUCH_AHEAD_MAX_STEPS = 63           # kAheadMaxSteps of csrc/mf_touch.h
 TOUCH_MIN_TABLE_BYTES = 256 << 20    # auto rule: the job's live rows (w, m, second buffer) exceed the Infinity Cache
 
 
@@ -137,7 +138,7 @@ def build_shards(triples, n_user, n_item, device=None, keep_positions=False):
     for s in range(S):
         blob[d_off[s]:d_off[s] + used[s]].copy_(stage[off[s]:off[s] + used[s]], non_blocking=pinned)
     # engine-side scratch: batch tags (0xFFFF matches no batch) and the stages of the inverse permutation
-    t_words = [(al(2 * int(k)), al(len(c[0]))) for k, c in zip(n_slots, cols)]
+    t_words = [(al(3 * int(k)), al(len(c[0]))) for k, c in zip(n_slots, cols)]       # three tag buffers (touch_mode 2 prepares two epochs ahead)
     z_words = [(al(len(c[0])), al(max(((len(c[0]) + 2047) // 2048) * ((len(c[0]) + 2047) // 2048 + 1), 1) if (len(c[0]) + 2047) // 2048 <= 1024 else 1))
                for c in cols]
     tags = torch.full((sum(a + b for a, b in t_words),), -1, dtype=torch.int16, device=dev)
@@ -161,7 +162,7 @@ def build_shards(triples, n_user, n_item, device=None, keep_positions=False):
                                   np.ascontiguousarray(rating, dtype=np.float32), n_user, n_item, want_pos=True)
             sh.u_pos, sh.i_pos = lay['u_pos'], lay['i_pos']
         a, b = t_words[s]
-        sh.ent_tag = tags[t_at:t_at + 2 * k].view(2, k)
+        sh.ent_tag = tags[t_at:t_at + 3 * k].view(3, k)
         sh.file_tag = tags[t_at + a:t_at + a + n]
         t_at += a + b
         a, b = z_words[s]
@@ -262,7 +263,7 @@ class TrainJob:
     """
 
     def __init__(self, shards, inits, perms, k, batch, epochs, lr, lam, momentum, lr_decay=1.0, lr_step=50, lazy_rows=None, snapshots=False,
-                 touch=None):
+                 touch=None, final_only=False):
         assert len(shards) == len(inits) == len(perms) and len(shards) > 0
         self.shards, self.k, self.d = shards, int(k), pad_dim(int(k))
         self.batch, self.epochs = int(batch), int(epochs)
@@ -283,6 +284,10 @@ class TrainJob:
             live = sum(sh.n_active for sh in shards) * self.d * 12
             touch = (env == '1') or (env == 'auto' and live > TOUCH_MIN_TABLE_BYTES)
         self.touch = bool(touch) and self.lazy_rows and max(steps_all) <= TOUCH_MAX_STEPS
+        # touch_mode 2 (csrc/mf_touch.h, "masks one epoch ahead"): no dense pass at the epoch starts; for callers that read the tables
+        # only after the last epoch (final_only) and epochs of at most 63 steps.  URE_TOUCH_AHEAD=0 keeps mode 1.
+        self.ahead = (self.touch and bool(final_only) and max(steps_all) <= TOUCH_AHEAD_MAX_STEPS and snapshots in (False, None, 'compact')
+                      and os.environ.get('URE_TOUCH_AHEAD', '1') != '0')
         # end-of-epoch snapshots: 'compact' keeps the n_active rows with interactions only (every other row is a_e * w0 and is
         # rebuilt where it is read: ure_eval_series_compact; needs lazy_rows), True / 'full' keeps complete tables
         self.snapshots = ('compact' if self.lazy_rows else 'full') if snapshots == 'compact' else ('full' if snapshots else False)
@@ -350,7 +355,7 @@ class TrainJob:
             D.N, D.n_user, D.n_item, D.d = sh.N, sh.n_user, sh.n_item, self.d
             D.batch, D.epochs = self.batch, self.epochs
             D.lam, D.mu = float(lam), float(momentum)
-            D.touch_mode = int(self.touch)
+            D.touch_mode = (2 if self.ahead else 1) if self.touch else 0
             if self.snapshots:
                 snap_a = small[1 + s]
                 self.state[-1].update(snap_a=snap_a)
@@ -396,7 +401,7 @@ class TrainJob:
                 # the launches of tick t read the permutation of the epoch AFTER the one a shard is in (the batch tags are
                 # prepared one epoch ahead): wait for the chunk that holds it, and launch only up to where the next one is needed
                 min_steps = min(self.steps_per_epoch(s) for s in range(len(self.shards)))
-                need = self.done // min_steps + 1                       # newest epoch any shard can read at tick self.done
+                need = self.done // min_steps + (2 if self.ahead else 1)  # newest epoch any shard can read at tick self.done
                 st = stream if stream is not None else torch.cuda.current_stream(self.device)
                 horizon = self.epochs
                 def wait(chunk):                                        # host: until the worker queued the upload; device: until it is done
@@ -419,7 +424,7 @@ class TrainJob:
                             ch.pop(0)
                 self._chunks = [ch for ch in self._chunks if ch]
                 if horizon < self.epochs:
-                    t_next = min(t_next, max(self.done + 1, (horizon - 1) * min_steps))
+                    t_next = min(t_next, max(self.done + 1, (horizon - (2 if self.ahead else 1)) * min_steps))
             nv.check(nv.lib().ure_job_train(self._job, self.done, t_next, nv.stream_handle(stream)), 'ure_job_train')
             self.done = t_next
             if getattr(self, '_early', None):

@@ -266,7 +266,8 @@ class Sisa(Scratch):
             batch = as_loader(train_dlist[mine[0]]).batch_size
             job = engine.TrainJob([prepared[i][0] for i in mine], [prepared[i][1] for i in mine],
                                   [prepared[i][2] for i in mine], self.k, batch, self.epochs, self.lr, self.lam,
-                                  self.momentum, self.lr_decay, snapshots=snap_mode if keep_logs else False)
+                                  self.momentum, self.lr_decay, snapshots=snap_mode if keep_logs else False,
+                                  final_only=True)       # (the tables are read once, after the last epoch)
             from .. import rng
             engine.mark('job_created')
             # the per-epoch test series of every shard (scratch.py:83-97).  URE_EARLY_SCORES=1: the shard's own half is scored on a
