@@ -75,8 +75,9 @@ __device__ __forceinline__ int mask_rank_parity(unsigned long long mk, int s) { 
 // of epoch e launch B builds the masks of epoch e + 1 (row order + work order, by epoch parity) and hands the owners of epoch e each
 // row's next first step; launch C marks the buffer bits of epoch e + 1's tags.  A row's weights are no longer normalised into buffer 0
 // at an epoch start: bit 63 of its mask word says in which buffer they are when the epoch starts (cumulative parity of its steps).
-// Rows without a step in epoch e ("orphans": 2 % at configs[3]) are valid at the END of e; launch B of that epoch start carries them on
-// to their first step of e + 1 (and writes their snapshot of e).  Only the very first epoch needs the dense pass.
+// A row without a step in epoch e (an "orphan": only a permutation that misses interactions leaves one -- every interaction trains once
+// per epoch) is valid at the END of e; launch B of that epoch start carries it on to its first step of e + 1 (and writes its snapshot of e).
+// Only the very first epoch needs the dense pass.
 // The arithmetic is that of mode 1 -- the same two table entries applied to the same values -- so both modes agree to the last bit.
 constexpr unsigned long long kStartBit = 1ull << 63;
 constexpr unsigned long long kStepBits = ~kStartBit;
@@ -320,6 +321,78 @@ __device__ __forceinline__ void touch_ahead_build(const ure_shard_t &S, const sh
             }
         }
     }
+}
+
+// ---- the same for 256 single-pass rows of at most 8 slots each ("tiny": 73 % of the rows of a configs[3] shard), ONE LANE per row
+// instead of a lane group: the schedule entries, the tags and the work-order stores of consecutive lanes are consecutive in memory,
+// and a wavefront covers 64 rows where it covered 64 / LPR.  rel0 = the first row's place among the single-pass rows.
+template <int V4LPR>
+__device__ __forceinline__ void touch_ahead_build_tiny(const ure_shard_t &S, const shard_aux &A, int e_next, bool has_next, int rel0)
+{
+    const int rel = rel0 + (int)threadIdx.x;
+    if (rel >= S.n_active - S.n_multi) return;
+    const int4 sc = ldg_i4(S.sched + 4 * (size_t)(S.n_multi + rel));           // {row id, first slot, end slot (= first + 8), nnz}
+    unsigned long long mk = 0;
+    if (has_next) {
+        const uint4 t4 = ldg_u4(S.ent_tag + tag_buffer(S, e_next) + sc.y);
+        const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned st = (tw[k >> 1] >> ((k & 1) * 16)) & kTagStep;
+            if (st < (unsigned)kAheadMaxSteps) mk |= 1ull << st;
+        }
+    }
+    const unsigned long long prev = e_next >= 1 ? ldg(A.mask[(e_next - 1) & 1] + sc.x) : 0ull;
+    const int start_e = (int)(prev >> 63);
+    const unsigned long long start_next = e_next >= 1 ? (unsigned long long)(start_e ^ (__popcll(prev & kStepBits) & 1)) : 0ull;
+    const unsigned long long word = mk | (start_next << 63);
+    const int nf = mk ? __ffsll((long long)mk) - 1 : kNoNext;
+    stg(A.mask[e_next & 1] + sc.x, word);
+    stg(ahead_work(A, e_next).sched_mask + rel, word);
+    stg(A.sched_nf + rel, (uint8_t)nf);
+    if (e_next >= 1 && (prev & kStepBits) == 0) {
+        // an orphan (only a permutation that misses interactions leaves a row without a step): the lane carries the row on by itself
+        const int D = S.d;
+        const bool is_user = sc.x < S.n_user;
+        const size_t off = (size_t)(is_user ? sc.x : sc.x - S.n_user) * D;
+        float *wrow = (is_user ? S.U[start_e] : S.V[start_e]) + off, *mrow = (is_user ? S.mU : S.mV) + off;
+        const int slot = (S.snap && S.row_slot) ? ldg(S.row_slot + sc.x) : -1;
+        const int gap = mk ? nf : A.steps;
+        for (int c = 0; c < D; c += 4) {
+            RowVec<1> w, m;
+            w.q[0] = ldg_f4(wrow + c);
+            m.q[0] = ldg_f4(mrow + c);
+            if (slot >= 0) stg_f4(S.snap + ((size_t)(e_next - 1) * S.n_active + slot) * D + c, w.q[0]);
+            if (has_next && gap > 0) {
+                row_advance<1>(w, m, A.ptab[(size_t)e_next * kTouchTab + gap]);
+                stg_f4(wrow + c, w.q[0]);
+                stg_f4(mrow + c, m.q[0]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void touch_ahead_mark_tiny(const ure_shard_t &S, const shard_aux &A, int e_next, int rel0)
+{
+    const int rel = rel0 + (int)threadIdx.x;
+    if (rel >= S.n_active - S.n_multi) return;
+    const int4 sc = ldg_i4(S.sched + 4 * (size_t)(S.n_multi + rel));
+    const unsigned long long *__restrict__ masks = A.mask[e_next & 1];
+    uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, e_next);
+    const int other_base = sc.x < S.n_user ? S.n_user : 0;
+    const uint4 t4 = ldg_u4(ent_tag + sc.y);
+    const int4 o0 = ldg_i4(S.ent_oid + sc.y), o1 = ldg_i4(S.ent_oid + sc.y + 4);
+    const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+    const int ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+    unsigned out[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned tg = (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+        const unsigned st = tg & kTagStep;
+        out[k] = tg;
+        if (st < (unsigned)kAheadMaxSteps) out[k] = st | ((unsigned)ahead_buffer_at(ldg(masks + other_base + ov[k]), (int)st) << 15);
+    }
+    stg_u4(ent_tag + sc.y, make_uint4(out[0] | (out[1] << 16), out[2] | (out[3] << 16), out[4] | (out[5] << 16), out[6] | (out[7] << 16)));
 }
 
 // ---- touch_mode 2, launch C: bit 15 of every tag of epoch e_next = the buffer the slot's OTHER row is in at the slot's step

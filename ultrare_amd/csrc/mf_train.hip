@@ -504,6 +504,8 @@ __global__ __launch_bounds__(kBlock) void touch_prep_kernel(const ure_shard_t *_
     else touch_advance_rows(S, A, P, (int)blockIdx.x - piece_blocks, (int)gridDim.x - piece_blocks);
 }
 
+constexpr int kAheadRun = 8;        // blocks of single-pass rows one workgroup of touch_ahead_kernel works off
+
 // touch_mode 2 (mf_touch.h): the two launches of an epoch start.  PHASE 1 = launch B (masks of the next epoch, hand-over to the owners,
 // orphans), PHASE 2 = launch C (buffer bits of the next epoch's tags).  boot = 1 (tick 0 only): the same for epoch 0 itself, whose
 // launch C also carries the one dense pass of the job (every row from the initial tables to its first step).
@@ -520,13 +522,34 @@ __global__ __launch_bounds__(kBlock) void touch_ahead_kernel(const ure_shard_t *
     const int e_next = boot ? 0 : epoch + 1;
     const bool has_next = e_next < S.epochs;
     const int n_pieces = touch_piece_blocks<LPR>(S.n_units, S.n_active, S.n_multi);
-    if (PHASE == 1) {
-        if ((int)blockIdx.x < n_pieces) touch_ahead_build<LPR, V4>(S, A, e_next, has_next, (int)blockIdx.x, wg_mask);
-        return;
-    }
+    // A workgroup takes one block of work units, or kAheadRun consecutive blocks of single-pass rows: 16 rows of one scan pass each
+    // are two dependent loads and a store -- at 60.8 k rows per shard and 32 shards the launch was bound by the rate at which
+    // workgroups are dispatched (122 k of them), not by its 0.1 GB of tags.
+    const int nbU = S.n_units / (kBlock / LPR);
     if ((int)blockIdx.x < piece_blocks) {
-        if (has_next && (int)blockIdx.x < n_pieces) touch_ahead_mark<LPR>(S, A, e_next, (int)blockIdx.x);
-    } else if (boot) {
+        const int first = (int)blockIdx.x < nbU ? (int)blockIdx.x : nbU + ((int)blockIdx.x - nbU) * kAheadRun;
+        const int count = (int)blockIdx.x < nbU ? 1 : kAheadRun;
+        if ((int)blockIdx.x >= nbU && kAheadRun * (kBlock / LPR) <= kBlock) {
+            // the rows of this workgroup, the first of them first (the schedule is heaviest first): all of at most 8 slots -> a lane each
+            const int rel0 = (first - nbU) * (kBlock / LPR);
+            if (rel0 < S.n_active - S.n_multi) {
+                const int4 sc0 = ldg_i4(S.sched + 4 * (size_t)(S.n_multi + rel0));
+                if (sc0.z - sc0.y <= kSegPerLane) {
+                    if ((int)threadIdx.x < kAheadRun * (kBlock / LPR)) {
+                        if (PHASE == 1) touch_ahead_build_tiny<V4>(S, A, e_next, has_next, rel0);
+                        else if (has_next) touch_ahead_mark_tiny(S, A, e_next, rel0);
+                    }
+                    return;
+                }
+            }
+        }
+        for (int r = 0; r < count; ++r) {
+            const int wg = first + r;
+            if (wg >= n_pieces) break;
+            if (PHASE == 1) touch_ahead_build<LPR, V4>(S, A, e_next, has_next, wg, wg_mask);
+            else if (has_next) touch_ahead_mark<LPR>(S, A, e_next, wg);
+        }
+    } else if (PHASE == 2 && boot) {
         touch_advance_rows(S, A, touch_pos(A, 0, 0), (int)blockIdx.x - piece_blocks, (int)gridDim.x - piece_blocks);
     }
 }
@@ -556,8 +579,11 @@ template <int LPR, int V4>
 static void launch_touch_ahead(const ure_job *job, int64_t tick, hipStream_t st)
 {
     const unsigned n_sh = (unsigned)job->host.size();
-    int pieces = 1;
-    for (const ure_shard_t &S : job->host) pieces = std::max(pieces, touch_piece_blocks<LPR>(S.n_units, S.n_active, S.n_multi));
+    int pieces = 1;                     // workgroups of the row-structured passes: one per block of units, one per kAheadRun blocks of single-pass rows
+    for (const ure_shard_t &S : job->host) {
+        const int nbU = S.n_units / (kBlock / LPR);
+        pieces = std::max(pieces, nbU + (touch_piece_blocks<LPR>(S.n_units, S.n_active, S.n_multi) - nbU + kAheadRun - 1) / kAheadRun);
+    }
     const unsigned adv_b = (unsigned)std::max<int64_t>(1, std::min<int64_t>((job->max_active4 + kBlock - 1) / kBlock, 8192));
     if (tick == 0) {
         hipLaunchKernelGGL((touch_ahead_kernel<LPR, V4, 1>), dim3((unsigned)pieces, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, 1, pieces);
