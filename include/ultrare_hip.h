@@ -132,9 +132,11 @@ typedef struct ure_shard {
                              * advances it across the epoch boundary at its last own step, and the dense pass at every epoch start of
                              * mode 1 is gone; the tables are readable (ure_job_materialize) only once training has finished, epoch
                              * ends through `snap`.  Same results as mode 1, bit for bit.                                        */
-    /* touch mode: the first n_multi rows of the schedule are longer than one scan pass (8 * lanes slots)
-     * and `units` covers exactly those; the rows [n_multi, n_active) fit in one pass and are worked off
-     * from a per-step compaction of the rows that have interactions in the step.                  */
+    /* touch mode: `units` covers exactly the first n_multi rows of the schedule (the longest); the rows
+     * [n_multi, n_active) are worked off row by row from a per-step compaction of the rows that have
+     * interactions in the step.  Epochs of at most 64 steps: n_multi = the rows longer than one scan pass
+     * (8 * lanes slots).  Longer epochs: a row of up to 64 passes may stay on the row side -- the pass
+     * masks let its lane group skip the passes without a slot of the step.                          */
     int32_t n_multi;
 } ure_shard_t;
 

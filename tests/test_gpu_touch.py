@@ -320,3 +320,36 @@ def test_touch_ahead_mode_orphans_and_table_reads():
         assert rel(jobs[True].tables(s)[0], st.U) < 2e-5 and rel(jobs[True].tables(s)[1], st.V) < 2e-5
     for j in jobs.values():
         j.close()
+
+
+def test_touch_mode_windows_heavy_row_pass_skipping():
+    """A row far heavier than a workgroup's lane groups can cover one pass each (one item with 5,000 of the shard's 5,600 interactions)
+    is cut into long work units of many scan passes; with epochs of several windows every pass carries the mask of the steps it holds
+    and the lane groups skip the passes without a slot of the step.  94 steps per epoch (two windows), against the C oracle."""
+    from ultrare_amd import engine, rng
+    rs = np.random.RandomState(3)
+    n_user, n_item, k, B, E = 5200, 40, 16, 60, 3
+    heavy_users = rs.permutation(n_user)[:5000]
+    u = np.concatenate([heavy_users, rs.randint(0, n_user, 600)])
+    i = np.concatenate([np.zeros(5000, dtype=np.int64), rs.randint(1, n_item, 600)])
+    key = np.unique(u.astype(np.int64) * n_item + i)                      # no duplicate (user, item)
+    u, i = (key // n_item).astype(np.int32), (key % n_item).astype(np.int32)
+    r = (rs.randint(1, 6, len(u)) / 5).astype(np.float32)
+    part = (u, i, r)
+    steps = (len(u) + B - 1) // B
+    assert steps > 64
+    torch.manual_seed(21)
+    init = tuple(t * 0.3 for t in rng.mf_init(n_user, n_item, k))
+    perms = rng.epoch_perms(rng.epoch_seeds(E, True), len(u))
+    sh = engine.ShardData(*part, n_user, n_item)
+    assert sh.max_row >= 5000
+    job = engine.TrainJob([sh], [init], [perms], k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=True)
+    assert job.touch and not job.ahead
+    job.run()
+    st = O.MFState(init[0].numpy().copy(), init[1].numpy().copy())
+    losses = [O.train_epoch(st, part, perms[t].numpy(), B, 1e-3, 0.1, 0.9)[0] for t in range(E)]
+    U, V = job.tables(0)
+    assert np.isfinite(st.V).all()
+    assert rel(U, st.U) < 2e-5 and rel(V, st.V) < 2e-5, (rel(U, st.U), rel(V, st.V))
+    np.testing.assert_allclose(np.sqrt(job.epoch_sse(0) / len(u)), losses, rtol=2e-5)
+    job.close()

@@ -168,13 +168,25 @@ __device__ __forceinline__ void touch_build_masks(const ure_shard_t &S, const sh
     const uint16_t *__restrict__ ent_tag = S.ent_tag + (size_t)(P.epoch & 1) * S.n_slots;
     unsigned long long mk = 0;
     if (pc.x >= 0) {
-        for (int p0 = pc.y + sub * kSegPerLane; p0 < pc.z; p0 += CAP) {
-            const uint4 t4 = ldg_u4(ent_tag + p0);
-            const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+        // a unit of several scan passes (the pieces of the heaviest rows: 120 k slots each for the top item of the 25 M set) also
+        // records which steps every single pass holds: with 750 steps per epoch five passes in six hold none of a given step
+        const bool per_pass = A.pass_mask != nullptr && pc.z - pc.y > CAP;
+        for (int seg = pc.y; seg < pc.z; seg += CAP) {          // (lane-group uniform: every lane of the group stays for the pass masks)
+            const int p0 = seg + sub * kSegPerLane;
+            unsigned long long bits = 0;
+            if (p0 < pc.z) {
+                const uint4 t4 = ldg_u4(ent_tag + p0);
+                const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const unsigned st = (tw[k >> 1] >> ((k & 1) * 16)) & kTagStep;      // (slots of earlier windows carry their buffer bit already)
-                if ((int)(st >> kTouchWindowBits) == P.win) mk |= 1ull << (st & (kTouchWindow - 1));
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned st = (tw[k >> 1] >> ((k & 1) * 16)) & kTagStep;      // (slots of earlier windows carry their buffer bit already)
+                    if ((int)(st >> kTouchWindowBits) == P.win) bits |= 1ull << (st & (kTouchWindow - 1));
+                }
+            }
+            mk |= bits;
+            if (per_pass) {
+                const unsigned long long pm = group_or<LPR>(bits);
+                if (sub == 0) stg(A.pass_mask + (seg >> 3), pm);
             }
         }
     }
@@ -500,7 +512,28 @@ __device__ __forceinline__ void touch_process(const ure_shard_t &S, const shard_
     int *gq = qo + grp * CAP;
     float *gr = qr + grp * CAP;
     const int beg = du.y, end = (hit && scan) ? du.z : du.y;      // scan: this unit's own slots have an interaction in the step
-    for (int seg = beg;; seg += CAP) {
+    // a unit of several passes under per-pass masks (tag_prep.h: pass_mask): its lane group looks LPR passes ahead -- a lane per pass,
+    // one coalesced load -- and visits only the passes that hold a slot of this step
+    const bool by_pass = A.pass_mask != nullptr && end - beg > CAP;
+    int look = beg;                      // first pass not yet looked up
+    int look0 = beg;                     // first pass of the batch `pending` describes
+    unsigned long long pending = 0;      // passes of that batch still to visit (bit = pass of the batch)
+    auto next_pass = [&]() -> int {
+        while (true) {
+            if (pending) {
+                const int bit = __ffsll((long long)pending) - 1;
+                pending &= pending - 1;
+                return look0 + bit * CAP;
+            }
+            if (look >= end) return end;
+            const int mine = look + sub * CAP;
+            const unsigned long long pm = mine < end ? ldg(A.pass_mask + (mine >> 3)) : 0ull;
+            pending = group_or<LPR>(((pm >> P.sl) & 1ull) << sub);
+            look0 = look;
+            look += LPR * CAP;
+        }
+    };
+    for (int seg = by_pass ? next_pass() : beg;; seg = by_pass ? next_pass() : seg + CAP) {
         if (!__any(seg < end)) break;
         const int p0 = seg + sub * kSegPerLane;
         const bool valid = p0 < end;

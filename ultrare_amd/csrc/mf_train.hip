@@ -761,6 +761,17 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             job->aux_host[k].sched_mask = static_cast<unsigned long long *>(wm) + 2 * n_um;
             job->aux_host[k].n_um = (int32_t)n_um;
             job->aux_host[k].n_sm = (int32_t)n_sm;
+            if (!job->ahead && job->aux_host[k].windows > 1 && shards[k].n_units > 0) {
+                // epochs of several windows: the steps of every scan pass of the multi-pass units (mf_touch.h: pass skipping)
+                void *pm = nullptr;
+                const size_t bytes = ((size_t)shards[k].n_slots / 8 + 1) * sizeof(unsigned long long);
+                e = hipMalloc(&pm, bytes);
+                if (e != hipSuccess) break;
+                job->touch_mem.push_back(pm);
+                e = hipMemset(pm, 0, bytes);
+                if (e != hipSuccess) break;
+                job->aux_host[k].pass_mask = static_cast<unsigned long long *>(pm);
+            }
             if (job->ahead) {
                 // touch_mode 2: the work-order masks once per epoch parity (the first set is the one above), and the owners' hand-over
                 void *wm2 = nullptr, *nf = nullptr;

@@ -195,6 +195,8 @@ struct shard_aux {
     const float4 *ptab;            // [epochs][65] A_e^j = {p11, p12, p21, p22}: j optimizer steps without a gradient at epoch e's lr
     unsigned long long *unit_mask; // [n_units] the current window's mask of each work unit's row
     unsigned long long *unit_own;  // [n_units] the steps of the window in which the UNIT's own slots have interactions (a subset of its row's)
+    unsigned long long *pass_mask; // [n_slots / 8] (epochs of several windows only, else NULL) the same for every scan pass of a work unit of several
+                                   // passes, at index (first slot of the pass) / 8: the unit's lane group skips the passes without a slot of the step
     // touch_mode 2 ("masks one epoch ahead"): the three work-order arrays once per epoch parity (an epoch's are written at the start of
     // the epoch before it), and for the owners of the current epoch the row's first own step of the NEXT epoch (255: none)
     unsigned long long *ahead_masks[2];   // [2 n_um + n_sm] each: unit_mask | unit_own | sched_mask
