@@ -220,9 +220,11 @@ int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *r
 int ure_host_build_layouts(int n_shards, const int64_t *const *uid, const int64_t *const *iid, const double *const *rating, const int64_t *n,
                            int32_t n_user, int32_t n_item, int32_t *const *region, int64_t *n_slots, int32_t *n_active, int n_threads);
 /* Cuts the active rows of a schedule into the work units of struct ure_shard for row width d and
- * packs them into workgroups.  units == NULL: only *n_units is written (size query); otherwise
- * `capacity` units may be written. */
-int ure_host_build_units(const int32_t *sched, int32_t n_active, int32_t d, int32_t *units, int64_t capacity, int64_t *n_units);
+ * packs them into workgroups.  unit_passes = scan passes of one lane group per unit: 1 everywhere, except touch
+ * mode with epochs of several windows (more than 64 steps), where a unit of several passes skips the passes
+ * without a slot of the step by their masks (8: full MF at the 25 M shape 106 -> 63 us per launch).
+ * units == NULL: only *n_units is written (size query); otherwise `capacity` units may be written. */
+int ure_host_build_units(const int32_t *sched, int32_t n_active, int32_t d, int32_t unit_passes, int32_t *units, int64_t capacity, int64_t *n_units);
 
 /* ---------------------------------------------------------------------------
  * Evaluation (baseTest, utils.py:115-187)

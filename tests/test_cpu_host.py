@@ -660,3 +660,30 @@ def test_upload_many_on_the_host_device():
     out = engine.upload_many(arrs, torch.device('cpu'))
     for a, t in zip(arrs, out):
         assert tuple(t.shape) == a.shape and np.array_equal(t.numpy(), a)
+
+
+def test_work_units_of_several_passes(lib):
+    """ure_host_build_units with unit_passes > 1 (touch mode, epochs of several windows): the pieces of a row are unit_passes scan
+    passes long, still tile the row's segment without gaps, and a row's units still share one workgroup."""
+    from ultrare_amd.engine import ShardData
+    tr = O.partition(*O.load_csv(TRAIN), [list(range(N_USER))])[0]
+    sh = ShardData(*tr, N_USER, N_ITEM, device=torch.device('cpu'))
+    sched = sh._sched_host
+    d, lanes = 16, 4
+    for passes in (1, 3, 8):
+        units = lib.build_units(sched, sh.n_active, d, passes)
+        upb = 256 // lanes
+        assert len(units) % upb == 0
+        cover = {}
+        for q, (row, beg, end, word) in enumerate(units.tolist()):
+            if row < 0:
+                continue
+            leader, count = word & 0xFFFF, (word >> 16) & 0x3FFF
+            assert q // upb == (q - (q % upb) + leader) // upb              # the row's first unit is in the same workgroup
+            cover.setdefault(row, []).append((beg, end))
+            assert end - beg <= max(8 * lanes * passes, (sched[sched[:, 0] == row][0][2] - sched[sched[:, 0] == row][0][1] + upb - 1) // upb + 8)
+        for row, beg, end, nnz in sched[:sh.n_active].tolist():
+            pieces = sorted(cover[row])
+            assert pieces[0][0] == beg and pieces[-1][1] == end and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+        if passes > 1:
+            assert len(units) < len(lib.build_units(sched, sh.n_active, d, 1))

@@ -55,6 +55,11 @@ if has e2e; then
   python3 "$ROOT/tools/e2e_cold.py" > "$OUT/e2e_cold.json" 2>/dev/null
   python3 "$ROOT/tools/profile_ot.py" --rounds 6 > "$OUT/ot_rounds.json" 2>/dev/null
 fi
+if has pmcfull; then
+  python3 "$ROOT/tools/pmc_traffic.py" "$OUT/pmc" --tag "$TAG" -- --workload ml25m --shards 1 --d 128 --steps 1 --warmup 1 --roofline-steps 1 > "$OUT/pmc_fullmf.log" 2>&1; echo "pmc fullmf touch rc=$?"
+  cp "$OUT"/pmc/*_pmc_hbm_traffic_*.json "$OUT"/ 2>/dev/null
+  rm -rf "$OUT/pmc"
+fi
 if has fullmf; then
   ARGS="--workload ml25m --shards 1 --d 128 --no-cpu-baseline --no-unlearn --steps 1 --warmup 1 --roofline-steps 1"
   URE_TOUCH=0 timeout -k 10 500 python3 "$ROOT/bench.py" $ARGS > "$OUT/fullmf25m_d128_dense.json" 2> /dev/null; echo "fullmf dense rc=$?"

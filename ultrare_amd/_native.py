@@ -65,7 +65,7 @@ _PROTOTYPES = {
                                              ctypes.POINTER(_i64), ctypes.POINTER(_i32), _vp, _vp]),
     'ure_host_build_layouts': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i32, _i32,
                                               ctypes.POINTER(_vp), _vp, _vp, ctypes.c_int]),
-    'ure_host_build_units': (ctypes.c_int, [_vp, _i32, _i32, _vp, _i64, ctypes.POINTER(_i64)]),
+    'ure_host_build_units': (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _i64, ctypes.POINTER(_i64)]),
     'ure_score': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_int, _vp, _vp, _vp, _i64, ctypes.c_int, _vp, _vp, _vp]),
     'ure_eval_users': (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
@@ -290,11 +290,11 @@ def build_layout(uid, iid, rating, n_user, n_item, want_pos=False, out=None):
             'n_active': na.value, 'u_pos': u_pos, 'i_pos': i_pos}
 
 
-def build_units(sched, n_active, d):
+def build_units(sched, n_active, d, unit_passes=1):
     """ure_host_build_units: the work units [n_units, 4] of a row schedule for table width d."""
     sched = np.ascontiguousarray(sched, dtype=np.int32)
     n = _i64()
-    check(lib().ure_host_build_units(sched.ctypes.data, n_active, d, None, 0, ctypes.byref(n)), 'ure_host_build_units')
+    check(lib().ure_host_build_units(sched.ctypes.data, n_active, d, int(unit_passes), None, 0, ctypes.byref(n)), 'ure_host_build_units')
     units = np.empty((max(n.value, 1), 4), dtype=np.int32)
-    check(lib().ure_host_build_units(sched.ctypes.data, n_active, d, units.ctypes.data, n.value, ctypes.byref(n)), 'ure_host_build_units')
+    check(lib().ure_host_build_units(sched.ctypes.data, n_active, d, int(unit_passes), units.ctypes.data, n.value, ctypes.byref(n)), 'ure_host_build_units')
     return units[:n.value]

@@ -328,12 +328,12 @@ int ure_host_build_layouts(int n_shards, const int64_t *const *uid, const int64_
 // (256 / L) is cut into 256 / L longer pieces instead.  Rows are taken heaviest first; when the next
 // heavy row does not fit into what is left of the workgroup, the gap is filled with the lightest
 // rows, so a row never straddles workgroups and its partial sums meet in LDS.
-int ure_host_build_units(const int32_t *sched, int32_t n_active, int32_t d, int32_t *units, int64_t capacity, int64_t *n_units)
+int ure_host_build_units(const int32_t *sched, int32_t n_active, int32_t d, int32_t unit_passes, int32_t *units, int64_t capacity, int64_t *n_units)
 {
-    if (!sched || !n_units || n_active < 0 || d < 4 || d > 256 || (d & (d - 1)))
+    if (!sched || !n_units || n_active < 0 || d < 4 || d > 256 || (d & (d - 1)) || unit_passes < 1 || unit_passes > 4096)
         return ure::fail(-1, "ure_host_build_units: bad arguments");
     const int lanes = d <= URE_NARROW_MAX ? d / 4 : d / 8;
-    const int cap = 8 * lanes, upb = 256 / lanes;
+    const int cap = 8 * lanes * unit_passes, upb = 256 / lanes;        // slots of a unit: unit_passes scan passes of one lane group
     auto pieces = [&](int64_t q, int32_t *len) {
         const int64_t slots = (int64_t)sched[4 * q + 2] - sched[4 * q + 1];
         int64_t l = cap, nu = (slots + cap - 1) / cap;

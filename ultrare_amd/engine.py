@@ -31,6 +31,10 @@ EARLY_SCORE_EPOCHS = 8               # TrainJob.early_scores: epochs per batch h
 # launch: 106.7 at 1 (a unit per pass), 95.5 at 2, 97.0 at 4, 118.8 at 8, 157.3 at 16, 386.7 at 64 -- a lane group walks its row's
 # passes one after the other (a scan, a compaction and a gather each), units work theirs side by side
 TOUCH_ROW_PASSES = int(os.environ.get('URE_TOUCH_ROW_PASSES', '2'))
+# ... and the work units of the longer rows take this many passes each (a unit skips the passes without a slot of the step by their masks;
+# fewer, larger units: the step visits 1,700 workgroups of them instead of 13,600).  The same leg: 105.8 us at 1, 81.7 at 2, 68.0 at 4,
+# 62.9 at 8, 61.6 at 16
+TOUCH_UNIT_PASSES = int(os.environ.get('URE_TOUCH_UNIT_PASSES', '8'))
 TOUCH_AHEAD_MAX_STEPS = 63           # kAheadMaxSteps of csrc/mf_touch.h
 TOUCH_MIN_TABLE_BYTES = 256 << 20    # auto rule: the job's live rows (w, m, second buffer) exceed the Infinity Cache
 
@@ -205,27 +209,27 @@ class ShardData:
         interactions in this shard (the rows a compact snapshot stores), -1 otherwise."""
         return self._row_slot
 
-    def units(self, d, touch=False, min_passes=1):
+    def units(self, d, touch=False, min_passes=1, unit_passes=1):
         """The work units of the step kernel for table width d (device int32 [n_units, 4]).  touch: only the rows
         longer than one scan pass get units (-> (units, n_multi)); the others are worked off per step from a
         compaction of the rows that are trained in it (csrc/mf_touch.h)."""
-        key = (d, bool(touch)) if min_passes == 1 else (d, bool(touch), int(min_passes))
+        key = (d, bool(touch)) if min_passes == 1 and unit_passes == 1 else (d, bool(touch), int(min_passes), int(unit_passes))
         if key not in self._units:
-            u, n_units, n_rows = self.units_host(d, touch, min_passes)
+            u, n_units, n_rows = self.units_host(d, touch, min_passes, unit_passes)
             self._units[key] = (to_device_async(u, self.device), n_units, n_rows)
         dev_u, n_units, n_rows = self._units[key]
         return (dev_u, n_units, n_rows) if touch else dev_u
 
-    def units_host(self, d, touch=False, min_passes=1):
+    def units_host(self, d, touch=False, min_passes=1, unit_passes=1):
         """The host half of units(): -> (int32 [max(n_units, 1), 4] array to upload, n_units, rows covered).  touch: only the
-        rows of more than min_passes scan passes get units (the others are worked off per row)."""
+        rows of more than min_passes scan passes get units (the others are worked off per row); unit_passes = scan passes per unit."""
         n_rows = self.n_active
         if touch:
             lanes = d // 4 if d <= 32 else d // 8
             seg = self._sched_host[:self.n_active, 2] - self._sched_host[:self.n_active, 1]
             n_rows = int(np.count_nonzero(seg > 8 * lanes * min_passes))
             assert n_rows == 0 or (seg[:n_rows] > 8 * lanes * min_passes).all()          # the schedule is heaviest first
-        u = nv.build_units(self._sched_host, n_rows, d)
+        u = nv.build_units(self._sched_host, n_rows, d, unit_passes)
         return (u if len(u) else np.full((1, 4), -1, np.int32)), len(u), n_rows
 
     def nbytes(self):
@@ -349,7 +353,9 @@ class TrainJob:
             if self.touch:
                 # epochs of several windows (more than 64 steps): a row of up to TOUCH_ROW_PASSES scan passes stays ONE work item -- its
                 # lane group skips the passes without a slot of the step (csrc/mf_touch.h: pass masks) -- instead of one unit per pass
-                units, n_units, n_multi = sh.units(self.d, touch=True, min_passes=TOUCH_ROW_PASSES if max(steps_all) > 64 else 1)
+                long_epochs = max(steps_all) > 64
+                units, n_units, n_multi = sh.units(self.d, touch=True, min_passes=TOUCH_ROW_PASSES if long_epochs else 1,
+                                                   unit_passes=TOUCH_UNIT_PASSES if long_epochs else 1)
                 D.n_multi = n_multi
             else:
                 units = sh.units(self.d)
