@@ -249,7 +249,8 @@ int ure_score(const float *const *U_tables, const float *const *V_tables, int n_
 /* Users [0, n_wide) get one wavefront each (segments of any length); users [n_wide, n_users) MUST have at most 16
  * entries and share wavefronts four by four (n_wide = n_users: every user a wavefront).  top_rating (optional, device
  * [n_users][10]): the top-10 positions of the RATINGS, which do not depend on the model -- ure_eval_rank_ratings
- * computes them once per test set; NULL = ranked inside the call.                                               */
+ * computes them once per test set; NULL = ranked inside the call.  With top_rating the call is two launches (rank, then
+ * metrics by one thread per user); between them `hits` / `ndcg` hold the packed positions of the ranking.          */
 int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const float *rating,
                    const double *log2_tab, int32_t *hits, double *ndcg, const int32_t *top_rating, int32_t n_wide, void *stream);
 int ure_eval_rank_ratings(const int32_t *off, int32_t n_users, const float *rating, int32_t *top_rating, void *stream);

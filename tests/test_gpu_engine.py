@@ -416,3 +416,36 @@ def test_upload_many_on_the_device():
         out = engine.upload_many(arrs, engine._device())
         for a, t in zip(arrs, out):
             assert tuple(t.shape) == a.shape and t.is_cuda and t.data_ptr() % 64 == 0 and np.array_equal(t.cpu().numpy(), a)
+
+
+def test_two_launch_ranking_handles_ties_nans_and_every_segment_class():
+    """ure_eval_users with a cached ranking of the ratings runs as two launches (csrc/mf_eval.hip: eval_rank_kernel leaves the
+    ten predicted positions packed in the output slots, eval_metrics_kernel turns them into HR / NDCG).  Its fast ranking counts
+    with the strict comparison and falls back when two of the best keys are equal: predictions drawn from FEW distinct values
+    (ties in nearly every top-10), NaNs, and users of every class -- 1, 3, 10, 16 (four per wavefront), 17, 40, 64 (a lane per
+    entry), 65, 128, 300, 512 (several per lane), 513, 700 (from memory: finished by the first launch) -- per user against the
+    one-launch kernel (no cached ranking) and the means against the oracle."""
+    from ultrare_amd import engine, _native as nv
+    rs = np.random.RandomState(11)
+    lengths = [1, 3, 10, 16, 17, 40, 64, 65, 128, 300, 512, 513, 700] * 3 + list(rs.randint(1, 90, 400))
+    uid = np.repeat(rs.permutation(len(lengths)), lengths).astype(np.int32)
+    uid = uid[rs.permutation(len(uid))]                         # interleaved: first-appearance order is not sorted order
+    n = len(uid)
+    r = rs.choice([0.2, 0.4, 0.6, 0.8, 1.0], n).astype(np.float32)
+    for name, pred in (('ties', rs.choice(np.linspace(-1, 1, 7), n).astype(np.float32)),
+                       ('distinct', rs.standard_normal(n).astype(np.float32)),
+                       ('nan', np.where(rs.rand(n) < 0.2, np.nan, rs.choice(np.linspace(-1, 1, 5), n)).astype(np.float32))):
+        ev = engine.EvalSet(uid, np.zeros(n, np.int32), r)
+        ev.pred.copy_(torch.from_numpy(pred[ev.order]))
+        L, st = nv.lib(), nv.stream_handle()
+        out = {}
+        for cached in (True, False):
+            ev.hits.fill_(-7)
+            ev.ndcg.fill_(-7.0)
+            nv.check(L.ure_eval_users(nv.ptr(ev.off), ev.n_users, nv.ptr(ev.pred), nv.ptr(ev.rating), nv.ptr(ev.log2), nv.ptr(ev.hits), nv.ptr(ev.ndcg),
+                                      nv.ptr(ev.top_rating) if cached else None, ev.n_wide, st), 'ure_eval_users')
+            out[cached] = (ev.hits.cpu().numpy().copy(), ev.ndcg.cpu().numpy().copy())
+        assert np.array_equal(out[True][0], out[False][0]), name
+        assert np.array_equal(out[True][1], out[False][1]), name          # the same arithmetic in the same order: bit for bit
+        want = O.eval_from_pred(uid, r, pred, 3000)
+        np.testing.assert_allclose([out[True][1].mean(), (out[True][0] / 10).mean()], want[1:], rtol=1e-12, err_msg=name)

@@ -263,14 +263,33 @@ __device__ __forceinline__ bool key_gt(float v, int i, float bv, int bi) { retur
 // has rank k for some k and the selection returns position -1.
 __device__ __forceinline__ float nan_last(float v) { return v != v ? __builtin_inff() : v; }
 
+// The best (value, position) key of the wave, on every lane: four DPP exchanges inside each row of 16 lanes, then the four row
+// winners through scalar registers.  (As six __shfl_xor steps -- twelve dependent ds_bpermute -- a selection round took ~0.8 us
+// and the ten rounds of the 199 users with more than 64 test entries were the tail of every eval launch: 8 us for one member, r3.)
+template <int CTRL>
+__device__ __forceinline__ void argmax_step(float &v, int &i)
+{
+    const float ov = dpp_f<CTRL>(v);
+    const int oi = dpp_i<CTRL>(i);
+    if (key_gt(ov, oi, v, i)) { v = ov; i = oi; }
+}
 __device__ __forceinline__ void wave_argmax(float &v, int &i)
 {
+    argmax_step<kDppQuadXor1>(v, i);
+    argmax_step<kDppQuadXor2>(v, i);
+    argmax_step<kDppHalfMirror>(v, i);
+    argmax_step<kDppRowMirror>(v, i);
+    const int vi = __builtin_bit_cast(int, v);
+    float bv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
+    int bi = __builtin_amdgcn_readlane(i, 0);
 #pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const float ov = __shfl_xor(v, o, kWave);
-        const int oi = __shfl_xor(i, o, kWave);
-        if (key_gt(ov, oi, v, i)) { v = ov; i = oi; }
+    for (int r = 1; r < 4; ++r) {
+        const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16 * r));
+        const int oi = __builtin_amdgcn_readlane(i, 16 * r);
+        if (key_gt(ov, oi, bv, bi)) { bv = ov; bi = oi; }
     }
+    v = bv;
+    i = bi;
 }
 
 // Positions (within the user's segment) of the top-K keys of `val`, best first.
@@ -299,39 +318,57 @@ __device__ __forceinline__ void top_k_positions(const float *__restrict__ val, i
 // The same selection when the segment has at most 64 entries: lane t holds entry t.
 // Every lane counts the entries that beat its own (val, position) key -- `cnt` independent
 // broadcasts instead of ten dependent arg-max rounds -- and the entry of rank k is top[k].
-template <int K>
+// FAST (predictions): ranks are counted with the strict comparison alone -- three instructions per entry instead of six --
+// and are exact unless two of the ten best keys are EQUAL, which shows as two entries with one rank; only then (the wave
+// decides as one) the ranks are counted again with the position as the tie-break.  Ratings tie all the time: FAST off.
+template <int K, bool FAST = false>
 __device__ __forceinline__ void top_k_in_registers(float val, int cnt, int lane, int (&top)[K])
 {
     // entry t is broadcast through a scalar register (v_readlane: t is wave-uniform) -- a ds_bpermute per entry, as __shfl
     // compiles to, sends all 64 lanes through the LDS crossbar for it (eval_users: 125 -> 7x us per series call, r3)
-    int rank = 0;
     const int vi = __builtin_bit_cast(int, val);
-    for (int t = 0; t < cnt; ++t) {
-        const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, t));
-        rank += key_gt(ov, t, val, lane) ? 1 : 0;
-    }
+    // the lanes that hold an entry, as a mask: a ballot of (lane < cnt && rank == k) compiles to a select and a second compare
+    const unsigned long long valid = __builtin_amdgcn_ballot_w64(lane < cnt);
+    int rank = 0;
+    bool exact = !FAST;
+    if (FAST) {
+        for (int t = 0; t < cnt; ++t) rank += __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, t)) > val ? 1 : 0;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const unsigned long long m = __ballot(lane < cnt && rank == k);
-        top[k] = m ? (int)__builtin_ctzll(m) : -1;
+        for (int k = 0; k < K; ++k) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(rank == k) & valid;
+            top[k] = m ? (int)__builtin_ctzll(m) : -1;
+            exact = exact || (m & (m - 1)) != 0;
+        }
+    }
+    if (exact) {
+        rank = 0;
+        for (int t = 0; t < cnt; ++t) {
+            const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, t));
+            rank += key_gt(ov, t, val, lane) ? 1 : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(rank == k) & valid;
+            top[k] = m ? (int)__builtin_ctzll(m) : -1;
+        }
     }
 }
 
 // Segments of up to 64 * kRegItems entries: lane t holds entries t, t+64, ... in registers; every
 // round takes the best not-yet-taken key of the wave (no memory access per round).
 constexpr int kRegItems = 8;
-template <int K>
-__device__ __forceinline__ void top_k_multi(const float (&val)[kRegItems], int cnt, int lane, int (&top)[K])
+template <int K, int R>
+__device__ __forceinline__ void top_k_multi(const float (&val)[R], int cnt, int lane, int (&top)[K])
 {
     unsigned taken = 0;
 #pragma unroll
-    for (int r = 0; r < kRegItems; ++r) taken |= (lane + r * kWave >= cnt ? 1u : 0u) << r;
+    for (int r = 0; r < R; ++r) taken |= (lane + r * kWave >= cnt ? 1u : 0u) << r;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         float bv = -FLT_MAX;
         int bi = -1;
 #pragma unroll
-        for (int r = 0; r < kRegItems; ++r) {
+        for (int r = 0; r < R; ++r) {
             const int t = lane + r * kWave;
             if (!((taken >> r) & 1u) && (bi < 0 || key_gt(val[r], t, bv, bi))) { bv = val[r]; bi = t; }
         }
@@ -351,20 +388,45 @@ __device__ __forceinline__ void quarter_rank_steps(const int vi, const int s, co
     rank += (ot < cnt && key_gt(ov, ot, val, s)) ? 1 : 0;
     if constexpr (N < 15) quarter_rank_steps<N + 1>(vi, s, cnt, val, rank);
 }
+// The strict comparison alone (lanes past the segment carry -inf, which is greater than nothing): no position travels.
+template <int N>
+__device__ __forceinline__ void quarter_rank_steps_strict(const int vi, const float val, int &rank)
+{
+    rank += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x120 + N, 0xF, 0xF, false)) > val ? 1 : 0;
+    if constexpr (N < 15) quarter_rank_steps_strict<N + 1>(vi, val, rank);
+}
 
 // Rank of every entry of a segment of at most 16 entries held one per lane by a quarter wave (lanes 16 g .. 16 g + 15):
-// the in-register selection of top_k_in_registers at width 16, four users per wavefront.
-template <int K>
+// the in-register selection of top_k_in_registers at width 16, four users per wavefront.  FAST as there: the wave falls
+// back to the exact count when any of its four users has equal keys among its ten best.
+template <int K, bool FAST = false>
 __device__ __forceinline__ void top_k_quarter(float val, int cnt, int lane, int (&top)[K])
 {
     const int g16 = lane & ~15, s = lane & 15;
     int rank = 0;
-    quarter_rank_steps<1>(__builtin_bit_cast(int, val), s, cnt, val, rank);      // all 15 other lanes of the row, one rotation each
+    bool exact = !FAST;
+    if (FAST) {
+        const float padded = s < cnt ? val : -__builtin_inff();
+        quarter_rank_steps_strict<1>(__builtin_bit_cast(int, padded), padded, rank);
+        bool tie = false;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const unsigned long long m = __ballot(s < cnt && rank == k);
-        const unsigned mg = (unsigned)(m >> g16) & 0xFFFFu;
-        top[k] = mg ? (int)__builtin_ctz(mg) : -1;
+        for (int k = 0; k < K; ++k) {
+            const unsigned long long m = __ballot(s < cnt && rank == k);
+            const unsigned mg = (unsigned)(m >> g16) & 0xFFFFu;
+            top[k] = mg ? (int)__builtin_ctz(mg) : -1;
+            tie = tie || (mg & (mg - 1)) != 0;
+        }
+        exact = __ballot(tie) != 0;
+    }
+    if (exact) {
+        rank = 0;
+        quarter_rank_steps<1>(__builtin_bit_cast(int, val), s, cnt, val, rank);      // all 15 other lanes of the row, one rotation each
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned long long m = __ballot(s < cnt && rank == k);
+            const unsigned mg = (unsigned)(m >> g16) & 0xFFFFu;
+            top[k] = mg ? (int)__builtin_ctz(mg) : -1;
+        }
     }
 }
 
@@ -373,24 +435,44 @@ __device__ __forceinline__ void top_k_quarter(float val, int cnt, int lane, int 
 // up rating[top_pred[j]], tests the threshold and the membership in top_rating, and divides by log2(j + 1) -- and the
 // group's first lane adds the ten terms in numpy's order.  (One lane doing all ten -- nine dependent float64 divisions,
 // ten dependent gathers, with the other 63 lanes idle -- was most of eval_users_kernel's time: 114 -> us per series call, r3.)
+// Lane 0 of a 16-lane row reads the double of lane N of its row (two DPP row_shl moves; lanes past the row read 0).
+template <int N>
+__device__ __forceinline__ double row_lane_f64(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)dpp_i<0x100 + N>((int)(unsigned)b), hi = (unsigned)dpp_i<0x100 + N>((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <int N>
+__device__ __forceinline__ double wave_lane_f64(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, N), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), N);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// trj: position j of the user's top-10 by RATING on lane j of the group (-1 where there is none).
+// own_rating: the rating at the lane's own position of the segment, fetched together with the predictions when the segment
+// fits the group (in_regs) -- the rating of a ranked position then comes through the LDS crossbar instead of a third
+// dependent memory access.  log2_j = log2_tab[max(j - 1, 0)], idcg = log2_tab[9], fetched before the ranking too.
 template <bool QUARTER>
-__device__ __forceinline__ void user_metrics(const float *__restrict__ rating, int beg, int cnt, const int (&tp)[10], const int (&tr)[10],
-                                             const double *__restrict__ log2_tab, int lane, bool have, int32_t *hits_out, double *ndcg_out)
+__device__ __forceinline__ void user_metrics(const float *__restrict__ rating, int beg, int cnt, const int (&tp)[10], const int trj,
+                                             const float own_rating, const bool in_regs, const double log2_j, const double idcg,
+                                             int lane, bool have, int32_t *hits_out, double *ndcg_out)
 {
     constexpr int K = 10;
     const int base = QUARTER ? (lane & ~15) : 0;
     const int j = lane - base;
     const int n_top = cnt < K ? cnt : K;
-    int tpj = -1, trj = -1;
+    int tpj = -1;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        tpj = j == k ? tp[k] : tpj;
-        trj = j == k ? tr[k] : trj;
-    }
+    for (int k = 0; k < K; ++k) tpj = j == k ? tp[k] : tpj;
+    const bool ranked = have && j < n_top && tpj >= 0;               // (a position is always found; the guard keeps a bad input from reading out of bounds)
+    const float from_regs = __shfl(own_rating, base + (ranked ? tpj : 0), kWave);      // every lane takes part
     double val = 0.0;
     bool hit = false;
-    if (have && j < n_top && tpj >= 0) {                             // (a position is always found; the guard keeps a bad input from reading out of bounds)
-        const double rel = (double)rating[beg + tpj];                // float32 widened (utils.py:132,153)
+    if (ranked) {
+        const double rel = (double)(in_regs ? from_regs : rating[beg + tpj]);          // float32 widened (utils.py:132,153)
         hit = rel >= (4.0 / 5.0);                                    // utils.py:175
         bool common = false;                                         // np.in1d(top_rating, top_pred)[j]
 #pragma unroll
@@ -402,15 +484,38 @@ __device__ __forceinline__ void user_metrics(const float *__restrict__ rating, i
     // computeDCG (utils.py:209-210): r[0] + np.sum(r[1:] / log2(2..10)); np.sum of 9 float64 = numpy pairwise: 8 terms
     // combined as a tree, then the 9th added.  The ideal DCG, computeDCG(np.ones(10)), is a constant: the host evaluates
     // it with numpy itself and passes it as log2_tab[9].
-    const double term = (j >= 1 && j < K) ? val / log2_tab[j - 1] : val;
+    const double term = (j >= 1 && j < K) ? val / log2_j : val;
+    // the ten terms to the group's first lane: scalar broadcasts (whole wave) or row shifts (quarter) instead of ten 64-bit
+    // ds_bpermute pairs
     double t[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) t[k] = __shfl(term, base + k, kWave);
+    t[0] = term;
+    if constexpr (QUARTER) {
+        t[1] = row_lane_f64<1>(term); t[2] = row_lane_f64<2>(term); t[3] = row_lane_f64<3>(term);
+        t[4] = row_lane_f64<4>(term); t[5] = row_lane_f64<5>(term); t[6] = row_lane_f64<6>(term);
+        t[7] = row_lane_f64<7>(term); t[8] = row_lane_f64<8>(term); t[9] = row_lane_f64<9>(term);
+    } else {
+        t[1] = wave_lane_f64<1>(term); t[2] = wave_lane_f64<2>(term); t[3] = wave_lane_f64<3>(term);
+        t[4] = wave_lane_f64<4>(term); t[5] = wave_lane_f64<5>(term); t[6] = wave_lane_f64<6>(term);
+        t[7] = wave_lane_f64<7>(term); t[8] = wave_lane_f64<8>(term); t[9] = wave_lane_f64<9>(term);
+    }
     if (have && j == 0) {
         const double dcg = t[0] + ((((t[1] + t[2]) + (t[3] + t[4])) + ((t[5] + t[6]) + (t[7] + t[8]))) + t[9]);
         *hits_out = n_hit;
-        *ndcg_out = dcg / log2_tab[K - 1];
+        *ndcg_out = dcg / idcg;
     }
+}
+
+template <bool IS_PRED, int R>
+__device__ __forceinline__ void multi_items(const float *__restrict__ val, int beg, int cnt, int lane, int (&top)[10])
+{
+    float v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int t = lane + r * kWave;
+        v[r] = t < cnt ? val[beg + t] : 0.f;
+        if (IS_PRED) v[r] = nan_last(v[r]);
+    }
+    top_k_multi<10, R>(v, cnt, lane, top);
 }
 
 // Positions of the top-10 of `val` over the segment [beg, beg + cnt) of a wave-per-user segment (any length).
@@ -422,17 +527,12 @@ __device__ __forceinline__ void rank_wide(const float *__restrict__ val, int beg
         // the common case (the items fit one per lane): ten ballots after `cnt` broadcasts, no memory access per round
         float v = lane < cnt ? val[beg + lane] : 0.f;
         if (IS_PRED) v = nan_last(v);
-        top_k_in_registers<K>(v, cnt, lane, top);
+        top_k_in_registers<K, IS_PRED>(v, cnt, lane, top);
+    } else if (cnt <= kWave * 2) {
+        // heavier users: a few entries per lane (2, or up to 8), loaded once; ten arg-max rounds in registers
+        multi_items<IS_PRED, 2>(val, beg, cnt, lane, top);
     } else if (cnt <= kWave * kRegItems) {
-        // heavier users: up to 8 entries per lane, loaded once; ten arg-max rounds in registers
-        float v[kRegItems];
-#pragma unroll
-        for (int r = 0; r < kRegItems; ++r) {
-            const int t = lane + r * kWave;
-            v[r] = t < cnt ? val[beg + t] : 0.f;
-            if (IS_PRED) v[r] = nan_last(v[r]);
-        }
-        top_k_multi<K>(v, cnt, lane, top);
+        multi_items<IS_PRED, kRegItems>(val, beg, cnt, lane, top);
     } else {
         top_k_positions<K>(val + beg, cnt, lane, top);
     }
@@ -471,18 +571,25 @@ __global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__res
     pred += (size_t)blockIdx.y * pred_stride;
     hits += (size_t)blockIdx.y * n_users;
     ndcg += (size_t)blockIdx.y * n_users;
-    int tp[K], tr[K];
+    int tp[K];
+    const int jj = (wave < n_wide ? lane : lane & 15) - 1;
     if (wave < n_wide) {
         const int user = wave;
         const int beg = off[user], cnt = off[user + 1] - beg;
+        // everything that does not depend on the ranking is requested in front of it
+        const double log2_j = log2_tab[jj >= 0 && jj < K - 1 ? jj : 0], idcg = log2_tab[K - 1];
+        const bool in_regs = cnt <= kWave;
+        const float own_rating = in_regs && lane < cnt ? rating[beg + lane] : 0.f;
+        int trj = -1;
+        if (top_rating && lane < K) trj = top_rating[(size_t)user * 10 + lane];
         rank_wide<true>(pred, beg, cnt, lane, tp);
-        if (top_rating) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) tr[k] = top_rating[(size_t)user * 10 + k];
-        } else {
+        if (!top_rating) {
+            int tr[K];
             rank_wide<false>(rating, beg, cnt, lane, tr);
+#pragma unroll
+            for (int k = 0; k < K; ++k) trj = lane == k ? tr[k] : trj;
         }
-        user_metrics<false>(rating, beg, cnt, tp, tr, log2_tab, lane, true, hits + user, ndcg + user);
+        user_metrics<false>(rating, beg, cnt, tp, trj, own_rating, in_regs, log2_j, idcg, lane, true, hits + user, ndcg + user);
         return;
     }
     const int user = n_wide + (wave - n_wide) * 4 + (lane >> 4);
@@ -490,16 +597,162 @@ __global__ __launch_bounds__(kBlock) void eval_users_kernel(const int32_t *__res
     const bool have = user < n_users;
     const int s = lane & 15;
     const int beg = have ? off[user] : 0, cnt = have ? off[user + 1] - beg : 0;       // cnt <= 16 by the caller's ordering
+    const double log2_j = log2_tab[jj >= 0 && jj < K - 1 ? jj : 0], idcg = log2_tab[K - 1];
+    const float own_rating = s < cnt ? rating[beg + s] : 0.f;
+    int trj = -1;
+    if (top_rating && have && s < K) trj = top_rating[(size_t)user * 10 + s];
     const float pv = s < cnt ? nan_last(pred[beg + s]) : 0.f;
-    top_k_quarter<K>(pv, cnt, lane, tp);
-    if (top_rating) {
+    top_k_quarter<K, true>(pv, cnt, lane, tp);
+    if (!top_rating) {
+        int tr[K];
+        top_k_quarter<K>(own_rating, cnt, lane, tr);
 #pragma unroll
-        for (int k = 0; k < K; ++k) tr[k] = have ? top_rating[(size_t)user * 10 + k] : -1;
-    } else {
-        const float rv = s < cnt ? rating[beg + s] : 0.f;
-        top_k_quarter<K>(rv, cnt, lane, tr);
+        for (int k = 0; k < K; ++k) trj = s == k ? tr[k] : trj;
     }
-    user_metrics<true>(rating, beg, cnt, tp, tr, log2_tab, lane, have, hits + (have ? user : 0), ndcg + (have ? user : 0));
+    user_metrics<true>(rating, beg, cnt, tp, trj, own_rating, true, log2_j, idcg, lane, have, hits + (have ? user : 0), ndcg + (have ? user : 0));
+}
+
+// ---- The same evaluation as two launches (what ure_eval_users / the series run when the ranking of the ratings is cached) ----
+// eval_users_kernel spends most of its VALU time behind the ranking: ten of a wave's 64 lanes (or forty, four users) divide,
+// compare and gather for the metrics.  Split: eval_rank_kernel leaves the ten predicted positions of a user PACKED in the
+// user's output slots (hits: 32 bits, ndcg: 64 bits), eval_metrics_kernel -- one THREAD per user and member, every lane busy --
+// unpacks them, computes HR / NDCG exactly as user_metrics does and overwrites the slots with the results.
+// Packing: users [n_wide, n_users) (segments <= 16): 4 bits per position in the ndcg slot; users [0, n_wide) with at most
+// kPackMax entries: 9 bits per position, seven in the ndcg slot and three in the hits slot; longer segments (rare) are finished
+// by the ranking launch itself, as before, and skipped by the second.
+constexpr int kPackMax = 512;
+
+// Sum over the 16 lanes of a DPP row (every lane ends with the total).
+__device__ __forceinline__ unsigned row_sum_u32(unsigned v)
+{
+    v += (unsigned)dpp_i<kDppQuadXor1>((int)v);
+    v += (unsigned)dpp_i<kDppQuadXor2>((int)v);
+    v += (unsigned)dpp_i<kDppHalfMirror>((int)v);
+    v += (unsigned)dpp_i<kDppRowMirror>((int)v);
+    return v;
+}
+
+// The ranking half: one member per wave.  What a wave of each class costs was measured on test sets of users with equal
+// segment lengths (tools/exp_eval_classes.py, profiles/r03/NOTES.md): the launch sits at the knee of VALU issue (12 cycles per
+// entry of an in-register ranking) and of latency times occupancy (two dependent accesses per wave, 8 waves per SIMD).  Several
+// members of a series per wave -- bounds fetched once, the M predictions requested together, ranked by one copy of the code --
+// lost at every M (2: +22 %, 5: +30 %, 10: +100 %; as unrolled bodies earlier: 69 -> 82 us).  So the instructions are what is
+// cut: wave-uniform segment bounds (a scalar loop and scalar ballots instead of exec-masked ones), the ten positions packed on
+// the scalar unit; a quarter wave does not search the lane of every rank (ten ballots, each unpacked per row) but lets every
+// lane ADD its position into the field of its rank, with a count and a rank sum that expose equal keys.
+__global__ __launch_bounds__(kBlock) void eval_rank_kernel(const int32_t *__restrict__ off, int32_t n_users, int32_t n_wide,
+                                                           const float *__restrict__ pred, const float *__restrict__ rating,
+                                                           const int32_t *__restrict__ top_rating, const double *__restrict__ log2_tab,
+                                                           int32_t *__restrict__ hits, double *__restrict__ ndcg, int64_t pred_stride)
+{
+    constexpr int K = 10;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6));
+    pred += (size_t)blockIdx.y * pred_stride;
+    hits += (size_t)blockIdx.y * n_users;
+    ndcg += (size_t)blockIdx.y * n_users;
+    if (wave < n_wide) {
+        const int user = wave;
+        const int beg = __builtin_amdgcn_readfirstlane(off[user]), cnt = __builtin_amdgcn_readfirstlane(off[user + 1]) - beg;
+        int tp[K];
+        rank_wide<true>(pred, beg, cnt, lane, tp);
+        if (cnt > kPackMax) {                                       // too long to pack: finished here
+            const int jj = lane - 1;
+            const int trj = lane < K ? top_rating[(size_t)user * 10 + lane] : -1;
+            user_metrics<false>(rating, beg, cnt, tp, trj, 0.f, false, log2_tab[jj >= 0 && jj < K - 1 ? jj : 0], log2_tab[K - 1], lane, true,
+                                hits + user, ndcg + user);
+            return;
+        }
+        unsigned long long lo = 0;
+        unsigned hi = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) lo |= (unsigned long long)(tp[k] & 511) << (9 * k);
+#pragma unroll
+        for (int k = 7; k < K; ++k) hi |= (unsigned)(tp[k] & 511) << (9 * (k - 7));
+        if (lane == 0) {
+            hits[user] = (int32_t)hi;
+            ndcg[user] = __builtin_bit_cast(double, lo);
+        }
+        return;
+    }
+    const int user = n_wide + (wave - n_wide) * 4 + (lane >> 4);
+    if (n_wide + (wave - n_wide) * 4 >= n_users) return;
+    const bool have = user < n_users;
+    const int s = lane & 15;
+    const int beg = have ? off[user] : 0, cnt = have ? off[user + 1] - beg : 0;       // cnt <= 16 by the caller's ordering
+    const float pv = s < cnt ? nan_last(pred[beg + s]) : -__builtin_inff();           // lanes past the segment: greater than nothing
+    const int n_top = cnt < K ? cnt : K;
+    int rank = 0;
+    quarter_rank_steps_strict<1>(__builtin_bit_cast(int, pv), pv, rank);
+    // positions 0-4 in w0, 5-9 in w1 (4 bits each); chk = (lanes with one of the first n_top ranks) << 16 | the sum of those ranks
+    bool in_top = s < cnt && rank < n_top;
+    unsigned w0 = row_sum_u32(in_top && rank < 5 ? (unsigned)s << (4 * rank) : 0u);
+    unsigned w1 = row_sum_u32(in_top && rank >= 5 ? (unsigned)s << (4 * (rank - 5)) : 0u);
+    const unsigned chk = row_sum_u32(in_top ? 0x10000u + (unsigned)rank : 0u);
+    // distinct keys: n_top lanes with the ranks 0 .. n_top - 1.  Equal keys among the first n_top leave a rank out (the sum falls
+    // short) or bring more lanes in (the count exceeds n_top): the wave then counts again with the position as the tie-break.
+    const bool tie = chk != ((unsigned)n_top << 16) + (unsigned)(n_top * (n_top - 1) / 2);
+    if (__builtin_amdgcn_ballot_w64(tie) != 0) {
+        rank = 0;
+        quarter_rank_steps<1>(__builtin_bit_cast(int, pv), s, cnt, pv, rank);
+        in_top = s < cnt && rank < n_top;
+        w0 = row_sum_u32(in_top && rank < 5 ? (unsigned)s << (4 * rank) : 0u);
+        w1 = row_sum_u32(in_top && rank >= 5 ? (unsigned)s << (4 * (rank - 5)) : 0u);
+    }
+    if (have && s == 0) ndcg[user] = __builtin_bit_cast(double, (unsigned long long)w0 | ((unsigned long long)w1 << 20));
+}
+
+__global__ __launch_bounds__(kBlock) void eval_metrics_kernel(const int32_t *__restrict__ off, int32_t n_users, int32_t n_wide,
+                                                              const float *__restrict__ rating, const int32_t *__restrict__ top_rating,
+                                                              const double *__restrict__ log2_tab, int32_t *hits, double *ndcg)
+{
+    constexpr int K = 10;
+    const int user = (int)blockIdx.x * kBlock + (int)threadIdx.x;
+    if (user >= n_users) return;
+    hits += (size_t)blockIdx.y * n_users;
+    ndcg += (size_t)blockIdx.y * n_users;
+    const int beg = off[user], cnt = off[user + 1] - beg;
+    if (user < n_wide && cnt > kPackMax) return;                    // finished by eval_rank_kernel
+    const unsigned long long lo = __builtin_bit_cast(unsigned long long, ndcg[user]);
+    int tp[K], tr[K];
+    if (user < n_wide) {
+        const unsigned hi = (unsigned)hits[user];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) tp[k] = (int)((lo >> (9 * k)) & 511);
+#pragma unroll
+        for (int k = 7; k < K; ++k) tp[k] = (int)((hi >> (9 * (k - 7))) & 511);
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) tp[k] = (int)((lo >> (4 * k)) & 15);
+    }
+    const int2 *__restrict__ trp = reinterpret_cast<const int2 *>(top_rating + (size_t)user * 10);     // 40 bytes per user: 8-aligned
+#pragma unroll
+    for (int k = 0; k < K; k += 2) {
+        const int2 v = trp[k / 2];
+        tr[k] = v.x;
+        tr[k + 1] = v.y;
+    }
+    const int n_top = cnt < K ? cnt : K;
+    double t[K];
+    int n_hit = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        double val = 0.0;
+        if (j < n_top) {
+            const double rel = (double)rating[beg + (tp[j] < cnt ? tp[j] : 0)];       // float32 widened (utils.py:132,153)
+            const bool hit = rel >= (4.0 / 5.0);                                       // utils.py:175
+            bool common = false;                                                       // np.in1d(top_rating, top_pred)[j]
+#pragma unroll
+            for (int q = 0; q < K; ++q) common = common || (q < n_top && tr[j] >= 0 && tp[q] == tr[j]);
+            n_hit += hit ? 1 : 0;
+            val = (hit && common) ? rel : 0.0;
+        }
+        t[j] = j >= 1 ? val / log2_tab[j - 1] : val;
+    }
+    // computeDCG (utils.py:209-210) in numpy's pairwise order, as in user_metrics
+    const double dcg = t[0] + ((((t[1] + t[2]) + (t[3] + t[4])) + ((t[5] + t[6]) + (t[7] + t[8]))) + t[9]);
+    hits[user] = n_hit;
+    ndcg[user] = dcg / log2_tab[K - 1];
 }
 
 // utils.py:163-184 tail: rmse = sqrt(sse / n_rows), ndcg = mean(ndcg), hr = mean(hits / 10), reduced on
@@ -625,6 +878,21 @@ static unsigned eval_user_blocks(int32_t n_users, int32_t n_wide)
     return (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
 }
 
+// HR / NDCG of every user for n_series members (member m: pred + m * pred_stride, hits / ndcg + m * n_users).
+static void launch_eval_users(const int32_t *off, int32_t n_users, int32_t n_wide, const float *pred, const float *rating,
+                              const int32_t *top_rating, const double *log2_tab, int32_t *hits, double *ndcg, int64_t pred_stride,
+                              int n_series, hipStream_t st)
+{
+    const dim3 grid(eval_user_blocks(n_users, n_wide), (unsigned)n_series);
+    if (!top_rating) {                  // no cached ranking of the ratings: the one-launch form ranks them too
+        hipLaunchKernelGGL(eval_users_kernel, grid, dim3(kBlock), 0, st, off, n_users, n_wide, pred, rating, top_rating, log2_tab, hits, ndcg, pred_stride);
+        return;
+    }
+    hipLaunchKernelGGL(eval_rank_kernel, grid, dim3(kBlock), 0, st, off, n_users, n_wide, pred, rating, top_rating, log2_tab, hits, ndcg, pred_stride);
+    hipLaunchKernelGGL(eval_metrics_kernel, dim3((unsigned)((n_users + kBlock - 1) / kBlock), (unsigned)n_series), dim3(kBlock), 0, st, off, n_users,
+                       n_wide, rating, top_rating, log2_tab, hits, ndcg);
+}
+
 int ure_eval_rank_ratings(const int32_t *off, int32_t n_users, const float *rating, int32_t *top_rating, void *stream)
 {
     URE_ARG(off && rating && top_rating && n_users >= 0);
@@ -640,8 +908,7 @@ int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const
 {
     URE_ARG(off && pred && rating && log2_tab && hits && ndcg && n_users >= 0 && n_wide >= 0 && n_wide <= n_users);
     if (n_users == 0) return 0;
-    hipLaunchKernelGGL(eval_users_kernel, dim3(eval_user_blocks(n_users, n_wide)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), off, n_users,
-                       n_wide, pred, rating, top_rating, log2_tab, hits, ndcg, (int64_t)0);
+    launch_eval_users(off, n_users, n_wide, pred, rating, top_rating, log2_tab, hits, ndcg, 0, 1, static_cast<hipStream_t>(stream));
     URE_HIP(hipGetLastError());
     return 0;
 }
@@ -684,8 +951,7 @@ int ure_eval_series(const float *const *U_fixed, const float *const *V_fixed, in
         default: return fail(-1, "ure_eval_series: unsupported d=%d", d);
     }
     if (n_users > 0)
-        hipLaunchKernelGGL(eval_users_kernel, dim3(eval_user_blocks(n_users, n_wide), (unsigned)n_series), dim3(kBlock), 0, st, off, n_users, n_wide,
-                           pred, rating, top_rating, log2_tab, hits, ndcg, n);
+        launch_eval_users(off, n_users, n_wide, pred, rating, top_rating, log2_tab, hits, ndcg, n, n_series, st);
     hipLaunchKernelGGL(eval_reduce_kernel, dim3((unsigned)n_series), dim3(1024), 0, st, hits, ndcg, n_users, sse, n, out);
     URE_HIP(hipGetLastError());
     return 0;
@@ -770,8 +1036,7 @@ int ure_eval_series_own(const float *const *U_fixed, const float *const *V_fixed
     }
 #undef URE_COMBINE
     if (n_users > 0)
-        hipLaunchKernelGGL(eval_users_kernel, dim3(eval_user_blocks(n_users, n_wide), (unsigned)n_series), dim3(kBlock), 0, st, off, n_users, n_wide,
-                           pred, rating, top_rating, log2_tab, hits, ndcg, n);
+        launch_eval_users(off, n_users, n_wide, pred, rating, top_rating, log2_tab, hits, ndcg, n, n_series, st);
     hipLaunchKernelGGL(eval_reduce_kernel, dim3((unsigned)n_series), dim3(1024), 0, st, hits, ndcg, n_users, sse, n, out);
     URE_HIP(hipGetLastError());
     return 0;
