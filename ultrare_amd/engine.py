@@ -129,8 +129,7 @@ def build_shards(triples, n_user, n_item, device=None, keep_positions=False):
             raise ValueError('a shard needs at least one interaction')
         if not (len(iid) == n and len(rating) == n):
             raise ValueError('uid / iid / rating lengths differ')
-        if uid.min() < 0 or uid.max() >= n_user or iid.min() < 0 or iid.max() >= n_item:
-            raise ValueError('user or item id outside [0, n_user) x [0, n_item)')
+        # (ids outside [0, n_user) x [0, n_item) are refused by the native builder, which walks the arrays anyway)
         cols.append((uid, iid, rating))
     S = len(cols)
     al = lambda x: (x + 7) // 8 * 8                              # every array starts on a 32-byte boundary
