@@ -137,7 +137,13 @@ def build_shards(triples, n_user, n_item, device=None, keep_positions=False):
     stage = rng.STAGING.take((sum(words),), torch.int32)
     host = stage.numpy()
     off = np.concatenate([[0], np.cumsum(words)]).astype(np.int64)
-    n_slots, n_active = nv.build_layouts(cols, n_user, n_item, [host[off[s]:off[s + 1]] for s in range(S)], threads=min(S, rng.host_cpus()))
+    try:
+        n_slots, n_active = nv.build_layouts(cols, n_user, n_item, [host[off[s]:off[s + 1]] for s in range(S)], threads=min(S, rng.host_cpus()))
+    except nv.NativeError as e:
+        rng.STAGING.give(stage, None)
+        if 'outside' in str(e):
+            raise ValueError(f'user or item id outside [0, n_user) x [0, n_item): {e}') from None
+        raise
     used = [al(3 * int(k) + 5 * rows) for k in n_slots]
     d_off = np.concatenate([[0], np.cumsum(used)]).astype(np.int64)
     blob = torch.empty(int(d_off[-1]), dtype=torch.int32, device=dev)
