@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tools'))
 from ultrare_amd import rng
 import e2e_sisa
 
+KW = dict(shards=int(sys.argv[1]), k=int(sys.argv[2])) if len(sys.argv) > 2 else {}
 real = rng.draws_batch_async
 cache = {}
 
@@ -26,6 +27,6 @@ out = {}
 for name, fn in (('draws as in the product', real), ('draws memoised (free)', memo)):
     rng.draws_batch_async = fn
     rng.release = (lambda perms: None) if fn is memo else rng.release
-    ts = [e2e_sisa.measure(reps=4)['learn_s'] * 1e3 for _ in range(4)]
+    ts = [e2e_sisa.measure(reps=4, **KW)['learn_s'] * 1e3 for _ in range(4)]
     out[name] = {'learn_ms_median': round(statistics.median(ts), 2), 'learn_ms_min': round(min(ts), 2)}
 print(json.dumps(out))

@@ -79,12 +79,17 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
         futures = {}
         try:
             specs, order = [], []
+            # permutation chunks: 8 epochs each for a few shards (a 5-shard call: 8 -> 13.8 / 11.7 ms learn / unlearn, 17 -> 19.7 /
+            # 14.2), larger ones when many shards make many chunk uploads (16 shards: 8 -> 21.6 / 23.2, 13 -> 20.9 / 20.1;
+            # tools/ab_host.py medians): about 64 chunks per call.  URE_CHUNK_EPOCHS overrides.
+            n_owned = sum(1 for pos in range(len(ids)) if owner[pos] == rank)
+            chunk_epochs = int(os.environ.get('URE_CHUNK_EPOCHS', '0')) or max(8, -(-epochs * n_owned // 64))
             for pos, i in enumerate(ids):
                 loader = as_loader(train_dlist[i])
                 base = dict(start_state=starts[pos], n_user=n_user, n_item=n_item, k=k, epochs=epochs, with_total_test=True)
                 if owner[pos] == rank:
                     specs.append(dict(base, n_rows=len(loader.dataset), shuffle=loader.shuffle, device=engine._device(),
-                                      chunk_epochs=int(os.environ.get('URE_CHUNK_EPOCHS', '8'))))
+                                      chunk_epochs=chunk_epochs))
                     order.append(i)
                 elif foreign_u0 is not None:
                     specs.append(dict(base, n_rows=0, shuffle=False, want_perms=False))
