@@ -569,6 +569,14 @@ class TrainJob:
         """Per-epoch sum of squared training errors (host float64 array; synchronises)."""
         return self.state[s]['sse'].double().sum(dim=1).cpu().numpy()
 
+    def epoch_sse_all(self):
+        """epoch_sse of every shard, [n_shards, epochs], read in ONE copy (a copy per shard is a synchronisation per shard:
+        0.4 ms of a 5-shard call, 1.3 ms of a 16-shard one)."""
+        out = torch.empty(len(self.state), self.epochs, dtype=torch.float64, device=self.device)
+        for s, st in enumerate(self.state):
+            torch.sum(st['sse'].double(), dim=1, out=out[s])
+        return out.cpu().numpy()
+
     def close(self):
         if self._job:
             nv.lib().ure_job_destroy(self._job)
