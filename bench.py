@@ -204,7 +204,13 @@ def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_st
         if split:
             torch.manual_seed(42 + 1000 * s)                       # own shards only: any fixed init serves a throughput leg
         inits.append(rng.mf_init(spec['n_user'], spec['n_item'], d))
-        perms.append(rng.epoch_perms(rng.epoch_seeds(epochs, True), all_sizes[s], threads=min(8, os.cpu_count() or 1)))
+        # the epochs' batches as the product hands them to the device (method/sisa.py, method/scratch.py): batch tags made of the
+        # permutations on the host (struct ure_shard: file_tags); URE_HOST_TAGS=0: the permutations themselves, partitioned on the device
+        seeds_s = rng.epoch_seeds(epochs, True)
+        if os.environ.get('URE_HOST_TAGS', '1') != '0' and -(-all_sizes[s] // batch) <= 65535:
+            perms.append(rng.epoch_tags(seeds_s, all_sizes[s], batch, threads=min(8, os.cpu_count() or 1)))
+        else:
+            perms.append(rng.epoch_perms(seeds_s, all_sizes[s], threads=min(8, os.cpu_count() or 1)))
     t_rng = time.perf_counter() - t_rng
     job, shards = None, []
     if mine:

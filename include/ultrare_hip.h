@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define URE_ABI_VERSION 4
+#define URE_ABI_VERSION 5
 #define URE_MAX_MODELS_PER_CALL 32
 #define URE_SCORE_PARTIALS 2048       /* length of ure_score's sse buffer */
 
@@ -113,7 +113,7 @@ typedef struct ure_shard {
                              * writes a row's compact snapshot itself in the last step of an epoch -- every active row is
                              * rewritten in every step -- and no snapshot launch is needed; NULL: a copy kernel per epoch end. */
     /* per-epoch inputs / outputs */
-    const int32_t *perm;    /* [epochs][N] the epoch permutations (RandomSampler)   */
+    const int32_t *perm;    /* [epochs][N] the epoch permutations (RandomSampler); may be NULL when file_tags is given */
     const float   *lr;      /* [epochs] learning rate of each epoch (StepLR)        */
     float         *sse;     /* [epochs][n_user] per-user sum over the epoch of (pred - r)^2;
                              * the epoch's training loss is the sum over users       */
@@ -138,6 +138,12 @@ typedef struct ure_shard {
      * (8 * lanes slots).  Longer epochs: a row of up to 64 passes may stay on the row side -- the pass
      * masks let its lane group skip the passes without a slot of the step.                          */
     int32_t n_multi;
+    /* Alternative to `perm` (ABI 5): [epochs][N] the optimizer step of the epoch in which every interaction trains,
+     * file_tags[e][perm_e[b]] = b / batch -- what the device derives from a permutation with a two-phase radix partition
+     * (csrc/tag_prep.h), computed by the host while it expands the permutation (ure_host_randperm_tags): HALF the bytes
+     * of the permutations on their way to the device (the 180 MB of a 5-shard, 50-epoch ml-1m request were as long on
+     * PCIe as its training on the GPU), and the partition phases fall away.  NULL: tags are derived from `perm`.       */
+    const uint16_t *file_tags;
 } ure_shard_t;
 
 typedef struct ure_job ure_job_t;   /* a set of shards trained side by side */
@@ -179,6 +185,9 @@ int ure_job_train_profiled(ure_job_t *job, int64_t tick0, int64_t tick1, void *s
  * seeds[t]) for t < n_perms, as int32, computed on `n_threads` host threads (0 = all).
  * HOST memory; bit-identical to torch's CPU randperm for n < 2^32/20. */
 int ure_host_randperm(const int64_t *seeds, int n_perms, int64_t n, int32_t *out, int n_threads);
+/* The same permutations as batch tags (struct ure_shard: file_tags): tags[t][perm_t[b]] = b / batch, uint16 (needs
+ * ceil(n / batch) <= 65535 steps per epoch).  HOST memory.                                                       */
+int ure_host_randperm_tags(const int64_t *seeds, int n_perms, int64_t n, int32_t batch, uint16_t *tags, int n_threads);
 /* Moves a torch CPU generator state (the bytes of torch.get_rng_state(): u64 seed, i32 left, i32 seeded,
  * u64 next, u64 state[624], ...) past `n_draws` 32-bit MT19937 outputs without producing them: the model
  * init fills the reference discards (utils.py:31-40: the nn.Embedding constructors' fills) and, in a

@@ -687,3 +687,21 @@ def test_work_units_of_several_passes(lib):
             assert pieces[0][0] == beg and pieces[-1][1] == end and all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
         if passes > 1:
             assert len(units) < len(lib.build_units(sched, sh.n_active, d, 1))
+
+
+def test_host_batch_tags_are_the_inverse_permutation_in_batches():
+    """ure_host_randperm_tags (struct ure_shard: file_tags): tags[t][perm_t[b]] = b // batch for the very permutations
+    ure_host_randperm / torch.randperm give -- the numbers the device otherwise derives from perm (csrc/tag_prep.h)."""
+    from ultrare_amd import rng
+    seeds = [3, 2 ** 40 + 17, 99, 12345678901]
+    for n, batch in ((1, 5), (7, 3), (1000, 64), (30001, 30000), (180000, 30000), (5000, 1)):
+        if -(-n // batch) > 65535:
+            continue
+        perms = rng.epoch_perms(seeds, n).numpy()
+        tags = rng.epoch_tags(seeds, n, batch, threads=3).numpy().view(np.uint16)
+        want = np.empty_like(tags)
+        for t in range(len(seeds)):
+            want[t, perms[t]] = (np.arange(n) // batch).astype(np.uint16)
+        assert np.array_equal(tags, want), (n, batch)
+    with pytest.raises(Exception):
+        rng.epoch_tags(seeds, 70000, 1)                 # more than 65535 steps per epoch

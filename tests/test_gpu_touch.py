@@ -353,3 +353,30 @@ def test_touch_mode_windows_heavy_row_pass_skipping():
     assert rel(U, st.U) < 2e-5 and rel(V, st.V) < 2e-5, (rel(U, st.U), rel(V, st.V))
     np.testing.assert_allclose(np.sqrt(job.epoch_sse(0) / len(u)), losses, rtol=2e-5)
     job.close()
+
+
+@pytest.mark.parametrize('mode', ['default', 'touch', 'ahead'])
+@pytest.mark.parametrize('S,k,B,E', [(3, 32, 700, 5), (2, 16, 4000, 3), (1, 8, 90000, 2)])
+def test_host_batch_tags_train_like_permutations(mode, S, k, B, E):
+    """struct ure_shard: file_tags (ABI 5).  The same job driven by the epoch permutations (the device derives the batch tags:
+    csrc/tag_prep.h) and by the tags the host makes of the same permutations (rng.epoch_tags): identical tables and losses,
+    bit for bit, in the default kernel and in both touch modes -- riders (3 or more steps per epoch), standalone tag launches
+    (B = 4000 and 90000: 2 steps / 1 step per epoch) and the first epoch alike."""
+    from ultrare_amd import engine, rng
+    raw = O.load_csv(TRAIN)
+    parts = O.partition(*raw, O.uniform_groups(N_USER, S))
+    torch.manual_seed(7)
+    inits = [rng.mf_init(N_USER, N_ITEM, k) for _ in parts]
+    seeds = [rng.epoch_seeds(E, True) for _ in parts]
+    perms = [rng.epoch_perms(sd, len(p[0])) for sd, p in zip(seeds, parts)]
+    tags = [rng.epoch_tags(sd, len(p[0]), B) for sd, p in zip(seeds, parts)]
+    got = []
+    for feed in (perms, tags):
+        shards = [engine.ShardData(*p, N_USER, N_ITEM) for p in parts]
+        job = engine.TrainJob(shards, inits, feed, k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=mode != 'default', final_only=mode == 'ahead')
+        assert job.touch == (mode != 'default') and job.ahead == (mode == 'ahead' and max(job.steps_per_epoch(s) for s in range(S)) <= 63)
+        job.run()
+        got.append([(job.tables(s)[0].cpu().numpy().copy(), job.tables(s)[1].cpu().numpy().copy(), job.epoch_sse(s)) for s in range(S)])
+        job.close()
+    for a, b in zip(*got):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])

@@ -11,7 +11,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('URE_LIB') or os.path.join(_PKG, 'libultrare_hip.so')      # URE_LIB: experiment builds (tools/) only
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_MODELS_PER_CALL = 32
 
 _vp = ctypes.c_void_p
@@ -32,6 +32,7 @@ class UreShard(ctypes.Structure):
         ('batch', _i32), ('epochs', _i32),
         ('lam', ctypes.c_float), ('mu', ctypes.c_float),
         ('touch_mode', _i32), ('n_multi', _i32),
+        ('file_tags', _vp),
     ]
 
 
@@ -55,6 +56,7 @@ _PROTOTYPES = {
     'ure_job_train_profiled': (ctypes.c_int, [_vp, _i64, _i64, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
                                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64)]),
     'ure_host_randperm': (ctypes.c_int, [_vp, ctypes.c_int, _i64, _vp, ctypes.c_int]),
+    'ure_host_randperm_tags': (ctypes.c_int, [_vp, ctypes.c_int, _i64, _i32, _vp, ctypes.c_int]),
     'ure_host_mt_advance': (ctypes.c_int, [_vp, _i64, _i64]),
     'ure_host_read_csv': (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                          ctypes.POINTER(_i64), ctypes.c_int]),

@@ -144,6 +144,40 @@ extern "C" int ure_host_randperm(const int64_t *seeds, int n_perms, int64_t n, i
     return 0;
 }
 
+extern "C" int ure_host_randperm_tags(const int64_t *seeds, int n_perms, int64_t n, int32_t batch, uint16_t *tags, int n_threads)
+{
+    if (!seeds || !tags || n_perms < 0 || n < 0 || batch <= 0) return ure::fail(-1, "ure_host_randperm_tags: bad arguments");
+    if (n >= (int64_t)(0xffffffffu / 20)) return ure::fail(-1, "ure_host_randperm_tags: n=%lld uses ATen's large-n branch, not restated", (long long)n);
+    if ((n + batch - 1) / batch > 65535) return ure::fail(-1, "ure_host_randperm_tags: more than 65535 steps per epoch");
+    if (n_perms == 0 || n == 0) return 0;
+    int nt = n_threads > 0 ? n_threads : ure::host_threads();
+    nt = nt < 1 ? 1 : (nt > n_perms ? n_perms : nt);
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        std::vector<uint32_t> z;
+        std::vector<int32_t> r((size_t)n);
+        for (int t = next.fetch_add(1); t < n_perms; t = next.fetch_add(1)) {
+            one_perm((uint64_t)seeds[t], n, r.data(), z);
+            // position b of the epoch trains file row r[b]: that row's step is b / batch
+            uint16_t *out = tags + (size_t)t * n;
+            int64_t b = 0;
+            for (uint32_t step = 0; b < n; ++step) {
+                const int64_t end = std::min<int64_t>(n, b + batch);
+                for (; b < end; ++b) out[r[(size_t)b]] = (uint16_t)step;
+            }
+        }
+    };
+    if (nt == 1) {
+        work();
+        return 0;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve(nt);
+    for (int t = 0; t < nt; ++t) pool.emplace_back(work);
+    for (auto &th : pool) th.join();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Skip-ahead of torch's CPU generator.  The reference draws four N(0,1) fills per model
 // (utils.py:31-40) and throws two of them away (the nn.Embedding constructors' own fills, overwritten

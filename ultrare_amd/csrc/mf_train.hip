@@ -658,7 +658,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         const bool ok = S.N > 0 && S.n_user > 0 && S.n_item > 0 && S.batch > 0 && S.epochs > 0 && pow2(S.d) && S.d >= 4 &&
                         S.d <= 256 && S.n_active >= 0 && S.n_active <= n_rows && S.units && S.n_units >= 0 &&
                         S.n_units % (kBlock / lanes_per_row(S.d)) == 0 && S.n_slots >= S.N && S.ent_oid && S.ent_r && S.ent_tag && S.ent_src &&
-                        S.file_tag && S.sched && S.U[0] && S.U[1] && S.V[0] && S.V[1] && S.mU && S.mV && S.perm && S.lr && S.sse &&
+                        S.file_tag && S.sched && S.U[0] && S.U[1] && S.V[0] && S.V[1] && S.mU && S.mV && (S.perm || S.file_tags) && S.lr && S.sse &&
                         (!S.lazy_rows || (S.U0 && S.V0 && S.lr_host));
         if (!ok) { delete job; return fail(-1, "ure_job_create: shard %d has an invalid descriptor", k); }
         if (S.d != shards[0].d) { delete job; return fail(-1, "ure_job_create: all shards of a job share d"); }

@@ -53,6 +53,7 @@ struct BatchOf {
 // Phase A, workgroup `c` of tag_ranges(N) (256 threads).
 __device__ inline void tag_partition(const ure_shard_t &S, int epoch, int c, char *lds)
 {
+    if (S.file_tags) return;                                            // the host supplies the file tags (struct ure_shard)
     int *cnt = reinterpret_cast<int *>(lds);                            // [kMaxRanges + 1]
     uint32_t *buf = reinterpret_cast<uint32_t *>(cnt + kMaxRanges + 1);  // [kRange]
     int *scan = reinterpret_cast<int *>(buf + kRange);                  // [kBlock]
@@ -122,6 +123,7 @@ __device__ inline void tag_partition(const ure_shard_t &S, int epoch, int c, cha
 // Phase B, workgroup `r` of tag_ranges(N) (256 threads).
 __device__ inline void tag_collect(const ure_shard_t &S, int r, char *lds)
 {
+    if (S.file_tags) return;
     uint16_t *img = reinterpret_cast<uint16_t *>(lds);                  // [kRange]
     int *lo = reinterpret_cast<int *>(img + kRange);                    // [kMaxRanges]
     int *hi = lo + kMaxRanges;                                          // [kMaxRanges]
@@ -161,7 +163,7 @@ __host__ __device__ inline size_t tag_buffer(const ure_shard_t &S, int epoch) { 
 __device__ inline void tag_derive(const ure_shard_t &S, int epoch, int blk, int n_blk)
 {
     const int32_t *__restrict__ ent_src = S.ent_src;
-    const uint16_t *__restrict__ file_tag = S.file_tag;
+    const uint16_t *__restrict__ file_tag = S.file_tags ? S.file_tags + (size_t)epoch * S.N : S.file_tag;
     uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, epoch);
     const int64_t n8 = S.n_slots / 8;
     for (int64_t q = (int64_t)blk * kBlock + threadIdx.x; q < n8; q += (int64_t)n_blk * kBlock) {

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void tag_scatter_kernel(const ure_shard_t *
 {
     const ure_shard_t &S = shards[blockIdx.y];
     const int epoch = standalone_epoch(S, tick, pass);
-    if (epoch < 0 || tag_partitioned(S.N)) return;
+    if (epoch < 0 || tag_partitioned(S.N) || S.file_tags) return;
     const int n = S.N;
     const int32_t *__restrict__ perm = S.perm + (size_t)epoch * n;
     uint16_t *__restrict__ file_tag = S.file_tag;

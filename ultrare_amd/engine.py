@@ -273,7 +273,7 @@ class TrainJob:
 
     shards : list[ShardData]
     inits  : list of (U0 [n_user,k], V0 [n_item,k]) float32 numpy / CPU tensors
-    perms  : list of int32 [epochs, N_s] arrays (numpy or torch; CPU or device)
+    perms  : list of int32 [epochs, N_s] arrays (numpy or torch; CPU or device), or int16 batch tags (rng.epoch_tags)
     """
 
     def __init__(self, shards, inits, perms, k, batch, epochs, lr, lam, momentum, lr_decay=1.0, lr_step=50, lazy_rows=None, snapshots=False,
@@ -349,7 +349,9 @@ class TrainJob:
             elif getattr(perm, '_ure_event', None) is not None:     # uploaded on a side stream (rng.epoch_perms_async)
                 torch.cuda.current_stream(dev).wait_event(perm._ure_event)
             assert perm.shape == (self.epochs, sh.N), f'perm of shard {s} must be [epochs, N]'
-            perm = perm.to(device=dev, dtype=torch.int32).contiguous()
+            # int16: not permutations but the batch tags the host made of them (rng.epoch_tags; struct ure_shard: file_tags)
+            as_tags = perm.dtype == torch.int16
+            perm = perm.to(device=dev, dtype=torch.int16 if as_tags else torch.int32).contiguous()
             sse = views[4].view(self.epochs, sh.n_user)
             self.state.append({'U': U, 'V': V, 'mU': mU, 'mV': mV, 'perm': perm, 'sse': sse})
             D = descs[s]
@@ -369,7 +371,8 @@ class TrainJob:
             D.U[0], D.U[1] = nv.ptr(U[0]), nv.ptr(U[1])
             D.V[0], D.V[1] = nv.ptr(V[0]), nv.ptr(V[1])
             D.mU, D.mV = nv.ptr(mU), nv.ptr(mV)
-            D.perm, D.lr, D.sse = nv.ptr(perm), nv.ptr(self.lr), nv.ptr(sse)
+            D.perm, D.lr, D.sse = (None if as_tags else nv.ptr(perm)), nv.ptr(self.lr), nv.ptr(sse)
+            D.file_tags = nv.ptr(perm) if as_tags else None
             D.N, D.n_user, D.n_item, D.d = sh.N, sh.n_user, sh.n_item, self.d
             D.batch, D.epochs = self.batch, self.epochs
             D.lam, D.mu = float(lam), float(momentum)

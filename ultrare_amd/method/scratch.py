@@ -42,8 +42,13 @@ def prepare_shard(train_loader, n_user, n_item, k, epochs, has_total, given_mode
         V0 = given_model.item_mat.weight.detach().float().cpu()
     seeds = rng.epoch_seeds(epochs, has_total)
     n = len(loader.dataset)
+    # the permutations go to the device as batch tags (rng.epoch_tags; struct ure_shard: file_tags): half the bytes, and the device
+    # does not partition them (URE_HOST_TAGS=0: as permutations)
+    tags = loader.batch_size if os.environ.get('URE_HOST_TAGS', '1') != '0' and 0 < -(-n // max(loader.batch_size, 1)) <= 65535 else 0
     if loader.shuffle and defer:
-        perms = rng.epoch_perms_async(seeds, n, threads=PERM_THREADS, pooled=True, device=engine._device())
+        perms = rng.epoch_perms_async(seeds, n, threads=PERM_THREADS, pooled=True, device=engine._device(), tags_batch=tags)
+    elif loader.shuffle and tags and n < (2 ** 32 - 1) // 20:
+        perms = rng.epoch_tags(seeds, n, tags, threads=PERM_THREADS)
     elif loader.shuffle:
         perms = rng.epoch_perms(seeds, n, threads=PERM_THREADS, pooled=True)
     else:

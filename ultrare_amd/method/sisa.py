@@ -89,6 +89,7 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
                 base = dict(start_state=starts[pos], n_user=n_user, n_item=n_item, k=k, epochs=epochs, with_total_test=True)
                 if owner[pos] == rank:
                     specs.append(dict(base, n_rows=len(loader.dataset), shuffle=loader.shuffle, device=engine._device(),
+                                      tags_batch=loader.batch_size if os.environ.get('URE_HOST_TAGS', '1') != '0' else 0,
                                       chunk_epochs=chunk_epochs))
                     order.append(i)
                 elif foreign_u0 is not None:
@@ -285,6 +286,7 @@ class Sisa(Scratch):
                 for pos, i in enumerate(mine):
                     early[i] = (job.early_scores(pos, as_loader(test_dlist[i]).eval_set()), job.early_scores(pos, total_ev))
             job.run()
+            self._rows_dev(mine[0])             # (the merge's row lists go up while the device works through the launches)
             engine.mark(f'launched (waited {getattr(job, "chunk_wait_s", 0.0) * 1e3:.2f} ms for permutation chunks)')
             for i in mine:
                 rng.release(prepared[i][2])                 # uploaded: host buffers go back to the pool
@@ -359,7 +361,11 @@ class Sisa(Scratch):
             logs[i] = entry
         engine.mark('logs_read')
         if job is not None:
-            job.close()
+            # the job's device memory is returned by a worker: ure_job_destroy waits for the device and takes 0.2-0.4 ms, and
+            # nothing below needs it (the models are copies, the logs are on the host)
+            from .. import rng
+            rng.worker_pool().submit(job.close)
+        engine.mark('job_closed')
         if dist:
             gathered = [None] * world
             dist.all_gather_object(gathered, logs)
@@ -370,6 +376,7 @@ class Sisa(Scratch):
             self.log['time'] += ['00:00:00'] * self.epochs
             if rank == 0:
                 self.save(out[i], save_dir, i + 1)
+        engine.mark('logs_appended')
         return out
 
     # ------------------------------------------------------------------ learn
@@ -392,9 +399,11 @@ class Sisa(Scratch):
         # merge user mat (sisa.py:52-58)
         merged = torch.zeros_like(self.model_list[0].user_mat.weight.detach()).contiguous()
         self._merge(merged, range(self.n_group))
+        engine.mark('merged')
 
         # total test
         self.test(test_data, verbose, save_dir)
+        engine.mark('tested')
         return self.model_list
 
     # ------------------------------------------------------------------ unlearn

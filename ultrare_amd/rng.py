@@ -253,8 +253,19 @@ _EXPANDER = None
 _UPLOAD_STREAMS = {}
 
 
-def epoch_perms_async(seeds, n, threads=0, pooled=False, device=None):
-    """epoch_perms on a background thread: returns a future whose result() is the tensor.  The seeds
+def epoch_tags(seeds, n, batch, threads=0):
+    """[len(seeds), n] int16 (uint16 bits): tags[t][perm_t[b]] = b // batch for perm_t = the permutation of epoch_perms -- the
+    step of the epoch in which every interaction trains (ure_host_randperm_tags; struct ure_shard: file_tags)."""
+    from . import _native as nv
+    nv.lib()
+    sd = np.asarray(seeds, dtype=np.uint64).astype(np.int64)
+    out = torch.empty((len(sd), int(n)), dtype=torch.int16)
+    nv.check(nv.lib().ure_host_randperm_tags(sd.ctypes.data, len(sd), int(n), int(batch), out.data_ptr(), int(threads or 0)), 'ure_host_randperm_tags')
+    return out
+
+
+def epoch_perms_async(seeds, n, threads=0, pooled=False, device=None, tags_batch=0):
+    """epoch_perms on a background thread (tags_batch = B > 0: the batch tags of those permutations instead, int16: epoch_tags): returns a future whose result() is the tensor.  The seeds
     are already drawn, so expanding them needs nothing from torch's generator and overlaps with the
     caller's next draws (the next shard's model init); the native call runs without the GIL.
     With `device` the worker also uploads the permutations on a side stream as soon as they exist;
@@ -274,7 +285,9 @@ def epoch_perms_async(seeds, n, threads=0, pooled=False, device=None):
             def result(self_inner):
                 return out
         return _Done()
-    out = POOL.take((len(seeds), n), torch.int32) if pooled else torch.empty(len(seeds), n, dtype=torch.int32)
+    tags_batch = int(tags_batch) if 0 < -(-n // max(int(tags_batch), 1)) <= 65535 else 0
+    word = torch.int16 if tags_batch else torch.int32
+    out = POOL.take((len(seeds), n), word) if pooled else torch.empty(len(seeds), n, dtype=word)
     sd = np.asarray(seeds, dtype=np.uint64).astype(np.int64)
 
     on_dev = ready = None
@@ -282,12 +295,15 @@ def epoch_perms_async(seeds, n, threads=0, pooled=False, device=None):
         # destination allocated here, on the caller's stream (the allocator's pools are per stream);
         # the side stream starts its copy only after whatever the caller's stream was doing with that memory
         dev = torch.device(device)
-        on_dev = torch.empty((len(seeds), n), dtype=torch.int32, device=dev)
+        on_dev = torch.empty((len(seeds), n), dtype=word, device=dev)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
 
     def work():
-        nv.check(nv.lib().ure_host_randperm(sd.ctypes.data, len(sd), n, out.data_ptr(), int(threads or 0)), 'ure_host_randperm')
+        if tags_batch:
+            nv.check(nv.lib().ure_host_randperm_tags(sd.ctypes.data, len(sd), n, tags_batch, out.data_ptr(), int(threads or 0)), 'ure_host_randperm_tags')
+        else:
+            nv.check(nv.lib().ure_host_randperm(sd.ctypes.data, len(sd), n, out.data_ptr(), int(threads or 0)), 'ure_host_randperm')
         if on_dev is None:
             return out
         dev = on_dev.device
@@ -326,7 +342,7 @@ class _DrawsTask:
     per step of the generator.  Buffers and events are created on the calling thread (the pool and the allocator see the
     caller's current stream)."""
 
-    def __init__(self, start_state, n_user, n_item, k, epochs, with_total_test, n_rows, shuffle, threads, device, want_perms, chunk_epochs):
+    def __init__(self, start_state, n_user, n_item, k, epochs, with_total_test, n_rows, shuffle, threads, device, want_perms, chunk_epochs, tags_batch=0):
         from . import _native as nv
         nv.lib()
         self.args = (start_state, n_user, n_item, k, epochs, with_total_test, n_rows, shuffle, int(threads or 0), want_perms)
@@ -335,17 +351,22 @@ class _DrawsTask:
         self.init_value = self.perms_value = None
         self.init_done, self.error = threading.Event(), None
         big = n_rows >= (2 ** 32 - 1) // 20
+        # tags_batch = B > 0: the permutations leave the host as BATCH TAGS (uint16 [epochs, n_rows]: the step of the epoch in which
+        # every interaction trains; struct ure_shard: file_tags; engine.TrainJob tells them from permutations by their dtype) -- half
+        # the bytes on PCIe, and no partition phases on the device.  Only on the chunked device path.
+        self.tags_batch = int(tags_batch) if (self.device is not None and 0 < -(-n_rows // max(int(tags_batch), 1)) <= 65535) else 0
+        word = torch.int16 if self.tags_batch else torch.int32
         if want_perms and shuffle and n_rows > 0 and epochs > 0 and not big:
-            self.host = POOL.take((epochs, n_rows), torch.int32)
+            self.host = POOL.take((epochs, n_rows), word)
             if self.device is not None:
                 dev = self.device
-                self.on_dev = torch.empty((epochs, n_rows), dtype=torch.int32, device=dev)
+                self.on_dev = torch.empty((epochs, n_rows), dtype=word, device=dev)
                 self.ready = torch.cuda.Event()
                 self.ready.record(torch.cuda.current_stream(dev))
                 self.on_dev._ure_host = self.host
                 # chunks of at least chunk_epochs epochs and ~4 MB: every chunk costs its worker ~0.1 ms of Python (slices, a copy,
                 # an event) under the GIL, and a request of 16 small shards had 112 of them competing with the calling thread
-                chunk_epochs = max(int(chunk_epochs), -(-(4 << 20) // (4 * n_rows)))
+                chunk_epochs = max(int(chunk_epochs), -(-(4 << 20) // ((2 if self.tags_batch else 4) * n_rows)))
                 self.on_dev._ure_chunks = [(min(epochs, c0 + chunk_epochs), threading.Event(), [None]) for c0 in range(0, epochs, chunk_epochs)]
 
     def fail(self, exc):
@@ -399,7 +420,7 @@ class _DrawsTask:
             self.perms_value = self.host
             return
         dev, st, on_dev, host = self.device, self.stream, self.on_dev, self.host
-        sd_ptr, host_ptr, row_bytes = sd.ctypes.data, host.data_ptr(), 4 * n_rows
+        sd_ptr, host_ptr, row_bytes = sd.ctypes.data, host.data_ptr(), (2 if self.tags_batch else 4) * n_rows
         self.perms_value = on_dev
         first = True
         c0 = 0
@@ -407,7 +428,10 @@ class _DrawsTask:
             if _TEST_CHUNK_DELAY_S:
                 import time
                 time.sleep(_TEST_CHUNK_DELAY_S)
-            nv.check(L.ure_host_randperm(sd_ptr + 8 * c0, c1 - c0, n_rows, host_ptr + row_bytes * c0, threads), 'ure_host_randperm')
+            if self.tags_batch:
+                nv.check(L.ure_host_randperm_tags(sd_ptr + 8 * c0, c1 - c0, n_rows, self.tags_batch, host_ptr + row_bytes * c0, threads), 'ure_host_randperm_tags')
+            else:
+                nv.check(L.ure_host_randperm(sd_ptr + 8 * c0, c1 - c0, n_rows, host_ptr + row_bytes * c0, threads), 'ure_host_randperm')
             with torch.cuda.device(dev), torch.cuda.stream(st):
                 if first:
                     st.wait_event(self.ready)
@@ -456,7 +480,8 @@ def draws_batch_async(specs, n_workers=0, gate=None):
     arguments.  -> [ShardDraws]."""
     pool = worker_pool()
     tasks = [_DrawsTask(sp['start_state'], sp['n_user'], sp['n_item'], sp['k'], sp['epochs'], sp['with_total_test'], sp.get('n_rows', 0),
-                        sp.get('shuffle', False), sp.get('threads', 0), sp.get('device'), sp.get('want_perms', True), sp.get('chunk_epochs', 8))
+                        sp.get('shuffle', False), sp.get('threads', 0), sp.get('device'), sp.get('want_perms', True), sp.get('chunk_epochs', 8),
+                        sp.get('tags_batch', 0))
              for sp in specs]
     W = max(1, min(len(tasks), int(n_workers) if n_workers else max(2, host_cpus() // 2)))
 
