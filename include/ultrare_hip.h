@@ -228,6 +228,14 @@ int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *r
  * snapshot stores), -1 otherwise.  A region can be pinned host memory: it is what goes to the device, in one copy. */
 int ure_host_build_layouts(int n_shards, const int64_t *const *uid, const int64_t *const *iid, const double *const *rating, const int64_t *n,
                            int32_t n_user, int32_t n_item, int32_t *const *region, int64_t *n_slots, int32_t *n_active, int n_threads);
+/* The same, and behind every layout the work units of table width units_d (ure_host_build_units with unit_passes 1) of its schedule:
+ *   region[s] = layout (3 k + 5 rows words) | pad to a multiple of 8 words | units [n_units[s]][4]
+ * so that one copy takes a shard's layout AND its units to the device (as two native calls with Python between them the units
+ * were 0.6-1.9 ms of a request's critical path).  region_words[s] = the words region[s] can take; n_units[s] = -1 when the
+ * units did not fit behind the layout (ask ure_host_build_units then). */
+int ure_host_build_layouts_units(int n_shards, const int64_t *const *uid, const int64_t *const *iid, const double *const *rating, const int64_t *n,
+                                 int32_t n_user, int32_t n_item, int32_t *const *region, const int64_t *region_words, int64_t *n_slots,
+                                 int32_t *n_active, int32_t units_d, int64_t *n_units, int n_threads);
 /* Cuts the active rows of a schedule into the work units of struct ure_shard for row width d and
  * packs them into workgroups.  unit_passes = scan passes of one lane group per unit: 1 everywhere, except touch
  * mode with epochs of several windows (more than 64 steps), where a unit of several passes skips the passes

@@ -705,3 +705,47 @@ def test_host_batch_tags_are_the_inverse_permutation_in_batches():
         assert np.array_equal(tags, want), (n, batch)
     with pytest.raises(Exception):
         rng.epoch_tags(seeds, 70000, 1)                 # more than 65535 steps per epoch
+
+
+def test_layouts_and_units_from_one_native_call():
+    """ure_host_build_layouts_units: the work units of a table width built behind every layout by the same call equal what
+    ure_host_build_units makes of the layout's schedule, for several shards and widths; a region too small for them reports -1
+    and leaves the layout intact."""
+    from ultrare_amd import engine, _native as nv
+    rs = np.random.RandomState(5)
+    n_user, n_item = 300, 500
+    triples = []
+    for n in (4000, 1, 2500, 9000):
+        u = rs.randint(0, n_user, n).astype(np.int64)
+        i = (rs.zipf(1.3, n) % n_item).astype(np.int64)
+        triples.append((u, i, rs.rand(n)))
+    for k in (4, 16, 32, 100, 256):
+        d = engine.pad_dim(k)
+        shards = engine.build_shards(triples, n_user, n_item, torch.device('cpu'), units_for=k)
+        plain = engine.build_shards(triples, n_user, n_item, torch.device('cpu'))
+        for sh, ref in zip(shards, plain):
+            assert (d, False) in sh._units and (d, False) not in ref._units
+            got, n_units, n_rows = sh._units[(d, False)]
+            want = nv.build_units(ref._sched_host, ref.n_active, d)
+            assert n_units == len(want) and n_rows == sh.n_active and np.array_equal(got.numpy(), want)
+            for name in ('ent_oid', 'ent_r', 'ent_src', 'sched'):
+                assert torch.equal(getattr(sh, name), getattr(ref, name))
+            assert torch.equal(sh.units(d), torch.from_numpy(want))                 # what TrainJob asks for
+    # a region without room for the units: -1, layout as usual
+    u, i, r = triples[0]
+    words = nv.layout_region_words(len(u), n_user, n_item)
+    reg = [np.zeros(words, dtype=np.int32)]
+    k0, a0 = nv.build_layouts([triples[0]], n_user, n_item, reg)
+    exact = (3 * int(k0[0]) + 5 * (n_user + n_item) + 7) // 8 * 8
+    # (the binding asks for layout_region_words() words; the library is told that only `exact` + 8 of them may be used)
+    import ctypes
+    L = nv.lib()
+    cols = [np.ascontiguousarray(t, dtype=dt) for t, dt in zip(triples[0], (np.int64, np.int64, np.float64))]
+    vp = ctypes.c_void_p
+    n = np.array([len(u)], dtype=np.int64)
+    region_words = np.array([exact + 8], dtype=np.int64)
+    n_slots, n_active, n_units = np.zeros(1, np.int64), np.zeros(1, np.int32), np.zeros(1, np.int64)
+    nv.check(L.ure_host_build_layouts_units(1, (vp * 1)(cols[0].ctypes.data), (vp * 1)(cols[1].ctypes.data), (vp * 1)(cols[2].ctypes.data), n.ctypes.data,
+                                            n_user, n_item, (vp * 1)(reg[0].ctypes.data), region_words.ctypes.data, n_slots.ctypes.data,
+                                            n_active.ctypes.data, 32, n_units.ctypes.data, 1), 'ure_host_build_layouts_units')
+    assert n_units[0] == -1 and n_slots[0] == k0[0] and n_active[0] == a0[0]

@@ -67,6 +67,8 @@ _PROTOTYPES = {
                                              ctypes.POINTER(_i64), ctypes.POINTER(_i32), _vp, _vp]),
     'ure_host_build_layouts': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i32, _i32,
                                               ctypes.POINTER(_vp), _vp, _vp, ctypes.c_int]),
+    'ure_host_build_layouts_units': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i32, _i32,
+                                                    ctypes.POINTER(_vp), _vp, _vp, _vp, _i32, _vp, ctypes.c_int]),
     'ure_host_build_units': (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _i64, ctypes.POINTER(_i64)]),
     'ure_score': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_int, _vp, _vp, _vp, _i64, ctypes.c_int, _vp, _vp, _vp]),
@@ -222,9 +224,20 @@ def layout_region_words(n, n_user, n_item):
     return 3 * layout_capacity(n, n_user, n_item) + 5 * (n_user + n_item)
 
 
-def build_layouts(triples, n_user, n_item, regions, threads=0):
+def units_capacity_words(n, n_user, n_item, d):
+    """int32 words to leave behind a packed layout region for the work units of table width d (ure_host_build_layouts_units): a
+    generous bound -- a row has ceil(slots / (8 lanes)) units, workgroups are padded to 256 / lanes units; when it is too small
+    after all the native builder says so (n_units = -1) and the units are built on their own."""
+    lanes = d // 4 if d <= 32 else d // 8
+    rows = n_user + n_item
+    return 4 * (2 * (layout_capacity(n, n_user, n_item) // (8 * lanes) + rows) + 2 * (256 // lanes)) + 8
+
+
+def build_layouts(triples, n_user, n_item, regions, threads=0, units_d=0):
     """ure_host_build_layouts: triples = [(uid int64, iid int64, rating float64)], regions = [int32 numpy views of
-    layout_region_words() words] -> (n_slots [S], n_active [S])."""
+    layout_region_words() words] -> (n_slots [S], n_active [S]).  units_d: also the work units of that table width, behind each
+    layout (ure_host_build_layouts_units; regions then hold layout_region_words() + units_capacity_words() words)
+    -> (n_slots, n_active, n_units [S] (-1: did not fit))."""
     S = len(triples)
     keep = []
     def col(c, dt):
@@ -237,6 +250,13 @@ def build_layouts(triples, n_user, n_item, regions, threads=0):
         assert len(r) >= layout_region_words(len(t[0]), n_user, n_item)
     reg = (_vp * S)(*[r.ctypes.data for r in regions])
     n_slots, n_active = np.zeros(S, dtype=np.int64), np.zeros(S, dtype=np.int32)
+    if units_d:
+        words = np.array([len(r) for r in regions], dtype=np.int64)
+        n_units = np.zeros(S, dtype=np.int64)
+        check(lib().ure_host_build_layouts_units(S, col(0, np.int64), col(1, np.int64), col(2, np.float64), n.ctypes.data, n_user, n_item, reg,
+                                                 words.ctypes.data, n_slots.ctypes.data, n_active.ctypes.data, int(units_d), n_units.ctypes.data,
+                                                 int(threads)), 'ure_host_build_layouts_units')
+        return n_slots, n_active, n_units
     check(lib().ure_host_build_layouts(S, col(0, np.int64), col(1, np.int64), col(2, np.float64), n.ctypes.data, n_user, n_item, reg,
                                        n_slots.ctypes.data, n_active.ctypes.data, int(threads)), 'ure_host_build_layouts')
     return n_slots, n_active

@@ -36,6 +36,8 @@ int fail(int code, const char *fmt, ...);
 int host_threads();
 }
 
+static int build_units_impl(const int32_t *sched, int32_t n_active, int32_t d, int32_t unit_passes, int32_t *units, int64_t capacity, int64_t *n_units);
+
 namespace {
 
 // strtod-free number parsing for the plain decimals of rating files ("123", "3.5", "4.0");
@@ -292,8 +294,28 @@ int ure_host_build_layout(const int32_t *uid, const int32_t *iid, const float *r
     return build_layout_t(uid, iid, rating, n, n_user, n_item, ent_oid, ent_r, ent_src, sched, nullptr, n_slots, n_active, u_pos, i_pos, false);
 }
 
+static int build_layouts_impl(int n_shards, const int64_t *const *uid, const int64_t *const *iid, const double *const *rating, const int64_t *n,
+                              int32_t n_user, int32_t n_item, int32_t *const *region, int64_t *n_slots, int32_t *n_active, int n_threads,
+                              int32_t units_d, const int64_t *region_words, int64_t *n_units);
+
 int ure_host_build_layouts(int n_shards, const int64_t *const *uid, const int64_t *const *iid, const double *const *rating, const int64_t *n,
                            int32_t n_user, int32_t n_item, int32_t *const *region, int64_t *n_slots, int32_t *n_active, int n_threads)
+{
+    return build_layouts_impl(n_shards, uid, iid, rating, n, n_user, n_item, region, n_slots, n_active, n_threads, 0, nullptr, nullptr);
+}
+
+int ure_host_build_layouts_units(int n_shards, const int64_t *const *uid, const int64_t *const *iid, const double *const *rating, const int64_t *n,
+                                 int32_t n_user, int32_t n_item, int32_t *const *region, const int64_t *region_words, int64_t *n_slots,
+                                 int32_t *n_active, int32_t units_d, int64_t *n_units, int n_threads)
+{
+    if (!region_words || !n_units || units_d < 4 || units_d > 256 || (units_d & (units_d - 1)))
+        return ure::fail(-1, "ure_host_build_layouts_units: bad arguments");
+    return build_layouts_impl(n_shards, uid, iid, rating, n, n_user, n_item, region, n_slots, n_active, n_threads, units_d, region_words, n_units);
+}
+
+static int build_layouts_impl(int n_shards, const int64_t *const *uid, const int64_t *const *iid, const double *const *rating, const int64_t *n,
+                              int32_t n_user, int32_t n_item, int32_t *const *region, int64_t *n_slots, int32_t *n_active, int n_threads,
+                              int32_t units_d, const int64_t *region_words, int64_t *n_units)
 {
     if (n_shards <= 0 || !uid || !iid || !rating || !n || !region || !n_slots || !n_active || n_user <= 0 || n_item <= 0)
         return ure::fail(-1, "ure_host_build_layouts: bad arguments");
@@ -308,7 +330,21 @@ int ure_host_build_layouts(int n_shards, const int64_t *const *uid, const int64_
         for (int s = next.fetch_add(1); s < n_shards; s = next.fetch_add(1)) {
             const int r = build_layout_t(uid[s], iid[s], rating[s], n[s], n_user, n_item, region[s], (float *)nullptr, (int32_t *)nullptr,
                                          (int32_t *)nullptr, (int32_t *)nullptr, n_slots + s, n_active + s, (int32_t *)nullptr, (int32_t *)nullptr, true);
-            if (r) { bad[s] = r; rc.store(r); }
+            if (r) { bad[s] = r; rc.store(r); continue; }
+            if (units_d) {
+                // the work units of this table width right behind the layout, so that ONE copy takes both to the device:
+                // region = layout (3 k + 5 rows words) | pad to 8 words | units [n_units][4].  -1: they did not fit (the caller asks
+                // ure_host_build_units later)
+                const int64_t rows = (int64_t)n_user + n_item;
+                const int64_t at = (3 * n_slots[s] + 5 * rows + 7) / 8 * 8;
+                const int64_t cap = (region_words[s] - at) / 4;
+                const int32_t *sched = region[s] + 3 * n_slots[s];
+                int64_t need = 0;
+                n_units[s] = -1;
+                if (cap > 0 && build_units_impl(sched, n_active[s], units_d, 1, nullptr, 0, &need) == 0 && need <= cap &&
+                    build_units_impl(sched, n_active[s], units_d, 1, region[s] + at, cap, &need) == 0)
+                    n_units[s] = need;
+            }
         }
     };
     if (nt == 1) work();
@@ -332,6 +368,13 @@ int ure_host_build_units(const int32_t *sched, int32_t n_active, int32_t d, int3
 {
     if (!sched || !n_units || n_active < 0 || d < 4 || d > 256 || (d & (d - 1)) || unit_passes < 1 || unit_passes > 4096)
         return ure::fail(-1, "ure_host_build_units: bad arguments");
+    return build_units_impl(sched, n_active, d, unit_passes, units, capacity, n_units);
+}
+
+}  // extern "C"
+
+static int build_units_impl(const int32_t *sched, int32_t n_active, int32_t d, int32_t unit_passes, int32_t *units, int64_t capacity, int64_t *n_units)
+{
     const int lanes = d <= URE_NARROW_MAX ? d / 4 : d / 8;
     const int cap = 8 * lanes * unit_passes, upb = 256 / lanes;        // slots of a unit: unit_passes scan passes of one lane group
     auto pieces = [&](int64_t q, int32_t *len) {
@@ -393,6 +436,8 @@ int ure_host_build_units(const int32_t *sched, int32_t n_active, int32_t d, int3
     *n_units = out;
     return 0;
 }
+
+extern "C" {
 
 // utils.py:377-396 of the comparison clusterer: labels from the [n][k] distance matrix.  capacity <= 0:
 // new_label = dist.argmin(axis=1).  capacity > 0 (balanced k-means, capacity = ceil(n / k)): walk the

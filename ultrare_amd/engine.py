@@ -110,11 +110,12 @@ def _device():
     return torch.device('cuda', torch.cuda.current_device())
 
 
-def build_shards(triples, n_user, n_item, device=None, keep_positions=False):
+def build_shards(triples, n_user, n_item, device=None, keep_positions=False, units_for=None):
     """The HBM layouts of the shards of one call: triples = [(uid, iid, rating)] -> [ShardData].
     ONE native call builds every layout, side by side on host threads, packed into one pinned staging buffer (pooled);
     each goes up in one asynchronous copy on the current stream into its part of one device allocation, and the
-    engine-side scratch of all shards (batch tags, inverse-permutation stages) comes from two fills.  From pageable numpy
+    engine-side scratch of all shards (batch tags, inverse-permutation stages) comes from two fills.  units_for = a table width k:
+    the work units of that width are built by the same native call and travel in the same copies (ShardData.units finds them).  From pageable numpy
     arrays, shard after shard, the same 22 MB of a 5-shard ml-1m call took 9-10 ms of a 20 ms Sisa.learn (profiles/r03/NOTES.md)."""
     from . import rng
     n_user, n_item = int(n_user), int(n_item)
@@ -133,18 +134,23 @@ def build_shards(triples, n_user, n_item, device=None, keep_positions=False):
         cols.append((uid, iid, rating))
     S = len(cols)
     al = lambda x: (x + 7) // 8 * 8                              # every array starts on a 32-byte boundary
-    words = [al(nv.layout_region_words(len(c[0]), n_user, n_item)) for c in cols]
+    d_units = pad_dim(int(units_for)) if units_for else 0
+    words = [al(nv.layout_region_words(len(c[0]), n_user, n_item) + (nv.units_capacity_words(len(c[0]), n_user, n_item, d_units) if d_units else 0))
+             for c in cols]
     stage = rng.STAGING.take((sum(words),), torch.int32)
     host = stage.numpy()
     off = np.concatenate([[0], np.cumsum(words)]).astype(np.int64)
     try:
-        n_slots, n_active = nv.build_layouts(cols, n_user, n_item, [host[off[s]:off[s + 1]] for s in range(S)], threads=min(S, rng.host_cpus()))
+        built = nv.build_layouts(cols, n_user, n_item, [host[off[s]:off[s + 1]] for s in range(S)], threads=min(S, rng.host_cpus()), units_d=d_units)
+        n_slots, n_active = built[0], built[1]
+        n_units = built[2] if d_units else [-1] * S
     except nv.NativeError as e:
         rng.STAGING.give(stage, None)
         if 'outside' in str(e):
             raise ValueError(f'user or item id outside [0, n_user) x [0, n_item): {e}') from None
         raise
-    used = [al(3 * int(k) + 5 * rows) for k in n_slots]
+    units_at = [al(3 * int(k) + 5 * rows) for k in n_slots]                       # where a shard's units start inside its region (when built)
+    used = [a + (al(4 * int(u)) if u > 0 else 0) for a, u in zip(units_at, n_units)]
     d_off = np.concatenate([[0], np.cumsum(used)]).astype(np.int64)
     blob = torch.empty(int(d_off[-1]), dtype=torch.int32, device=dev)
     pinned = stage.is_pinned() and on_gpu
@@ -183,6 +189,8 @@ def build_shards(triples, n_user, n_item, device=None, keep_positions=False):
         sh.inv_off = zeros[z_at + a:z_at + a + b]
         z_at += a + b
         sh._units = {}
+        if n_units[s] > 0:
+            sh._units[(d_units, False)] = (part[units_at[s]:units_at[s] + 4 * int(n_units[s])].view(int(n_units[s]), 4), int(n_units[s]), sh.n_active)
         out.append(sh)
     # whoever trains on a layout from another stream (layouts may be built on a worker thread, whose current stream is the
     # device's default stream) waits for this event first: TrainJob does

@@ -150,7 +150,7 @@ def shard_layouts(loaders, n_user, n_item, device=None, units_for=None):
     with on:
         if todo:
             raw = [(l.dataset.users, l.dataset.items, l.dataset.ratings) for l in todo]
-            for l, sh in zip(todo, build_shards(raw, n_user, n_item, device)):
+            for l, sh in zip(todo, build_shards(raw, n_user, n_item, device, units_for=units_for)):
                 l._cache[key] = sh
         out = [l._cache[key] for l in loaders]
         if units_for is not None:
