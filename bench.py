@@ -367,8 +367,9 @@ def unlearn_leg(a, data, shards, d):
     sp = importlib.util.spec_from_file_location('e2e_sisa', os.path.join(ROOT, 'tools', 'e2e_sisa.py'))
     e2e = importlib.util.module_from_spec(sp)
     sp.loader.exec_module(e2e)
-    r = e2e.measure(shards, d, 50, 1, 2.0, data=data)
-    out = {'learn_wall_s': r['learn_s'], 'unlearn_wall_s': r['unlearn_s'], 'epochs': 50,
+    r = e2e.measure(shards, d, 50, 1, 2.0, data=data, reps=6)
+    out = {'learn_wall_s': r['learn_s'], 'unlearn_wall_s': r['unlearn_s'], 'learn_wall_s_all': r['learn_s_all'], 'unlearn_wall_s_all': r['unlearn_s_all'],
+           'timed': r['timed'], 'epochs': 50,
            'deleted_users': r['deleted_users'], 'retrained_shards': r['retrained_shards'],
            'unlearn_interactions': r['unlearn_interactions'],
            'layouts_built_in_timed_call': r['layouts_built'],
@@ -553,8 +554,9 @@ def main():
             leg['job'] = leg['shards'] = job = None
             un, e2e = unlearn_leg(a, leg['data'], a.shards, a.d)
             # BASELINE.json configs[4]: 16 shards (d = the reference's default k = 16), 2 % random deletion
-            r16 = e2e.measure(16, 16, 50, 1, 2.0, data=leg['data'])
+            r16 = e2e.measure(16, 16, 50, 1, 2.0, data=leg['data'], reps=4)
             un['config4_16_shards_k16'] = {'learn_wall_s': r16['learn_s'], 'unlearn_wall_s': r16['unlearn_s'],
+                                           'learn_wall_s_all': r16['learn_s_all'], 'unlearn_wall_s_all': r16['unlearn_s_all'],
                                            'retrained_shards': r16['retrained_shards'], 'deleted_users': r16['deleted_users'],
                                            'layouts_built_in_timed_call': r16['layouts_built'],
                                            'final_test': {'learn': r16['log0'], 'unlearn': r16['unlearn_log0']},

@@ -19,8 +19,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def measure(shards=5, k=32, epochs=50, parallel=1, delper=2.0, data=None, reps=3, workload='ml1m'):
-    """Wall time of Sisa.learn and Sisa.unlearn (per-epoch evals, merge and final test included) on the synthetic set;
-    the last of `reps` repetitions is reported.  Every repetition is a NEW request: its own deletion set (a different 2 %
+    """Wall time of Sisa.learn and Sisa.unlearn (per-epoch evals, merge and final test included) on the synthetic set: the
+    MEDIAN of the repetitions after the first (which warms the allocator and the pools), every sample listed beside it
+    (`learn_s_all`, `unlearn_s_all`: a single timing on a shared host is off by up to 50 %).  Every repetition is a NEW request: its own deletion set (a different 2 %
     of the users) and freshly made train loaders, so the HBM layouts of the shards it trains are built and uploaded
     INSIDE the timed calls (`layouts_built` counts them); what the earlier repetitions leave behind is a warm device
     allocator, the pinned permutation pool and the test sets (a deletion does not change them: config.py:139-172 reads
@@ -49,6 +50,7 @@ def measure(shards=5, k=32, epochs=50, parallel=1, delper=2.0, data=None, reps=3
 
     out = {'shards': a.shards, 'k': a.k, 'epochs': a.epochs, 'parallel': bool(a.parallel),
            'train_rows': int(len(data['train'][0]))}
+    t_learns, t_unlearns = [], []
     for rep in range(reps):       # earlier repetitions warm the allocator and the pinned pool; no layout survives them
         del_user = np.random.RandomState(1 + rep).choice(n_user, int(a.delper / 100 * n_user), replace=False)
         keep = ~np.isin(data['train'][0], del_user)
@@ -71,13 +73,18 @@ def measure(shards=5, k=32, epochs=50, parallel=1, delper=2.0, data=None, reps=3
         torch.cuda.synchronize()
         t_unlearn = time.perf_counter() - t0
         built_unlearn = engine.ShardData.built - built0
+        if rep > 0 or reps == 1:
+            t_learns.append(t_learn)
+            t_unlearns.append(t_unlearn)
+    t_learn, t_unlearn = float(np.median(t_learns)), float(np.median(t_unlearns))
     n_learn = len(data['train'][0]) * a.epochs
     n_un = int(keep.sum()) * a.epochs if len(s2.retrained) == a.shards else None
     nan_shards = int(sum(1 for m in s2.model_list if not bool(torch.isfinite(m.item_mat.weight).all())))
     series = {k: np.asarray(v, dtype=np.float64) for k, v in sisa.log.items() if k != 'time'}
     epoch_logs = {'entries_per_series': int(len(series['total_rmse'])), 'finite_fraction': {k: round(float(np.isfinite(v).mean()), 4) for k, v in series.items()},
                   'first_epoch': {k: float(v[0]) for k, v in series.items() if len(v)}, 'last_epoch': {k: float(v[-1]) for k, v in series.items() if len(v)}}
-    out.update(learn_s=round(t_learn, 4), unlearn_s=round(t_unlearn, 4), retrained_shards=len(s2.retrained), deleted_users=int(len(del_user)),
+    out.update(learn_s=round(t_learn, 4), unlearn_s=round(t_unlearn, 4), learn_s_all=[round(t, 4) for t in t_learns], unlearn_s_all=[round(t, 4) for t in t_unlearns],
+               timed='median of the repetitions after the first; every one a new request', retrained_shards=len(s2.retrained), deleted_users=int(len(del_user)),
                deletion_set=f'RandomState({reps}).choice: a different 2 % in every repetition',
                layouts_built={'learn': built_learn, 'unlearn': built_unlearn},
                learn_interactions_per_s=round(n_learn / t_learn, 1), log0=sisa.log0, unlearn_log0=s2.log0,
