@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define URE_ABI_VERSION 5
+#define URE_ABI_VERSION 6
 #define URE_MAX_MODELS_PER_CALL 32
 #define URE_SCORE_PARTIALS 2048       /* length of ure_score's sse buffer */
 
@@ -127,7 +127,11 @@ typedef struct ure_shard {
      * epochs longer than 64 steps are worked off in windows of 64).
      * For jobs whose tables do not fit the caches (BASELINE.json configs[3], full MF at 25 M rows).  The
      * tables can then be read (ure_job_materialize, snapshots) at the shard's epoch boundaries only.   */
-    int32_t touch_mode;     /* 0 off | 1 as above | 2 "masks one epoch ahead" (at most 63 steps per epoch, compact snapshots only): the
+    int32_t touch_mode;     /* 0 off | 1 as above | 3 "indexed" (ABI 6; at most 1008 steps per epoch; csrc/mf_index.h): at every epoch start the
+                             * epoch's slots are sorted by step, and a step launches over exactly the (row, step) runs it trains instead
+                             * of testing every work unit's masks -- for epochs of hundreds of steps (full MF at 25 M rows: 750).  Tables
+                             * readable at epoch boundaries, as mode 1; `units` is not read (n_units = 0), n_multi / n_split below.
+                             * | 2 "masks one epoch ahead" (at most 63 steps per epoch, compact snapshots only): the
                              * batch tags are prepared two epochs ahead (ent_tag then holds THREE buffers, [3][n_slots]), a row's owner
                              * advances it across the epoch boundary at its last own step, and the dense pass at every epoch start of
                              * mode 1 is gone; the tables are readable (ure_job_materialize) only once training has finished, epoch
@@ -144,6 +148,10 @@ typedef struct ure_shard {
      * of the permutations on their way to the device (the 180 MB of a 5-shard, 50-epoch ml-1m request were as long on
      * PCIe as its training on the GPU), and the partition phases fall away.  NULL: tags are derived from `perm`.       */
     const uint16_t *file_tags;
+    /* touch_mode 3: the first n_multi rows of the schedule ("heavy": >= 16 slots per step on average) get a workgroup per step
+     * each, the first n_split <= n_multi of them ("split": >= 384) one per 256 slots of the step -- their partial sums are
+     * added in a fixed order by a second launch.  n_multi <= 256.  Any values are correct; they only place the work.     */
+    int32_t n_split;
 } ure_shard_t;
 
 typedef struct ure_job ure_job_t;   /* a set of shards trained side by side */
@@ -174,6 +182,12 @@ int ure_job_materialize(ure_job_t *job, int64_t ticks_done, void *stream);
  * the window's steps (from the window's row masks) -- and window_steps[s] = the number of steps of that window;
  * pairs = -1 for a job that is not in touch mode.                                                                */
 int ure_job_touch_rows(ure_job_t *job, int64_t *pairs, int64_t *window_steps);
+/* Test aid, touch_mode 3 (synchronises): copies one array of shard `shard`'s slot index of its current epoch to HOST memory `out`
+ * (capacity bytes; out == NULL: only *bytes is set).  which: 0 step_begin u32 [steps + 1] (first sorted slot of every step, then
+ * their number) | 1 step_item u32 [steps + 1] | 2 items int32 [n][4] {row id | buffer << 31, first sorted slot, end, steps until
+ * the row's next own step | class << 16} | 3 sorted slots u32 [n][4] {opposite id | buffer << 31, rating bits, schedule index of
+ * the row | item row << 31, step} | 4 W u64 [words][rows] | 5 heavy_cnt u32 [steps] | 6 heavy_cum u32 [steps][257].           */
+int ure_job_index_read(ure_job_t *job, int shard, int which, void *out, int64_t capacity, int64_t *bytes);
 /* Measurement aid (bench.py's roofline leg): the same ticks, each kernel launch
  * bracketed by a pair of HIP events on `stream`; synchronises the stream and returns
  * the summed durations and launch counts of the step kernel and of the per-epoch

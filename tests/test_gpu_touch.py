@@ -193,8 +193,16 @@ def _truncate(part, n):
     return tuple(x[:n] for x in part)
 
 
+@pytest.fixture(params=['windows', 'index'])
+def long_epochs(request, monkeypatch):
+    """Epochs of more than 63 steps run in touch_mode 3 (csrc/mf_index.h: the epoch's slots sorted by step) by default and in 64-step
+    windows (touch_mode 1) with URE_TOUCH_INDEX=0: the long-epoch tests run both ways."""
+    monkeypatch.setenv('URE_TOUCH_INDEX', '1' if request.param == 'index' else '0')
+    return request.param
+
+
 @pytest.mark.parametrize('n_rows,B,k,E', [(None, 437, 16, 3), (None, 219, 32, 2), (27714, 37, 16, 2), (None, 219, 128, 2)])   # d = 128: two float4 per lane
-def test_touch_mode_windows_vs_oracle(n_rows, B, k, E):
+def test_touch_mode_windows_vs_oracle(n_rows, B, k, E, long_epochs):
     """65, 130 and 750 optimizer steps per epoch (full MF at 25 M rows has 750: config.py:182-188 with batch 30,000): an
     epoch is worked off in windows of 64 steps, each with its own row masks; a row that is not trained in a window is
     carried to the window's end in one closed-form step and on from there.  Against the C oracle's dense optimizer."""
@@ -211,7 +219,7 @@ def test_touch_mode_windows_vs_oracle(n_rows, B, k, E):
         init = tuple(t * 0.3 for t in init)
     perms = rng.epoch_perms(rng.epoch_seeds(E, True), len(part[0]))
     job = engine.TrainJob([engine.ShardData(*part, N_USER, N_ITEM)], [init], [perms], k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=True)
-    assert job.touch
+    assert job.touch and job.index == (long_epochs == 'index')
     job.run()
     st = O.MFState(init[0].numpy().copy(), init[1].numpy().copy())
     losses = [O.train_epoch(st, part, perms[t].numpy(), B, 1e-3, 0.1, 0.9)[0] for t in range(E)]
@@ -222,7 +230,7 @@ def test_touch_mode_windows_vs_oracle(n_rows, B, k, E):
     job.close()
 
 
-def test_touch_mode_windows_with_shards_of_different_length_and_the_steplr_boundary():
+def test_touch_mode_windows_with_shards_of_different_length_and_the_steplr_boundary(long_epochs):
     """Three shards whose epochs have 93-96 steps (one full window and a short one, ending on different ticks), 52 epochs:
     window starts of different shards fall on different ticks, and epochs 51-52 run at the decayed learning rate."""
     from ultrare_amd import engine
@@ -245,7 +253,7 @@ def test_touch_mode_windows_with_shards_of_different_length_and_the_steplr_bound
     job.close()
 
 
-def test_touch_mode_windows_match_the_default_kernel_epoch_by_epoch():
+def test_touch_mode_windows_match_the_default_kernel_epoch_by_epoch(long_epochs):
     from ultrare_amd import engine
     k, B, E = 32, 150, 3
     parts, inits, perms, shards = _setup(1, k, B, E, seed=3)
@@ -322,7 +330,7 @@ def test_touch_ahead_mode_orphans_and_table_reads():
         j.close()
 
 
-def test_touch_mode_windows_heavy_row_pass_skipping():
+def test_touch_mode_windows_heavy_row_pass_skipping(long_epochs):
     """A row far heavier than a workgroup's lane groups can cover one pass each (one item with 5,000 of the shard's 5,600 interactions)
     is cut into long work units of many scan passes; with epochs of several windows every pass carries the mask of the steps it holds
     and the lane groups skip the passes without a slot of the step.  94 steps per epoch (two windows), against the C oracle."""
@@ -344,7 +352,7 @@ def test_touch_mode_windows_heavy_row_pass_skipping():
     sh = engine.ShardData(*part, n_user, n_item)
     assert sh.max_row >= 5000
     job = engine.TrainJob([sh], [init], [perms], k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=True)
-    assert job.touch and not job.ahead
+    assert job.touch and not job.ahead and job.index == (long_epochs == 'index')
     job.run()
     st = O.MFState(init[0].numpy().copy(), init[1].numpy().copy())
     losses = [O.train_epoch(st, part, perms[t].numpy(), B, 1e-3, 0.1, 0.9)[0] for t in range(E)]
@@ -380,3 +388,77 @@ def test_host_batch_tags_train_like_permutations(mode, S, k, B, E):
         job.close()
     for a, b in zip(*got):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+# ---------------------------------------------------------------- touch_mode 3: the epoch's slots sorted by step (round 4)
+@pytest.mark.parametrize('S,k,B,E', [(1, 16, 3000, 3), (3, 32, 700, 5), (2, 64, 1500, 53), (2, 128, 500, 2), (3, 8, 450, 2)])
+def test_touch_index_mode_vs_oracle_at_any_epoch_length(S, k, B, E):
+    """touch='index' forces touch_mode 3 for short epochs too (one mask word): shards side by side, the StepLR boundary, every table
+    width -- against the C oracle's dense optimizer, and bitwise reproducible."""
+    from ultrare_amd import engine
+    parts, inits, perms, shards = _setup(S, k, B, E)
+    got = []
+    for rep in range(2):
+        job = engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, touch='index')
+        assert job.touch and job.index and not job.ahead
+        job.run()
+        got.append([(job.tables(s)[0].clone(), job.tables(s)[1].clone(), job.epoch_sse(s)) for s in range(S)])
+        job.close()
+    for s, p in enumerate(parts):
+        st = O.MFState(inits[s][0].numpy().copy(), inits[s][1].numpy().copy())
+        losses = [O.train_epoch(st, p, perms[s][t].numpy(), B, 1e-3 * 0.95 ** (t // 50), 0.1, 0.9)[0] for t in range(E)]
+        U, V, sse = got[0][s]
+        assert rel(U, st.U) < 2e-5 and rel(V, st.V) < 2e-5, (s, rel(U, st.U), rel(V, st.V))
+        np.testing.assert_allclose(np.sqrt(sse / len(p[0])), losses, rtol=2e-5)
+        assert torch.equal(U, got[1][s][0]) and torch.equal(V, got[1][s][1]) and np.array_equal(sse, got[1][s][2])
+
+
+@pytest.mark.parametrize('B,heavy,split', [(60, 16, 384), (60, 16, 8), (600, 16, 8), (600, 4, 2), (2900, 1, 1)])
+def test_touch_index_mode_heavy_and_split_rows(B, heavy, split, monkeypatch):
+    """One item with 5,000 of the shard's 5,600 interactions.  Its runs take a whole workgroup per step (heavy), or -- split -- one
+    workgroup per 256 slots of the step whose partial sums a second launch adds in part order: B = 600 gives it ~535 slots per step
+    (three parts), B = 2,900 about 2,600 (eleven parts: the top item of the 25 M set); thresholds of 1 put every row of the schedule's
+    first 256 into the workgroup classes.  Against the C oracle, with snapshots at every epoch end."""
+    from ultrare_amd import engine, rng
+    monkeypatch.setattr(engine, 'INDEX_HEAVY_SLOTS', heavy)
+    monkeypatch.setattr(engine, 'INDEX_SPLIT_SLOTS', split)
+    rs = np.random.RandomState(3)
+    n_user, n_item, k, E = 5200, 40, 16, 3
+    heavy_users = rs.permutation(n_user)[:5000]
+    u = np.concatenate([heavy_users, rs.randint(0, n_user, 600)])
+    i = np.concatenate([np.zeros(5000, dtype=np.int64), rs.randint(1, n_item, 600)])
+    key = np.unique(u.astype(np.int64) * n_item + i)
+    u, i = (key // n_item).astype(np.int32), (key % n_item).astype(np.int32)
+    r = (rs.randint(1, 6, len(u)) / 5).astype(np.float32)
+    part = (u, i, r)
+    torch.manual_seed(21)
+    init = tuple(t * 0.3 for t in rng.mf_init(n_user, n_item, k))
+    perms = rng.epoch_perms(rng.epoch_seeds(E, True), len(u))
+    sh = engine.ShardData(*part, n_user, n_item)
+    job = engine.TrainJob([sh], [init], [perms], k, B, E, 1e-3, 0.1, 0.9, 0.95, touch='index', snapshots='compact')
+    assert job.index
+    st = O.MFState(init[0].numpy().copy(), init[1].numpy().copy())
+    rows = torch.as_tensor(sh._sched_host[:sh.n_active, 0].astype(np.int64)).to(sh.device)
+    for t in range(E):
+        job.run_epochs(1)
+        loss = O.train_epoch(st, part, perms[t].numpy(), B, 1e-3, 0.1, 0.9)[0]
+        U, V = job.tables(0)
+        assert np.isfinite(st.V).all()
+        assert rel(U, st.U) < 2e-5 and rel(V, st.V) < 2e-5, (t, rel(U, st.U), rel(V, st.V))
+        np.testing.assert_allclose(np.sqrt(job.epoch_sse(0)[t] / len(u)), loss, rtol=2e-5)
+        full = torch.cat([job.padded_tables(0)[0], job.padded_tables(0)[1]])
+        assert torch.equal(job.state[0]['snap'][t], full[rows])
+    per_step = job.touch_rows_per_step()[0]
+    steps = (len(u) + B - 1) // B
+    pairs = sum(len(np.unique(np.concatenate([u[perms[E - 1].numpy()[s0:s0 + B]], n_user + i[perms[E - 1].numpy()[s0:s0 + B]]]))) for s0 in range(0, len(u), B))
+    assert abs(per_step * steps - pairs) < 0.5, (per_step * steps, pairs)          # the index holds exactly the (row, step) pairs of the last epoch
+    job.close()
+
+
+def test_touch_index_mode_refusals():
+    from ultrare_amd import engine, _native as nv
+    parts, inits, perms, shards = _setup(1, 16, 20, 1)
+    assert (len(parts[0][0]) + 19) // 20 > engine.INDEX_MAX_STEPS
+    job = engine.TrainJob(shards, inits, perms, 16, 20, 1, 1e-3, 0.1, 0.9, 0.95, touch='index')
+    assert job.touch and not job.index                 # more than 1,008 steps per epoch: windows
+    job.close()

@@ -11,7 +11,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('URE_LIB') or os.path.join(_PKG, 'libultrare_hip.so')      # URE_LIB: experiment builds (tools/) only
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_MODELS_PER_CALL = 32
 
 _vp = ctypes.c_void_p
@@ -32,7 +32,7 @@ class UreShard(ctypes.Structure):
         ('batch', _i32), ('epochs', _i32),
         ('lam', ctypes.c_float), ('mu', ctypes.c_float),
         ('touch_mode', _i32), ('n_multi', _i32),
-        ('file_tags', _vp),
+        ('file_tags', _vp), ('n_split', _i32),
     ]
 
 
@@ -53,6 +53,7 @@ _PROTOTYPES = {
     'ure_job_train': (ctypes.c_int, [_vp, _i64, _i64, _vp]),
     'ure_job_materialize': (ctypes.c_int, [_vp, _i64, _vp]),
     'ure_job_touch_rows': (ctypes.c_int, [_vp, _vp, _vp]),
+    'ure_job_index_read': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _i64, ctypes.POINTER(_i64)]),
     'ure_job_train_profiled': (ctypes.c_int, [_vp, _i64, _i64, _vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64),
                                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64)]),
     'ure_host_randperm': (ctypes.c_int, [_vp, ctypes.c_int, _i64, _vp, ctypes.c_int]),

@@ -1,0 +1,731 @@
+// mf_index.h -- touch_mode 3, "indexed": touch mode (mf_touch.h) for epochs of hundreds of optimizer steps (full MF at 25 M rows:
+// 750 steps per epoch, config.py:182-188 with batch 30,000), where a step trains 30,000 of a shard's 22.5 M interactions.
+//
+// In 64-step windows (touch_mode 1) every work unit of every row is still looked at in every step -- its masks are tested, the
+// heaviest item row has 1.9 M slots that 16 lane groups scan to find the ~2,500 of the step -- and every window start costs two
+// dense passes.  Here the slots of an epoch are SORTED BY STEP once, at the epoch's start:
+//   sslot  the slots in (step, row, file order) order -- a stable counting sort of the row-major slot array by batch tag, so a
+//          step's slots are contiguous, a row's slots of the step are contiguous inside them, and rows keep the schedule's order
+//          (heaviest first);
+//   items  one entry per (step, row) run: {row id | the buffer its weights are in, first sorted slot, end, the number of steps
+//          until the row is trained next (or the epoch ends) | class};
+// and step s launches over exactly the items of step s: a lane group per item loads the entry, then -- in one memory level -- the
+// row's weights, its momentum and the run's slots, gathers the opposite rows, applies the optimizer and advances the row to its
+// next own step in closed form (next-touch form, as in mf_touch.h).  Rows whose runs are long get whole workgroups: "heavy" rows
+// (16 or more slots per step on average) one, "split" rows (384 or more) one per 256 slots -- a single compute unit pulls
+// ~30 GB/s of gathered rows, the top item's 2,500 rows of 512 bytes would take it 44 us -- whose partial sums a second, tiny launch adds
+// in part order and applies.  No atomics on the data path: runs, partial sums and their order are fixed by the sort, results are
+// bitwise reproducible.
+//
+// The epoch start (standalone launches, mf_index launch list in index_epoch_start):
+//   masks    W[w][row]: bit b = the row is trained in step 63 w + b.  A workgroup takes 4,096 consecutive slots (at most 512 rows),
+//            ORs the tags into an LDS bitmap and stores a row's words whole; rows that straddle chunks are ORed into memory.
+//   parity   bit 63 of every word = the buffer the row's weights are in at the word's first step (a row alternates between the two
+//            weight buffers with each of its own steps); the row's first step; its buffer at the epoch's end.
+//   sort     histogram per (chunk of 4,096 slots, step) -> exclusive scan over (step, chunk) -> every wavefront scatters its chunk
+//            in slot order (equal tags inside a batch of 64 are ranked by lane with ten ballots: stable).
+//   mark     per sorted slot: the buffer its OPPOSITE row is in at that step (a gather from one column of W, which an XCD's L2
+//            holds: a step's slots all read the same word index), and the bitmap of run starts.
+//   items    scan of the run starts -> one entry per run; per step the heavy prefix and its workgroup counts.
+//   advance  every active row from "valid at the end of the last epoch" to "valid at its first step", into buffer 0 (dense, once
+//            per EPOCH; the windows of touch_mode 1 pay it every 64 steps).
+//
+// Limits: at most 1,008 steps per epoch (16 mask words of 63 steps); the tables are readable at epoch boundaries (as touch_mode 1).
+// Included by mf_train.hip after mf_touch.h.
+#pragma once
+
+namespace ure {
+
+constexpr int kIdxWin = 63;                     // steps per mask word
+constexpr int kIdxMaxWords = 16;
+constexpr int kIdxMaxSteps = kIdxWin * kIdxMaxWords;
+constexpr int kIdxChunk = 4096;                 // slots one wavefront sorts: 64 batches of 64
+constexpr int kIdxSeg = 32;                     // segments of the scan over chunks
+constexpr int kIdxFlagBlock = 2048;             // sorted slots per workgroup of the mark / emit passes
+constexpr int kIdxHeavyMax = 256;               // rows that whole workgroups take (a prefix of the schedule)
+constexpr int kIdxPart = 256;                   // slots per workgroup of a split row
+constexpr unsigned long long kIdxBits = ~(1ull << 63);
+constexpr int kIdxLight = 0, kIdxHeavy = 1, kIdxSplit = 2;
+
+#ifndef URE_INDEX_KGB
+#define URE_INDEX_KGB 4                         // rows a lane group gathers together
+#endif
+#ifndef URE_INDEX_WAVES
+#define URE_INDEX_WAVES 4
+#endif
+
+// the epoch that starts at `tick` for this shard, or -1
+__device__ __forceinline__ int idx_epoch_start(const ure_shard_t &S, const shard_aux &A, int64_t tick)
+{
+    if (S.touch_mode != 3 || tick >= (int64_t)A.steps * S.epochs) return -1;
+    const int epoch = (int)epoch_of(A, tick);
+    return tick == (int64_t)epoch * A.steps ? epoch : -1;
+}
+
+__device__ __forceinline__ int idx_buffer_at(unsigned long long word, int b) { return (int)(word >> 63) ^ (__popcll(word & kIdxBits & mask_below(b)) & 1); }
+
+// ---- once per job: which row owns every group of 8 slots (segments lie in schedule order, 8-aligned)
+__global__ __launch_bounds__(kBlock) void idx_grp_row_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux)
+{
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    if (S.touch_mode != 3) return;
+    const int64_t n_grp = S.n_slots / 8;
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < n_grp; g += (int64_t)gridDim.x * kBlock) {
+        int lo = 0, hi = S.n_active - 1;                 // the last active row whose segment starts at or before slot 8 g
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((int64_t)ldg(S.sched + 4 * (size_t)mid + 1) <= 8 * g) lo = mid; else hi = mid - 1;
+        }
+        const int row_id = ldg(S.sched + 4 * (size_t)lo);
+        stg(A.grp_row + g, lo | (row_id >= S.n_user ? (int)0x80000000 : 0));
+    }
+}
+
+// ---- epoch start 1: the step masks of every row.  Workgroup c takes the slots [4096 c, 4096 (c + 1)).
+__global__ __launch_bounds__(kBlock) void idx_masks_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    __shared__ unsigned long long bits[(kIdxChunk / 8) * kIdxMaxWords];       // [rows of the chunk][words]: 64 KB
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    const int epoch = idx_epoch_start(S, A, tick);
+    if (epoch < 0 || (int)blockIdx.x >= A.idx_chunks) return;
+    const int words = A.idx_words, steps = A.steps;
+    const int64_t n_grp = S.n_slots / 8;
+    const int64_t g_lo = (int64_t)blockIdx.x * (kIdxChunk / 8), g_hi = min(g_lo + kIdxChunk / 8, n_grp);
+    const int idx0 = ldg(A.grp_row + g_lo) & 0x7FFFFFFF;
+    const int n_rows = (ldg(A.grp_row + g_hi - 1) & 0x7FFFFFFF) - idx0 + 1;
+    for (int t = threadIdx.x; t < n_rows * words; t += kBlock) bits[t] = 0ull;
+    __syncthreads();
+    const uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, epoch);
+    for (int64_t g = g_lo + threadIdx.x; g < g_hi; g += kBlock) {
+        const int local = (ldg(A.grp_row + g) & 0x7FFFFFFF) - idx0;
+        const uint4 t4 = ldg_u4(ent_tag + g * 8);
+        const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned st = (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            if (st < (unsigned)steps) atomicOr(&bits[local * words + (int)(st / kIdxWin)], 1ull << (st % kIdxWin));
+        }
+    }
+    __syncthreads();
+    const int n_all = S.n_user + S.n_item;
+    for (int t = threadIdx.x; t < n_rows * words; t += kBlock) {
+        const int local = t / words, w = t - local * words;
+        const int4 sc = ldg_i4(S.sched + 4 * (size_t)(idx0 + local));
+        const bool inside = (int64_t)sc.y >= g_lo * 8 && (int64_t)sc.z <= g_hi * 8;
+        unsigned long long *dst = A.W + (size_t)w * n_all + sc.x;
+        if (inside) stg(dst, bits[t]);                                   // (every word of the row, zeros too: nothing to clear)
+        else if (bits[t]) atomicOr(dst, bits[t]);                        // a row that straddles chunks (its words were cleared: idx_clear_kernel)
+    }
+}
+
+// the words of the rows that straddle chunks are ORed into memory: they start from zero.  One thread per (word, chunk edge).
+__global__ __launch_bounds__(kBlock) void idx_clear_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    if (idx_epoch_start(S, A, tick) < 0) return;
+    const int n_all = S.n_user + S.n_item;
+    const int64_t n_grp = S.n_slots / 8;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < (int64_t)A.idx_chunks * 2; t += (int64_t)gridDim.x * kBlock) {
+        const int64_t c = t >> 1;
+        const int64_t g = (t & 1) ? min((c + 1) * (kIdxChunk / 8), n_grp) - 1 : c * (kIdxChunk / 8);      // the chunk's first / last group
+        const int row_id = ldg(S.sched + 4 * (size_t)(ldg(A.grp_row + g) & 0x7FFFFFFF));
+        for (int w = 0; w < A.idx_words; ++w) stg(A.W + (size_t)w * n_all + row_id, 0ull);
+    }
+}
+
+// ---- epoch start 2: bit 63 of every word, the first step, the buffer at the epoch's end.  One thread per active row.
+__global__ __launch_bounds__(kBlock) void idx_parity_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    const int epoch = idx_epoch_start(S, A, tick);
+    if (epoch < 0) return;
+    const int n_all = S.n_user + S.n_item;
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < S.n_active; idx += gridDim.x * kBlock) {
+        const int row_id = ldg(S.sched + 4 * (size_t)idx);
+        int par = 0, first = A.steps;
+        for (int w = 0; w < A.idx_words; ++w) {
+            unsigned long long *p = A.W + (size_t)w * n_all + row_id;
+            const unsigned long long v = ldg(p) & kIdxBits;
+            if (v && first == A.steps) first = w * kIdxWin + __ffsll((long long)v) - 1;
+            stg(p, v | ((unsigned long long)par << 63));
+            par ^= __popcll(v) & 1;
+        }
+        stg(A.first_step + row_id, (uint16_t)first);
+        stg(A.end_par[epoch & 1] + row_id, (uint8_t)par);
+    }
+}
+
+// ---- epoch start 3: slots per (chunk, step).  One wavefront per chunk of 4,096 slots.
+__global__ __launch_bounds__(kBlock) void idx_hist_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    __shared__ unsigned cnt[kWavesPerBlock][kIdxMaxSteps];
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    const int epoch = idx_epoch_start(S, A, tick);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = (int)blockIdx.x * kWavesPerBlock + wave;
+    if (epoch < 0 || c >= A.idx_chunks) return;                     // (wave-uniform; no workgroup barrier below)
+    const int steps = A.steps;
+    unsigned *mine = cnt[wave];
+    for (int s = lane; s < steps; s += kWave) mine[s] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    const uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, epoch);
+    const int64_t lo = (int64_t)c * kIdxChunk, hi = min(lo + kIdxChunk, S.n_slots);
+    for (int64_t p = lo + lane * 8; p < hi; p += kWave * 8) {
+        const uint4 t4 = ldg_u4(ent_tag + p);
+        const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned st = (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            if (st < (unsigned)steps) atomicAdd(&mine[st], 1u);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t *__restrict__ out = A.hist + (size_t)c * (steps + 1);
+    for (int s = lane; s < steps; s += kWave) stg(out + s, mine[s]);
+}
+
+// ---- epoch start 4: exclusive scan of hist over (step, chunk), in three launches.  Chunks are cut into 32 segments.
+__device__ __forceinline__ void idx_seg_range(const shard_aux &A, int seg, int *c0, int *c1)
+{
+    const int per = (A.idx_chunks + kIdxSeg - 1) / kIdxSeg;
+    *c0 = min(seg * per, A.idx_chunks);
+    *c1 = min(*c0 + per, A.idx_chunks);
+}
+__global__ __launch_bounds__(kBlock) void idx_scan1_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    const ure_shard_t &S = shards[blockIdx.z];
+    const shard_aux &A = aux[blockIdx.z];
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (idx_epoch_start(S, A, tick) < 0 || s >= A.steps) return;
+    int c0, c1;
+    idx_seg_range(A, (int)blockIdx.y, &c0, &c1);
+    unsigned sum = 0;
+    for (int c = c0; c < c1; ++c) sum += ldg(A.hist + (size_t)c * (A.steps + 1) + s);
+    stg(A.seg + (size_t)blockIdx.y * (A.steps + 1) + s, sum);
+}
+// one workgroup per shard: step_begin = exclusive prefix of the steps' totals; seg[y][s] <- where segment y's slots of step s start
+__global__ __launch_bounds__(1024) void idx_scan2_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    __shared__ unsigned tot[1024];
+    const ure_shard_t &S = shards[blockIdx.x];
+    const shard_aux &A = aux[blockIdx.x];
+    if (idx_epoch_start(S, A, tick) < 0) return;
+    const int s = threadIdx.x, steps = A.steps;
+    unsigned mine = 0;
+    if (s < steps)
+        for (int y = 0; y < kIdxSeg; ++y) mine += ldg(A.seg + (size_t)y * (steps + 1) + s);
+    tot[s] = mine;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v = s >= o ? tot[s - o] : 0u;
+        __syncthreads();
+        tot[s] += v;
+        __syncthreads();
+    }
+    const unsigned begin = tot[s] - mine;
+    if (s < steps) {
+        stg(A.step_begin + s, begin);
+        unsigned run = begin;
+        for (int y = 0; y < kIdxSeg; ++y) {
+            uint32_t *p = A.seg + (size_t)y * (steps + 1) + s;
+            const unsigned t = ldg(p);
+            stg(p, run);
+            run += t;
+        }
+    }
+    if (s == steps) { stg(A.step_begin + steps, begin); stg(A.step_begin + steps + 1, begin); }      // sorted slots in all (s == steps <= 1008 < 1024)
+}
+__global__ __launch_bounds__(kBlock) void idx_scan3_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    const ure_shard_t &S = shards[blockIdx.z];
+    const shard_aux &A = aux[blockIdx.z];
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (idx_epoch_start(S, A, tick) < 0 || s >= A.steps) return;
+    int c0, c1;
+    idx_seg_range(A, (int)blockIdx.y, &c0, &c1);
+    unsigned run = ldg(A.seg + (size_t)blockIdx.y * (A.steps + 1) + s);
+    for (int c = c0; c < c1; ++c) {
+        uint32_t *p = A.hist + (size_t)c * (A.steps + 1) + s;
+        const unsigned t = ldg(p);
+        stg(p, run);
+        run += t;
+    }
+}
+
+// ---- epoch start 5: the stable scatter.  One wavefront per chunk walks its slots in order, 64 at a time; slots of a batch with
+// the same tag are ranked by lane (ten ballots find a lane's peers), the chunk's running offsets live in LDS, private to the wave.
+__global__ __launch_bounds__(kBlock) void idx_scatter_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    __shared__ unsigned cnt[kWavesPerBlock][kIdxMaxSteps];
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    const int epoch = idx_epoch_start(S, A, tick);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = (int)blockIdx.x * kWavesPerBlock + wave;
+    if (epoch < 0 || c >= A.idx_chunks) return;
+    const int steps = A.steps;
+    unsigned *mine = cnt[wave];
+    const uint32_t *__restrict__ off = A.hist + (size_t)c * (steps + 1);
+    for (int s = lane; s < steps; s += kWave) mine[s] = ldg(off + s);
+    __builtin_amdgcn_wave_barrier();
+    const uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, epoch);
+    const int64_t lo = (int64_t)c * kIdxChunk, hi = min(lo + kIdxChunk, S.n_slots);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int64_t p0 = lo; p0 < hi; p0 += kWave) {
+        const int64_t p = p0 + lane;
+        unsigned tag = 0xFFFFu;
+        int oid = 0, row = 0;
+        float r = 0.f;
+        if (p < hi) {
+            tag = ldg(ent_tag + p);
+            oid = ldg(S.ent_oid + p);
+            r = ldg(S.ent_r + p);
+            row = ldg(A.grp_row + (p >> 3));
+        }
+        const bool valid = tag < (unsigned)steps;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 10; ++b) {
+            const bool bit = (tag >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        if (valid) {
+            const unsigned base = mine[tag];                            // (all peers read before their first lane writes: LDS runs a wave's accesses in order)
+            const int rank = __popcll(peers & below);
+            if (rank == 0) mine[tag] = base + (unsigned)__popcll(peers);
+            stg_u4(A.sslot + (size_t)(base + rank), make_uint4((unsigned)oid, __builtin_bit_cast(unsigned, r), (unsigned)row, tag));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- epoch start 6: per sorted slot the buffer of its opposite row at that step, and the bitmap of run starts.
+// Workgroup b takes the sorted slots [2048 b, 2048 (b + 1)).
+__global__ __launch_bounds__(kBlock) void idx_mark_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    __shared__ unsigned wave_cnt[kWavesPerBlock];
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    if (idx_epoch_start(S, A, tick) < 0) return;
+    const int64_t total = ldg(A.step_begin + A.steps);
+    const int64_t q_lo = (int64_t)blockIdx.x * kIdxFlagBlock;
+    if (q_lo >= total) return;                                      // (workgroup-uniform)
+    const int n_all = S.n_user + S.n_item;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned starts = 0;
+    for (int it = 0; it < kIdxFlagBlock / kBlock; ++it) {
+        const int64_t q = q_lo + it * kBlock + threadIdx.x;
+        bool start = false;
+        if (q < total) {
+            uint4 rec = ldg_u4(A.sslot + q);
+            const unsigned st = rec.w;
+            const int other = (rec.z >> 31) ? (int)rec.x : S.n_user + (int)rec.x;              // this slot's row is an item row: the opposite row is a user
+            const unsigned long long word = ldg(A.W + (size_t)(st / kIdxWin) * n_all + other);
+            rec.x |= (unsigned)idx_buffer_at(word, (int)(st % kIdxWin)) << 31;
+            stg_u4(A.sslot + q, rec);
+            if (q == 0) start = true;
+            else {
+                const uint4 prev = ldg_u4(A.sslot + q - 1);
+                start = prev.z != rec.z || prev.w != rec.w;
+            }
+        }
+        const unsigned long long vote = __ballot(start);
+        if (lane == 0 && q < total) stg(A.runflag + (q >> 6), vote);
+        starts += (unsigned)__popcll(vote);
+    }
+    if (lane == 0) wave_cnt[wave] = starts;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned sum = 0;
+        for (int k = 0; k < kWavesPerBlock; ++k) sum += wave_cnt[k];
+        stg(A.blk_cnt + blockIdx.x, sum);
+    }
+}
+
+// one workgroup per shard: blk_cnt <- its exclusive prefix; blk_cnt[n_blk] = the number of items
+__global__ __launch_bounds__(1024) void idx_blkscan_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    __shared__ unsigned part[1024];
+    const ure_shard_t &S = shards[blockIdx.x];
+    const shard_aux &A = aux[blockIdx.x];
+    if (idx_epoch_start(S, A, tick) < 0) return;
+    const int64_t total = ldg(A.step_begin + A.steps);
+    const int n_blk = (int)((total + kIdxFlagBlock - 1) / kIdxFlagBlock);
+    const int per = (n_blk + 1023) / 1024;
+    const int b0 = min((int)threadIdx.x * per, n_blk), b1 = min(b0 + per, n_blk);
+    unsigned mine = 0;
+    for (int b = b0; b < b1; ++b) mine += ldg(A.blk_cnt + b);
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned run = part[threadIdx.x] - mine;
+    for (int b = b0; b < b1; ++b) {
+        const unsigned t = ldg(A.blk_cnt + b);
+        stg(A.blk_cnt + b, run);
+        run += t;
+    }
+    if (threadIdx.x == 1023) stg(A.blk_cnt + n_blk, part[1023]);
+}
+
+// index of the item that sorted slot q starts (or would start), from the run-start bitmap and the block prefix
+__device__ __forceinline__ unsigned idx_item_of(const shard_aux &A, int64_t q)
+{
+    const int64_t blk = q / kIdxFlagBlock;
+    unsigned at = ldg(A.blk_cnt + blk);
+    for (int64_t w = blk * (kIdxFlagBlock / 64); w < (q >> 6); ++w) at += (unsigned)__popcll(ldg(A.runflag + w));
+    return at + (unsigned)__popcll(ldg(A.runflag + (q >> 6)) & mask_below((int)(q & 63)));
+}
+
+// ---- epoch start 7: one item per run.  Workgroup b takes the sorted slots [2048 b, 2048 (b + 1)).
+__global__ __launch_bounds__(kBlock) void idx_emit_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    if (idx_epoch_start(S, A, tick) < 0) return;
+    const int64_t total = ldg(A.step_begin + A.steps);
+    const int64_t q_lo = (int64_t)blockIdx.x * kIdxFlagBlock;
+    if (q_lo >= total) return;
+    const int n_all = S.n_user + S.n_item, steps = A.steps, words = A.idx_words;
+    const int lane = threadIdx.x & 63;
+    for (int it = 0; it < kIdxFlagBlock / kBlock; ++it) {
+        const int64_t q = q_lo + it * kBlock + threadIdx.x;
+        if (q >= total) continue;
+        if (!((ldg(A.runflag + (q >> 6)) >> lane) & 1ull)) continue;
+        const unsigned i = idx_item_of(A, q);
+        const uint4 rec = ldg_u4(A.sslot + q);
+        const int idx = (int)(rec.z & 0x7FFFFFFFu), st = (int)rec.w;
+        const int row_id = ldg(S.sched + 4 * (size_t)idx);
+        const int w = st / kIdxWin, b = st % kIdxWin;
+        const unsigned long long word = ldg(A.W + (size_t)w * n_all + row_id);
+        const int buf = idx_buffer_at(word, b);
+        // steps that pass between this step and the row's next own step (none: until the epoch ends)
+        const unsigned long long rest = b + 1 < 64 ? (word & kIdxBits) >> (b + 1) : 0ull;
+        int gap;
+        if (rest) gap = __ffsll((long long)rest) - 1;
+        else {
+            gap = steps - 1 - st;
+            for (int w2 = w + 1; w2 < words; ++w2) {
+                const unsigned long long v = ldg(A.W + (size_t)w2 * n_all + row_id) & kIdxBits;
+                if (v) { gap = w2 * kIdxWin + __ffsll((long long)v) - 1 - st - 1; break; }
+            }
+        }
+        const int cls = idx < S.n_split ? kIdxSplit : idx < S.n_multi ? kIdxHeavy : kIdxLight;
+        int *e = reinterpret_cast<int *>(A.items + i);
+        stg(e + 0, row_id | (buf << 31));
+        stg(e + 1, (int)q);
+        stg(e + 3, gap | (cls << 16));
+        if (i > 0) stg(reinterpret_cast<int *>(A.items + (i - 1)) + 2, (int)q);        // the run before this one ends here
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned n_items = ldg(A.blk_cnt + (total + kIdxFlagBlock - 1) / kIdxFlagBlock);
+        if (n_items > 0) stg(reinterpret_cast<int *>(A.items + (n_items - 1)) + 2, (int)total);
+    }
+}
+
+// ---- epoch start 8: per step its first item, and the heavy prefix of its items with their workgroup counts.  One workgroup per step.
+__global__ __launch_bounds__(kIdxHeavyMax) void idx_heavy_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    __shared__ unsigned scan[kIdxHeavyMax];
+    __shared__ unsigned item0, item1;
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    if (idx_epoch_start(S, A, tick) < 0) return;
+    const int s = blockIdx.x;
+    if (s >= A.steps) return;
+    const int64_t total = ldg(A.step_begin + A.steps);
+    if (threadIdx.x < 2) {
+        const int64_t q = ldg(A.step_begin + s + (int)threadIdx.x);
+        const unsigned n_items = ldg(A.blk_cnt + (total + kIdxFlagBlock - 1) / kIdxFlagBlock);
+        const unsigned i = q >= total ? n_items : idx_item_of(A, q);
+        (threadIdx.x ? item1 : item0) = i;
+        if (threadIdx.x == 0) stg(A.step_item + s, i);
+        else if (s == A.steps - 1) { stg(A.step_item + A.steps, i); stg(A.step_item + A.steps + 1, i); }
+    }
+    __syncthreads();
+    const int k = threadIdx.x;
+    unsigned parts = 0;
+    if (item0 + k < item1) {
+        const int4 e = ldg_i4(reinterpret_cast<const int32_t *>(A.items + item0 + k));
+        const int cls = (e.w >> 16) & 3;
+        if (cls == kIdxSplit) parts = (unsigned)((e.z - e.y + kIdxPart - 1) / kIdxPart);
+        else if (cls == kIdxHeavy) parts = 1u;
+    }
+    // the heavy items are a prefix of the step's items (rows keep the schedule's order): the first light one ends it
+    scan[k] = parts;
+    __syncthreads();
+    __shared__ unsigned n_heavy;
+    if (k == 0) {
+        unsigned h = 0;
+        while (h < (unsigned)kIdxHeavyMax && scan[h] != 0u) ++h;
+        n_heavy = h;
+        stg(A.heavy_cnt + s, h);
+    }
+    __syncthreads();
+    if ((unsigned)k >= n_heavy) parts = 0;
+    scan[k] = parts;
+    __syncthreads();
+    for (int o = 1; o < kIdxHeavyMax; o <<= 1) {
+        const unsigned v = k >= o ? scan[k - o] : 0u;
+        __syncthreads();
+        scan[k] += v;
+        __syncthreads();
+    }
+    uint32_t *cum = A.heavy_cum + (size_t)s * (kIdxHeavyMax + 1);
+    if (k == 0) stg(cum, 0u);
+    stg(cum + k + 1, scan[k]);
+}
+
+// ---- epoch start 9: every active row from "valid at the end of the last epoch" (buffer end_par) to "valid at its first step of this
+// epoch", into buffer 0.  One lane per float4 of a row.
+__global__ __launch_bounds__(kBlock) void idx_advance_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    const int epoch = idx_epoch_start(S, A, tick);
+    if (epoch < 0) return;
+    const int d4 = S.d / 4;
+    const int64_t total = (int64_t)S.n_active * d4;
+    const float4 *__restrict__ tab = A.ptab + (size_t)epoch * A.ptab_stride;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+        const int idx = (int)(t / d4), c4 = (int)(t % d4);
+        const int row_id = ldg(S.sched + 4 * (size_t)idx);
+        const int from = epoch > 0 ? (int)ldg(A.end_par[(epoch - 1) & 1] + row_id) : 0;
+        const int j = (int)ldg(A.first_step + row_id);
+        if (from == 0 && j == 0) continue;
+        const bool is_user = row_id < S.n_user;
+        const size_t o = (size_t)(is_user ? row_id : row_id - S.n_user) * S.d + (size_t)c4 * 4;
+        float *wsrc = (is_user ? S.U[from] : S.V[from]) + o, *wdst = (is_user ? S.U[0] : S.V[0]) + o;
+        float *mom = (is_user ? S.mU : S.mV) + o;
+        RowVec<1> w, m;
+        w.q[0] = ldg_f4(wsrc);
+        m.q[0] = ldg_f4(mom);
+        if (j != 0) row_advance<1>(w, m, tab[j]);
+        stg_f4(wdst, w.q[0]);
+        if (j != 0) stg_f4(mom, m.q[0]);
+    }
+}
+
+// ---- one optimizer step.  Workgroups of a shard: [0, idx_hw) the heavy items (one each, split rows one per 256 slots) |
+// the light items, a lane group each.
+template <int LPR, int V4>
+__device__ __forceinline__ void idx_sgd(const RowVec<V4> &w, const RowVec<V4> &m4, const RowVec<V4> &acc, float lam, float mu, float lr, RowVec<V4> &nw, RowVec<V4> &nm)
+{
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {                   // torch.optim.SGD: g += lam w ; buf = mu buf + g ; w -= lr buf
+        const float4 ww = w.q[i], mm = m4.q[i], aa = acc.q[i];
+        float4 g, wn;
+        g.x = fmaf(lam, ww.x, aa.x); g.y = fmaf(lam, ww.y, aa.y); g.z = fmaf(lam, ww.z, aa.z); g.w = fmaf(lam, ww.w, aa.w);
+        g.x = __fadd_rn(__fmul_rn(mu, mm.x), g.x); g.y = __fadd_rn(__fmul_rn(mu, mm.y), g.y);
+        g.z = __fadd_rn(__fmul_rn(mu, mm.z), g.z); g.w = __fadd_rn(__fmul_rn(mu, mm.w), g.w);
+        wn.x = fmaf(-lr, g.x, ww.x); wn.y = fmaf(-lr, g.y, ww.y); wn.z = fmaf(-lr, g.z, ww.z); wn.w = fmaf(-lr, g.w, ww.w);
+        nm.q[i] = g;
+        nw.q[i] = wn;
+    }
+}
+
+// the update of one row, by the LPR lanes that hold it: optimizer, closed-form advance over `gap` steps, stores, train loss
+template <int LPR, int V4>
+__device__ __forceinline__ void idx_finish_row(const ure_shard_t &S, const shard_aux &A, int epoch, int row_id, int buf, int gap, const RowVec<V4> &w,
+                                               const RowVec<V4> &m4, const RowVec<V4> &acc, float sse, float lr, int sub)
+{
+    constexpr int D = LPR * V4 * 4;
+    const bool is_user = row_id < S.n_user;
+    const int row = is_user ? row_id : row_id - S.n_user;
+    const size_t row_off = (size_t)row * D;
+    RowVec<V4> nw, nm;
+    idx_sgd<LPR, V4>(w, m4, acc, S.lam, S.mu, lr, nw, nm);
+    if (gap > 0) row_advance<V4>(nw, nm, A.ptab[(size_t)epoch * A.ptab_stride + gap]);
+    row_store<LPR, V4>((is_user ? S.mU : S.mV) + row_off, sub, nm);
+    row_store<LPR, V4>((is_user ? S.U[buf ^ 1] : S.V[buf ^ 1]) + row_off, sub, nw);
+    if (is_user && sub == 0 && sse != 0.f) {
+        float *slot = S.sse + (size_t)epoch * S.n_user + row;
+        stg(slot, ldg(slot) + sse);
+    }
+}
+
+// the gradient of the slots [first, end) taken with stride `stride` by this lane group: acc += 2 e v, sse += e^2
+template <int LPR, int V4>
+__device__ __forceinline__ void idx_gather(const ure_shard_t &S, const shard_aux &A, bool is_user, const RowVec<V4> &w, int first, int end, int stride, bool have,
+                                           int sub, RowVec<V4> &acc, float &sse)
+{
+    constexpr int D = LPR * V4 * 4;
+    constexpr int kGB = URE_INDEX_KGB;
+    const float *__restrict__ other0 = is_user ? S.V[0] : S.U[0];
+    const float *__restrict__ other1 = is_user ? S.V[1] : S.U[1];
+    const uint4 *__restrict__ sslot = A.sslot;
+    const int last = end - 1;
+    ure_u2 rec[kGB];
+#pragma unroll
+    for (int k = 0; k < kGB; ++k) {
+        const int q = min(first + k * stride, last);
+        rec[k] = ure_u2{0u, 0u};
+        if (have && first < end) rec[k] = *(const ure_u2 URE_AS1 *)(sslot + q);
+    }
+    for (int t = first; __any(have && t < end); t += kGB * stride) {
+        bool act[kGB];
+        float r[kGB];
+        RowVec<V4> v[kGB];
+#pragma unroll
+        for (int k = 0; k < kGB; ++k) {
+            act[k] = have && t + k * stride < end;
+            const unsigned rbits = rec[k].y;             // (a copy first: __builtin_bit_cast of the vector ELEMENT read element 0, hipcc 7.2)
+            r[k] = __uint_as_float(rbits);
+            const unsigned o = act[k] ? rec[k].x : 0u;
+            v[k] = row_load<LPR, V4>(((o >> 31) ? other1 : other0) + (size_t)(o & 0x7FFFFFFFu) * D, sub);
+        }
+        // the next batch's slots are requested before this batch's arithmetic
+        const int tn = t + kGB * stride;
+#pragma unroll
+        for (int k = 0; k < kGB; ++k) {
+            const int q = min(tn + k * stride, last);
+            if (have && tn < end) rec[k] = *(const ure_u2 URE_AS1 *)(sslot + q);
+        }
+#pragma unroll
+        for (int k = 0; k < kGB; ++k) {
+            const float p = group_sum<LPR>(row_dot<V4>(w, v[k]));
+            const float e = p - r[k];
+            const float ge = act[k] ? 2.0f * e : 0.0f;
+            if (act[k]) sse = fmaf(e, e, sse);
+            row_axpy<V4>(acc, ge, v[k]);
+        }
+    }
+}
+
+template <int LPR, int V4>
+__device__ __forceinline__ void mf_index_step(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    constexpr int G = kWave / LPR;
+    constexpr int UPB = kBlock / LPR;
+    constexpr int D = LPR * V4 * 4;
+    __shared__ float4 part_acc[UPB][V4][LPR];
+    __shared__ float part_sse[UPB];
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    const int steps = A.steps;
+    if (tick >= (int64_t)steps * S.epochs) return;
+    const int epoch = (int)epoch_of(A, tick);
+    const int s = (int)(tick - (int64_t)epoch * steps);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sub = lane & (LPR - 1), grp = lane / LPR;
+    const int local = wave * G + grp;
+    const float lr = ldg(S.lr + epoch);
+    const unsigned i0 = ldg(A.step_item + s), i1 = ldg(A.step_item + s + 1), n_heavy = ldg(A.heavy_cnt + s);
+    const int4 *__restrict__ items = A.items;
+    if ((int)blockIdx.x < A.idx_hw) {
+        // ---- a heavy item (or one part of a split one): the workgroup's lane groups take its slots round robin
+        const uint32_t *__restrict__ cum = A.heavy_cum + (size_t)s * (kIdxHeavyMax + 1);
+        const unsigned b = blockIdx.x;
+        if (b >= ldg(cum + n_heavy)) return;
+        unsigned k = 0;
+        while (ldg(cum + k + 1) <= b) ++k;                                   // (workgroup-uniform; at most 256 entries)
+        const unsigned c0 = ldg(cum + k), c1 = ldg(cum + k + 1);
+        const int part = (int)(b - c0), n_parts = (int)(c1 - c0);
+        const int4 e = ldg_i4(reinterpret_cast<const int32_t *>(items + i0 + k));
+        const int row_id = e.x & 0x7FFFFFFF, buf = (int)((unsigned)e.x >> 31), gap = e.w & 0xFFFF;
+        const int first = n_parts > 1 ? e.y + part * kIdxPart : e.y;
+        const int end = n_parts > 1 ? min(e.z, first + kIdxPart) : e.z;
+        const bool is_user = row_id < S.n_user;
+        const size_t row_off = (size_t)(is_user ? row_id : row_id - S.n_user) * D;
+        const RowVec<V4> w = row_load<LPR, V4>((is_user ? S.U[buf] : S.V[buf]) + row_off, sub);
+        RowVec<V4> m4 = row_zero<V4>(), acc = m4;
+        if (local == 0 && n_parts == 1) m4 = row_load<LPR, V4>((is_user ? S.mU : S.mV) + row_off, sub);
+        float sse = 0.f;
+        idx_gather<LPR, V4>(S, A, is_user, w, first + local, end, UPB, true, sub, acc, sse);
+#pragma unroll
+        for (int i = 0; i < V4; ++i) part_acc[local][i][sub] = acc.q[i];
+        if (sub == 0) part_sse[local] = sse;
+        __syncthreads();
+        if (local != 0) return;
+        // the lane groups' sums in lane-group order (a fixed order: the result does not depend on timing)
+#pragma unroll
+        for (int i = 0; i < V4; ++i) {
+            float4 a4 = part_acc[0][i][sub];
+            for (int g = 1; g < UPB; ++g) {
+                const float4 t = part_acc[g][i][sub];
+                a4.x += t.x; a4.y += t.y; a4.z += t.z; a4.w += t.w;
+            }
+            acc.q[i] = a4;
+        }
+        sse = 0.f;
+        for (int g = 0; g < UPB; ++g) sse += part_sse[g];
+        if (n_parts == 1) {
+            idx_finish_row<LPR, V4>(S, A, epoch, row_id, buf, gap, w, m4, acc, sse, lr, sub);
+            return;
+        }
+        // a part of a split row: the partial sums go to memory, idx_combine_kernel adds the parts in order and applies them
+        float *out = A.partial + (size_t)b * (D + 4);
+        row_store<LPR, V4>(out, sub, acc);
+        if (sub == 0) stg(out + D, sse);
+        return;
+    }
+    // ---- light items: a lane group each
+    const unsigned i = i0 + n_heavy + ((unsigned)blockIdx.x - (unsigned)A.idx_hw) * UPB + (unsigned)local;
+    const bool have = i < i1;
+    if (!__any(have)) return;
+    int4 e = make_int4(0, 0, 0, 0);
+    if (have) e = ldg_i4(reinterpret_cast<const int32_t *>(items + i));
+    const int row_id = e.x & 0x7FFFFFFF, buf = (int)((unsigned)e.x >> 31), gap = e.w & 0xFFFF;
+    const bool is_user = row_id < S.n_user;
+    const size_t row_off = (size_t)(is_user ? row_id : row_id - S.n_user) * D;
+    RowVec<V4> w = row_zero<V4>(), m4 = w, acc = w;
+    if (have) {
+        w = row_load<LPR, V4>((is_user ? S.U[buf] : S.V[buf]) + row_off, sub);
+        m4 = row_load<LPR, V4>((is_user ? S.mU : S.mV) + row_off, sub);
+    }
+    float sse = 0.f;
+    idx_gather<LPR, V4>(S, A, is_user, w, e.y, e.z, 1, have, sub, acc, sse);
+    if (have) idx_finish_row<LPR, V4>(S, A, epoch, row_id, buf, gap, w, m4, acc, sse, lr, sub);
+}
+
+template <int LPR, int V4>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(URE_INDEX_WAVES))) void mf_index_step_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    mf_index_step<LPR, V4>(shards, aux, tick);
+}
+
+// the rows split over several workgroups: their parts' sums in part order, then the update.  One wavefront per split item.
+template <int LPR, int V4>
+__global__ __launch_bounds__(kWave) void idx_combine_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    constexpr int D = LPR * V4 * 4;
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    const int steps = A.steps;
+    if (tick >= (int64_t)steps * S.epochs) return;
+    const int epoch = (int)epoch_of(A, tick);
+    const int s = (int)(tick - (int64_t)epoch * steps);
+    const unsigned k = blockIdx.x;
+    if (k >= ldg(A.heavy_cnt + s)) return;
+    const uint32_t *__restrict__ cum = A.heavy_cum + (size_t)s * (kIdxHeavyMax + 1);
+    const unsigned c0 = ldg(cum + k), c1 = ldg(cum + k + 1);
+    if (c1 - c0 < 2u || (int)threadIdx.x >= LPR) return;
+    const int sub = threadIdx.x;
+    const int4 e = ldg_i4(reinterpret_cast<const int32_t *>(A.items + ldg(A.step_item + s) + k));
+    const int row_id = e.x & 0x7FFFFFFF, buf = (int)((unsigned)e.x >> 31), gap = e.w & 0xFFFF;
+    const bool is_user = row_id < S.n_user;
+    const size_t row_off = (size_t)(is_user ? row_id : row_id - S.n_user) * D;
+    const RowVec<V4> w = row_load<LPR, V4>((is_user ? S.U[buf] : S.V[buf]) + row_off, sub);
+    const RowVec<V4> m4 = row_load<LPR, V4>((is_user ? S.mU : S.mV) + row_off, sub);
+    RowVec<V4> acc = row_load<LPR, V4>(A.partial + (size_t)c0 * (D + 4), sub);
+    float sse = ldg(A.partial + (size_t)c0 * (D + 4) + D);
+    for (unsigned p = c0 + 1; p < c1; ++p) {
+        const RowVec<V4> t = row_load<LPR, V4>(A.partial + (size_t)p * (D + 4), sub);
+#pragma unroll
+        for (int i = 0; i < V4; ++i) { acc.q[i].x += t.q[i].x; acc.q[i].y += t.q[i].y; acc.q[i].z += t.q[i].z; acc.q[i].w += t.q[i].w; }
+        sse += ldg(A.partial + (size_t)p * (D + 4) + D);
+    }
+    idx_finish_row<LPR, V4>(S, A, epoch, row_id, buf, gap, w, m4, acc, sse, ldg(S.lr + epoch), sub);
+}
+
+}  // namespace ure

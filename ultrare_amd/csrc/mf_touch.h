@@ -774,12 +774,13 @@ __device__ __forceinline__ void touch_collect_rows(const ure_shard_t &S, const s
 {
     const int d4 = S.d / 4;
     const int64_t total = (int64_t)S.n_active * d4;
-    const unsigned long long *__restrict__ mk = A.mask[touch_last_window(A, last_epoch < 0 ? 0 : last_epoch) & 1];
+    const unsigned long long *__restrict__ mk = A.mask[touch_last_window(A, last_epoch < 0 ? 0 : last_epoch) & 1];      // (touch_mode 3 keeps no such masks: NULL, not read)
     for (int64_t t = (int64_t)blk * kBlock + threadIdx.x; t < total; t += (int64_t)n_blk * kBlock) {
         const int idx = (int)(t / d4), c4 = (int)(t % d4);
         const int row_id = ldg(S.sched + 4 * (size_t)idx);
-        const unsigned long long word = last_epoch < 0 ? 0ull : ldg(mk + row_id);
-        const int from = last_epoch < 0 ? 0 : (S.touch_mode == 2 ? ahead_buffer_at(word, 64) : (__popcll(word) & 1));
+        const unsigned long long word = (last_epoch < 0 || S.touch_mode == 3) ? 0ull : ldg(mk + row_id);
+        const int from = last_epoch < 0 ? 0 : S.touch_mode == 3 ? (int)ldg(A.end_par[last_epoch & 1] + row_id) :
+                         (S.touch_mode == 2 ? ahead_buffer_at(word, 64) : (__popcll(word) & 1));
         if (from == cur) continue;
         const bool is_user = row_id < S.n_user;
         const size_t o = (size_t)(is_user ? row_id : row_id - S.n_user) * S.d + (size_t)c4 * 4;

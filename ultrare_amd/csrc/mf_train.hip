@@ -405,12 +405,13 @@ __global__ __launch_bounds__(kBlock) void snapshot_kernel(const ure_shard_t *__r
     const unsigned long long *__restrict__ row_mask = nullptr;
     const bool compact = S.snap != nullptr;
     if (!compact && (!S.snapU || !S.snapV)) return;
-    if (compact && S.touch_mode != 1 && S.row_slot) return;             // written by the step kernel's owners (touch_mode 2: and launch B)
+    if (compact && (S.touch_mode == 0 || S.touch_mode == 2) && S.row_slot) return;      // written by the step kernel's owners (touch_mode 2: and launch B)
     const int steps = shard_steps(S);
     if (ticks_done > (int64_t)steps * S.epochs || ticks_done % steps != 0) return;   // only at an epoch end of this shard
     const int epoch = (int)(ticks_done / steps) - 1;
     const int cur = (int)(ticks_done & 1);
-    if (S.touch_mode) row_mask = aux[blockIdx.y].mask[touch_last_window(aux[blockIdx.y], epoch) & 1];      // touch mode: a row's w sits in the buffer of its step-count parity
+    if (S.touch_mode == 1 || S.touch_mode == 2) row_mask = aux[blockIdx.y].mask[touch_last_window(aux[blockIdx.y], epoch) & 1];      // touch mode: a row's w sits in the buffer of its step-count parity
+    const uint8_t *__restrict__ end_par = S.touch_mode == 3 ? aux[blockIdx.y].end_par[epoch & 1] : nullptr;               // touch_mode 3: the same, kept per row
     const float a = S.lazy_rows ? ldg(S.snap_a + epoch) : 0.f;
     const int d4 = S.d / 4;
     const int n_rows = compact ? S.n_active : S.n_user + S.n_item;
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void snapshot_kernel(const ure_shard_t *__r
             const float4 w0 = ldg_f4((is_user ? S.U0 : S.V0) + o);
             v = make_float4(a * w0.x, a * w0.y, a * w0.z, a * w0.w);
         } else {
-            const int from = row_mask ? (__popcll(ldg(row_mask + row_id)) & 1) : cur;
+            const int from = end_par ? (int)ldg(end_par + row_id) : row_mask ? (__popcll(ldg(row_mask + row_id)) & 1) : cur;
             v = ldg_f4((is_user ? S.U[from] : S.V[from]) + o);
         }
         if (compact) stg_f4(sc + t * 4, v);
@@ -465,6 +466,7 @@ __global__ __launch_bounds__(kBlock) void materialize_rows_kernel(const ure_shar
 
 }  // namespace ure
 #include "mf_touch.h"
+#include "mf_index.h"
 namespace ure {
 
 template <int LPR, int V4>
@@ -566,7 +568,7 @@ __global__ __launch_bounds__(kBlock) void touch_collect_kernel(const ure_shard_t
 
 static bool touch_prep_needed(const ure_job *job, int64_t tick)
 {
-    if (!job->touch) return false;
+    if (!job->touch || job->index) return false;
     for (size_t k = 0; k < job->host.size(); ++k) {
         const int64_t steps = job->aux_host[k].steps;
         if (tick < steps * job->host[k].epochs && (tick % steps) % kTouchWindow == 0) return true;      // (mode 2: steps <= 63, one window)
@@ -610,9 +612,69 @@ static void launch_touch_prep(const ure_job *job, int64_t tick, hipStream_t st)
 #endif
 }
 
+// touch_mode 3 (mf_index.h): does an epoch of some shard start at `tick`?
+static bool index_epoch_start_needed(const ure_job *job, int64_t tick)
+{
+    if (!job->index) return false;
+    for (size_t k = 0; k < job->host.size(); ++k) {
+        const int64_t steps = job->aux_host[k].steps;
+        if (tick < steps * job->host[k].epochs && tick % steps == 0) return true;
+    }
+    return false;
+}
+
+// ... then the epoch's slot index is built: masks, sort by step, items, and the one dense pass of the epoch
+static void launch_index_epoch_start(const ure_job *job, int64_t tick, hipStream_t st)
+{
+    const unsigned n_sh = (unsigned)job->host.size();
+    int chunks = 1, steps = 1;
+    int64_t slots = 8;
+    for (size_t k = 0; k < job->host.size(); ++k) {
+        chunks = std::max(chunks, job->aux_host[k].idx_chunks);
+        steps = std::max(steps, job->aux_host[k].steps);
+        slots = std::max(slots, job->host[k].n_slots);
+    }
+    const unsigned step_blocks = (unsigned)((steps + kBlock - 1) / kBlock);
+    const unsigned flag_blocks = (unsigned)((slots + kIdxFlagBlock - 1) / kIdxFlagBlock);
+    const unsigned wave_blocks = (unsigned)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
+    const unsigned row_blocks = (unsigned)std::max(1, std::min((job->max_rows + kBlock - 1) / kBlock, 4096));
+    const unsigned adv_b = (unsigned)std::max<int64_t>(1, std::min<int64_t>((job->max_active4 + kBlock - 1) / kBlock, 8192));
+    if (tick == 0) hipLaunchKernelGGL(idx_grp_row_kernel, dim3(std::min<unsigned>((unsigned)((slots / 8 + kBlock - 1) / kBlock), 8192u), n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux);
+    hipLaunchKernelGGL(idx_clear_kernel, dim3(std::min<unsigned>((unsigned)((2 * chunks + kBlock - 1) / kBlock), 1024u), n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+    hipLaunchKernelGGL(idx_masks_kernel, dim3((unsigned)chunks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+    hipLaunchKernelGGL(idx_parity_kernel, dim3(row_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+    hipLaunchKernelGGL(idx_hist_kernel, dim3(wave_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+    hipLaunchKernelGGL(idx_scan1_kernel, dim3(step_blocks, kIdxSeg, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+    hipLaunchKernelGGL(idx_scan2_kernel, dim3(n_sh), dim3(1024), 0, st, job->dev, job->dev_aux, tick);
+    hipLaunchKernelGGL(idx_scan3_kernel, dim3(step_blocks, kIdxSeg, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+    hipLaunchKernelGGL(idx_scatter_kernel, dim3(wave_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+    hipLaunchKernelGGL(idx_mark_kernel, dim3(flag_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+    hipLaunchKernelGGL(idx_blkscan_kernel, dim3(n_sh), dim3(1024), 0, st, job->dev, job->dev_aux, tick);
+    hipLaunchKernelGGL(idx_emit_kernel, dim3(flag_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+    hipLaunchKernelGGL(idx_heavy_kernel, dim3((unsigned)steps, n_sh), dim3(kIdxHeavyMax), 0, st, job->dev, job->dev_aux, tick);
+    hipLaunchKernelGGL(idx_advance_kernel, dim3(adv_b, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+}
+
+template <int LPR, int V4>
+static void launch_index_step(const ure_job *job, int64_t tick, hipStream_t st)
+{
+    constexpr int UPB = kBlock / LPR;
+    const unsigned n_sh = (unsigned)job->host.size();
+    int blocks = 1, split = 0;
+    for (size_t k = 0; k < job->host.size(); ++k) {
+        const shard_aux &A = job->aux_host[k];
+        if (tick >= (int64_t)A.steps * job->host[k].epochs) continue;
+        blocks = std::max(blocks, A.idx_hw + (A.idx_light + UPB - 1) / UPB);
+        split = std::max(split, job->host[k].n_split);
+    }
+    hipLaunchKernelGGL((mf_index_step_kernel<LPR, V4>), dim3((unsigned)blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+    if (split > 0) hipLaunchKernelGGL((idx_combine_kernel<LPR, V4>), dim3((unsigned)split, n_sh), dim3(kWave), 0, st, job->dev, job->dev_aux, tick);
+}
+
 template <int LPR, int V4>
 static void launch_step(const ure_job *job, int64_t tick, hipStream_t st)
 {
+    if (job->index) { launch_index_step<LPR, V4>(job, tick, st); return; }
     // grid.x = the largest need of any shard AT THIS TICK (row workgroups + the tag riders its
     // current step carries); finished shards need nothing
     int blocks = 1;
@@ -696,15 +758,19 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
     // ---- touch mode: all shards of the job or none; masks and closed-form tables are library-owned
     for (int k = 0; k < n_shards; ++k) job->touch = job->touch || shards[k].touch_mode != 0;
     job->ahead = shards[0].touch_mode == 2;
+    job->index = shards[0].touch_mode == 3;
+    for (int k = 0; k < n_shards; ++k) job->all_file_tags = job->all_file_tags && shards[k].file_tags != nullptr;
     if (job->touch) {
         for (int k = 0; k < n_shards; ++k) {
             const ure_shard_t &S = shards[k];
             const char *why = !S.touch_mode ? "every shard of a job must ask for it" :
-                              (S.touch_mode != 1 && S.touch_mode != 2) ? "touch_mode is 0, 1 or 2" :
+                              (S.touch_mode < 1 || S.touch_mode > 3) ? "touch_mode is 0, 1, 2 or 3" :
                               S.touch_mode != shards[0].touch_mode ? "every shard of a job must ask for the same touch mode" :
                               (S.touch_mode == 2 && job->aux_host[k].steps > kAheadMaxSteps) ? "touch_mode 2 takes at most 63 steps per epoch (the mask word's top bit is the start buffer)" :
                               (S.touch_mode == 2 && (S.snapU || S.snapV)) ? "touch_mode 2 writes compact snapshots only (snap + row_slot)" :
                               (S.touch_mode == 2 && S.snap && !S.row_slot) ? "touch_mode 2 needs row_slot with snap" :
+                              (S.touch_mode == 3 && job->aux_host[k].steps > kIdxMaxSteps) ? "touch_mode 3 takes at most 1008 steps per epoch (16 mask words of 63 steps)" :
+                              (S.touch_mode == 3 && (S.n_multi > kIdxHeavyMax || S.n_split < 0 || S.n_split > S.n_multi)) ? "touch_mode 3: 0 <= n_split <= n_multi <= 256" :
                               !S.lazy_rows ? "it needs lazy_rows" :
                               job->aux_host[k].steps > kTouchMaxSteps ? "more than 32000 steps per epoch (the step number shares the 16-bit batch tag with the buffer bit)" :
                               (S.epochs != shards[0].epochs || S.lam != shards[0].lam || S.mu != shards[0].mu ||
@@ -722,14 +788,18 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         // A_e^j for j = 0..64 (the length of a window) at every epoch's learning rate, in double: (w, m)' = A (w, m),
         // m' = mu m + lam w, w' = w - lr m'
         const int E = shards[0].epochs;
-        std::vector<float> tab((size_t)E * kTouchTab * 4);
+        int tab_n = kTouchTab;                                      // touch_mode 3: a row may wait a whole epoch for its next step
+        if (job->index)
+            for (int k = 0; k < n_shards; ++k) tab_n = std::max(tab_n, job->aux_host[k].steps + 1);
+        for (int k = 0; k < n_shards; ++k) job->aux_host[k].ptab_stride = tab_n;
+        std::vector<float> tab((size_t)E * tab_n * 4);
         const double lam = (double)shards[0].lam, mu = (double)shards[0].mu;
         for (int ep = 0; ep < E; ++ep) {
             const double lr = (double)job->lr_host[0][(size_t)ep];
             const double a11 = 1.0 - lr * lam, a12 = -lr * mu, a21 = lam, a22 = mu;
             double p11 = 1.0, p12 = 0.0, p21 = 0.0, p22 = 1.0;
-            for (int j = 0; j < kTouchTab; ++j) {
-                float *o = &tab[((size_t)ep * kTouchTab + j) * 4];
+            for (int j = 0; j < tab_n; ++j) {
+                float *o = &tab[((size_t)ep * tab_n + j) * 4];
                 o[0] = (float)p11; o[1] = (float)p12; o[2] = (float)p21; o[3] = (float)p22;
                 const double q11 = a11 * p11 + a12 * p21, q12 = a11 * p12 + a12 * p22;
                 const double q21 = a21 * p11 + a22 * p21, q22 = a21 * p12 + a22 * p22;
@@ -739,7 +809,48 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         void *ptab = nullptr;
         e = hipMalloc(&ptab, tab.size() * sizeof(float));
         if (e == hipSuccess) { job->touch_mem.push_back(ptab); e = hipMemcpy(ptab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice); }
-        for (int k = 0; k < n_shards && e == hipSuccess; ++k) {
+        for (int k = 0; k < n_shards && e == hipSuccess && job->index; ++k) {
+            // touch_mode 3: the slot index of the current epoch (mf_index.h), one allocation per shard
+            const ure_shard_t &S = shards[k];
+            shard_aux &A = job->aux_host[k];
+            A.ptab = static_cast<const float4 *>(ptab);
+            const size_t n_all = (size_t)S.n_user + S.n_item, steps = (size_t)A.steps, slots = (size_t)S.n_slots;
+            A.idx_words = (int32_t)((steps + kIdxWin - 1) / kIdxWin);
+            A.idx_chunks = (int32_t)((slots + kIdxChunk - 1) / kIdxChunk);
+            A.idx_hw = S.n_multi + 2 * S.batch / kIdxPart + 2;
+            A.idx_light = (int32_t)std::min<int64_t>(2 * (int64_t)S.batch, S.n_active);
+            size_t at = 0;
+            auto take = [&at](size_t bytes) { const size_t o = at; at += (bytes + 255) / 256 * 256; return o; };
+            const size_t o_grp = take(slots / 8 * 4), o_w = take((size_t)A.idx_words * n_all * 8), o_par = take(2 * n_all), o_first = take(n_all * 2);
+            const size_t o_hist = take((size_t)A.idx_chunks * (steps + 1) * 4), o_seg = take((size_t)kIdxSeg * (steps + 1) * 4), o_sb = take((steps + 2) * 4);
+            const size_t o_ss = take(slots * 16), o_rf = take((slots / 64 + 2) * 8), o_bc = take((slots / kIdxFlagBlock + 2) * 4);
+            const size_t o_it = take(((size_t)std::min<int64_t>(2 * (int64_t)S.N, S.n_slots) + 1) * 16), o_si = take((steps + 2) * 4), o_hc = take(steps * 4);
+            const size_t o_cum = take(steps * (kIdxHeavyMax + 1) * 4), o_pa = take((size_t)A.idx_hw * (S.d + 4) * 4);
+            void *mem = nullptr;
+            e = hipMalloc(&mem, at);
+            if (e != hipSuccess) break;
+            job->touch_mem.push_back(mem);
+            char *b = static_cast<char *>(mem);
+            e = hipMemset(b + o_w, 0, (o_hist - o_w));                       // masks, end-of-epoch buffers, first steps
+            A.grp_row = reinterpret_cast<int32_t *>(b + o_grp);
+            A.W = reinterpret_cast<unsigned long long *>(b + o_w);
+            A.end_par[0] = reinterpret_cast<uint8_t *>(b + o_par);
+            A.end_par[1] = A.end_par[0] + n_all;
+            A.first_step = reinterpret_cast<uint16_t *>(b + o_first);
+            A.hist = reinterpret_cast<uint32_t *>(b + o_hist);
+            A.seg = reinterpret_cast<uint32_t *>(b + o_seg);
+            A.step_begin = reinterpret_cast<uint32_t *>(b + o_sb);
+            A.sslot = reinterpret_cast<uint4 *>(b + o_ss);
+            A.runflag = reinterpret_cast<unsigned long long *>(b + o_rf);
+            A.blk_cnt = reinterpret_cast<uint32_t *>(b + o_bc);
+            A.items = reinterpret_cast<int4 *>(b + o_it);
+            A.step_item = reinterpret_cast<uint32_t *>(b + o_si);
+            A.heavy_cnt = reinterpret_cast<uint32_t *>(b + o_hc);
+            A.heavy_cum = reinterpret_cast<uint32_t *>(b + o_cum);
+            A.partial = reinterpret_cast<float *>(b + o_pa);
+            job->index_split = job->index_split || S.n_split > 0;
+        }
+        for (int k = 0; k < n_shards && e == hipSuccess && !job->index; ++k) {
             const size_t bytes = (size_t)(shards[k].n_user + shards[k].n_item) * sizeof(unsigned long long);
             void *mk = nullptr;
             e = hipMalloc(&mk, 2 * bytes);
@@ -856,6 +967,10 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
                 default: launch_touch_ahead<32, 2>(job, t, st); break;
             }
             if (int rc = mark(assign_ev)) return rc;
+        } else if (index_epoch_start_needed(job, t)) {
+            if (int rc = mark(assign_ev)) return rc;
+            launch_index_epoch_start(job, t, st);
+            if (int rc = mark(assign_ev)) return rc;
         } else if (touch_prep_needed(job, t)) {
             if (int rc = mark(assign_ev)) return rc;
             switch (lanes_per_row(job->d)) {
@@ -884,7 +999,7 @@ static int train_ticks(ure::ure_job *job, int64_t tick0, int64_t tick1, hipStrea
             bool epoch_end = false;
             for (const ure_shard_t &S : job->host) {
                 const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
-                const bool by_kernel = S.snapU || (S.snap && (S.touch_mode == 1 || !S.row_slot));      // otherwise the step kernel's owners wrote it
+                const bool by_kernel = S.snapU || (S.snap && (S.touch_mode == 1 || S.touch_mode == 3 || !S.row_slot));      // otherwise the step kernel's owners wrote it
                 if (by_kernel && t + 1 <= steps * S.epochs && (t + 1) % steps == 0) { epoch_end = true; break; }
             }
             if (epoch_end)
@@ -945,6 +1060,17 @@ int ure_job_touch_rows(ure_job_t *j, int64_t *pairs, int64_t *window_steps)
     for (size_t k = 0; k < job->host.size(); ++k) { pairs[k] = -1; window_steps[k] = 0; }
     if (!job->touch || job->next_tick == 0) return 0;
     URE_HIP(hipDeviceSynchronize());
+    if (job->index) {
+        // touch_mode 3: the (row, step) runs of the shard's current epoch = the items of its index
+        for (size_t k = 0; k < job->host.size(); ++k) {
+            const shard_aux &A = job->aux_host[k];
+            uint32_t n_items = 0;
+            URE_HIP(hipMemcpy(&n_items, A.step_item + A.steps, sizeof(n_items), hipMemcpyDeviceToHost));
+            pairs[k] = n_items;
+            window_steps[k] = A.steps;
+        }
+        return 0;
+    }
     std::vector<unsigned long long> host;
     for (size_t k = 0; k < job->host.size(); ++k) {
         const ure_shard_t &S = job->host[k];
@@ -959,6 +1085,36 @@ int ure_job_touch_rows(ure_job_t *j, int64_t *pairs, int64_t *window_steps)
         pairs[k] = n;
         window_steps[k] = std::min<int64_t>(kTouchWindow, steps - win * kTouchWindow);
     }
+    return 0;
+}
+
+int ure_job_index_read(ure_job_t *j, int shard, int which, void *out, int64_t capacity, int64_t *bytes)
+{
+    auto *job = reinterpret_cast<ure::ure_job *>(j);
+    URE_ARG(job && shard >= 0 && shard < (int)job->host.size() && bytes);
+    if (!job->index) return fail(-1, "ure_job_index_read: the job is not in touch_mode 3");
+    const ure_shard_t &S = job->host[(size_t)shard];
+    const shard_aux &A = job->aux_host[(size_t)shard];
+    URE_HIP(hipDeviceSynchronize());
+    uint32_t n_items = 0, total = 0;
+    URE_HIP(hipMemcpy(&n_items, A.step_item + A.steps, 4, hipMemcpyDeviceToHost));
+    URE_HIP(hipMemcpy(&total, A.step_begin + A.steps, 4, hipMemcpyDeviceToHost));
+    const void *src = nullptr;
+    size_t n = 0;
+    switch (which) {
+        case 0: src = A.step_begin; n = ((size_t)A.steps + 1) * 4; break;
+        case 1: src = A.step_item; n = ((size_t)A.steps + 1) * 4; break;
+        case 2: src = A.items; n = (size_t)n_items * 16; break;
+        case 3: src = A.sslot; n = (size_t)total * 16; break;
+        case 4: src = A.W; n = (size_t)A.idx_words * ((size_t)S.n_user + S.n_item) * 8; break;
+        case 5: src = A.heavy_cnt; n = (size_t)A.steps * 4; break;
+        case 6: src = A.heavy_cum; n = (size_t)A.steps * (kIdxHeavyMax + 1) * 4; break;
+        default: return fail(-1, "ure_job_index_read: which = %d", which);
+    }
+    *bytes = (int64_t)n;
+    if (!out) return 0;
+    if ((int64_t)n > capacity) return fail(-1, "ure_job_index_read: %zu bytes do not fit %lld", n, (long long)capacity);
+    URE_HIP(hipMemcpy(out, src, n, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -205,6 +205,28 @@ struct shard_aux {
     uint8_t *unit_nf, *sched_nf;          // [n_um], [n_sm]
     int32_t n_um, n_sm;
     unsigned long long *sched_mask;// [n_active - n_multi] the same for the single-pass rows, in schedule order
+    // touch_mode 3 ("indexed", mf_index.h): the per-step slot index of the current epoch, rebuilt at every epoch start
+    int32_t ptab_stride;           // entries of ptab per epoch (65; touch_mode 3: steps + 1)
+    int32_t idx_words;             // mask words per row and epoch = ceil(steps / 63)
+    int32_t idx_chunks;            // ceil(n_slots / 4096): one wavefront sorts one chunk
+    int32_t idx_hw;                // workgroups of a step launch reserved for heavy rows (upper bound)
+    int32_t idx_light;             // upper bound of a step's light items = min(2 B, n_active)
+    int32_t *grp_row;              // [n_slots / 8] schedule index of the row that owns the group of 8 slots | item row << 31 (static)
+    unsigned long long *W;         // [idx_words][n_user + n_item] bit b of word w = the row is trained in step 63 w + b; bit 63 = the buffer
+                                   // its weights are in at step 63 w
+    uint8_t *end_par[2];           // [n_user + n_item] buffer of the row at the end of an epoch, by epoch parity
+    uint16_t *first_step;          // [n_user + n_item] the row's first step of the epoch (steps: none)
+    uint32_t *hist;                // [idx_chunks][steps + 1] slots per (chunk, step) -> after the scan: where the chunk's run of the step starts
+    uint32_t *seg;                 // [32][steps + 1] scan scratch
+    uint32_t *step_begin;          // [steps + 2] first sorted slot of each step; [steps] = sorted slots in all
+    uint4 *sslot;                  // [n_slots] slots sorted by (step, row, file order): {opposite id | buffer << 31, rating, row, step}
+    unsigned long long *runflag;   // [n_slots / 64 + 1] bit = the sorted slot starts a (step, row) run
+    uint32_t *blk_cnt;             // [n_slots / 2048 + 2] runs that start in each block of 2048 sorted slots -> exclusive prefix
+    int4 *items;                   // [2 N + 1] one per (step, row) run, steps ascending: {row id | buffer << 31, first sorted slot, end, gap | class << 16}
+    uint32_t *step_item;           // [steps + 2] first item of each step
+    uint32_t *heavy_cnt;           // [steps] items of the step that whole workgroups take (a prefix of its items)
+    uint32_t *heavy_cum;           // [steps][257] workgroups of the step's heavy items, cumulative
+    float *partial;                // [idx_hw][d + 4] partial gradient sums of the rows split over several workgroups
 };
 
 constexpr int kTouchWindow = 64;            // steps a 64-bit row mask describes
@@ -220,7 +242,7 @@ inline shard_aux make_shard_aux(const ure_shard_t &S)
     a.ranges = tag_ranges(S.N);
     a.derive_blocks = tag_derive_blocks(S.n_slots);
     a.windows = (a.steps + kTouchWindow - 1) / kTouchWindow;
-    a.ride_m = a.steps >= 3 && tag_partitioned(S.N) ? a.steps / 3 : 0;
+    a.ride_m = a.steps >= 3 && tag_partitioned(S.N) && S.touch_mode != 3 ? a.steps / 3 : 0;      // (touch_mode 3 prepares every epoch's tags at its start)
     if (a.ride_m) {
         a.ride_ab = (a.ranges + a.ride_m - 1) / a.ride_m;
         a.ride_c = (a.derive_blocks + a.ride_m - 1) / a.ride_m;

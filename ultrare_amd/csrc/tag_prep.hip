@@ -12,7 +12,7 @@ __device__ __forceinline__ int standalone_epoch(const ure_shard_t &S, int64_t ti
 {
     const int steps = (S.N + S.batch - 1) / S.batch;
     if (tick >= (int64_t)steps * S.epochs || tick % steps != 0) return -1;      // not an epoch start
-    const bool riders = steps >= 3 && tag_partitioned(S.N);
+    const bool riders = steps >= 3 && tag_partitioned(S.N) && S.touch_mode != 3;
     const int epoch = (int)(tick / steps);
     if (S.touch_mode == 2) {
         if (pass == 0) return tick == 0 ? 0 : -1;
@@ -73,7 +73,7 @@ int tag_prep_needed(const ure_job *job, int64_t tick)
     for (const ure_shard_t &S : job->host) {
         const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
         if (tick >= steps * S.epochs || tick % steps != 0) continue;
-        const bool riders = steps >= 3 && tag_partitioned(S.N);
+        const bool riders = steps >= 3 && tag_partitioned(S.N) && S.touch_mode != 3;
         if (S.touch_mode == 2) {
             if (tick == 0) need |= 1;
             if ((tick == 0 || !riders) && tick / steps + 1 < S.epochs) need |= 2;
@@ -85,12 +85,13 @@ int tag_prep_needed(const ure_job *job, int64_t tick)
 void launch_tag_prep(const ure_job *job, int64_t tick, hipStream_t st, int pass)
 {
     const unsigned n_shards = (unsigned)job->host.size();
-    if (job->small_shards) {
+    // (with host-made batch tags -- struct ure_shard: file_tags, the product's default -- only the slot-order gather is left)
+    if (job->small_shards && !job->all_file_tags) {
         const unsigned ranges = (unsigned)tag_ranges(job->max_small_n);
         hipLaunchKernelGGL(tag_partition_kernel, dim3(ranges, n_shards), dim3(kBlock), 0, st, job->dev, tick, pass);
         hipLaunchKernelGGL(tag_collect_kernel, dim3(ranges, n_shards), dim3(kBlock), 0, st, job->dev, tick, pass);
     }
-    if (job->large_shards) {
+    if (job->large_shards && !job->all_file_tags) {
         const unsigned blocks = (unsigned)std::min((job->max_n + kBlock - 1) / kBlock, 4096);
         hipLaunchKernelGGL(tag_scatter_kernel, dim3(blocks, n_shards), dim3(kBlock), 0, st, job->dev, tick, pass);
     }

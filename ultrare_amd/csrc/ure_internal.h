@@ -64,6 +64,9 @@ struct ure_job {
     int64_t max_lazy = 0;                              // float4 slices of lazily advanced rows, max over shards
     bool touch = false;                                // touch mode (mf_touch.h): all shards of the job or none
     bool ahead = false;                                // touch_mode 2 (masks one epoch ahead): all shards of the job or none
+    bool index = false;                                // touch_mode 3 (per-step slot index, mf_index.h): all shards of the job or none
+    bool index_split = false;                          // ... and some shard has rows split over several workgroups (a combine launch per step)
+    bool all_file_tags = true;                         // every shard's batch tags come from the host: no partition / collect / scatter launches
     std::vector<void *> touch_mem;                     // library-owned device memory of touch mode (masks, tables)
     int max_units = 0;                                 // work units of the largest shard
     int64_t max_active4 = 0;                           // float4 slices of active rows, max over shards
@@ -83,6 +86,7 @@ void launch_tag_prep(const ure_job *job, int64_t tick, hipStream_t st, int pass)
 typedef float ure_f4 __attribute__((ext_vector_type(4)));
 typedef int ure_i4 __attribute__((ext_vector_type(4)));
 typedef unsigned ure_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned ure_u2 __attribute__((ext_vector_type(2)));
 template <typename T>
 __device__ __forceinline__ T ldg(const T *p) { return *(const T URE_AS1 *)p; }
 template <typename T>

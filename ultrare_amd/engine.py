@@ -36,6 +36,10 @@ TOUCH_ROW_PASSES = int(os.environ.get('URE_TOUCH_ROW_PASSES', '2'))
 # 62.9 at 8, 61.6 at 16
 TOUCH_UNIT_PASSES = int(os.environ.get('URE_TOUCH_UNIT_PASSES', '8'))
 TOUCH_AHEAD_MAX_STEPS = 63           # kAheadMaxSteps of csrc/mf_touch.h
+INDEX_MAX_STEPS = 1008               # kIdxMaxSteps of csrc/mf_index.h (touch_mode 3: the epoch's slots sorted by step)
+INDEX_HEAVY_SLOTS = 16               # touch_mode 3: rows with at least this many slots per step on average get a workgroup per step ...
+INDEX_SPLIT_SLOTS = 384              # ... and with this many, one per 256 slots of the step
+INDEX_HEAVY_MAX = 256                # kIdxHeavyMax
 TOUCH_MIN_TABLE_BYTES = 256 << 20    # auto rule: the job's live rows (w, m, second buffer) exceed the Infinity Cache
 
 
@@ -285,7 +289,10 @@ class TrainJob:
     """
 
     def __init__(self, shards, inits, perms, k, batch, epochs, lr, lam, momentum, lr_decay=1.0, lr_step=50, lazy_rows=None, snapshots=False,
-                 touch=None, final_only=False):
+                 touch=None, final_only=False, epoch_reads=False):
+        """touch: None = the auto rule (touch mode when the job's live rows exceed the Infinity Cache AND the caller reads the tables
+        at epoch ends only (epoch_reads) or after the last epoch only (final_only): a job in touch mode cannot be read inside an
+        epoch), True / False, or 'index' (touch_mode 3 whatever the epoch length)."""
         assert len(shards) == len(inits) == len(perms) and len(shards) > 0
         self.shards, self.k, self.d = shards, int(k), pad_dim(int(k))
         self.batch, self.epochs = int(batch), int(epochs)
@@ -304,12 +311,16 @@ class TrainJob:
         if touch is None:
             env = os.environ.get('URE_TOUCH', 'auto')
             live = sum(sh.n_active for sh in shards) * self.d * 12
-            touch = (env == '1') or (env == 'auto' and live > TOUCH_MIN_TABLE_BYTES)
+            touch = (env == '1') or (env == 'auto' and live > TOUCH_MIN_TABLE_BYTES and (final_only or epoch_reads))
         self.touch = bool(touch) and self.lazy_rows and max(steps_all) <= TOUCH_MAX_STEPS
         # touch_mode 2 (csrc/mf_touch.h, "masks one epoch ahead"): no dense pass at the epoch starts; for callers that read the tables
         # only after the last epoch (final_only) and epochs of at most 63 steps.  URE_TOUCH_AHEAD=0 keeps mode 1.
         self.ahead = (self.touch and bool(final_only) and max(steps_all) <= TOUCH_AHEAD_MAX_STEPS and snapshots in (False, None, 'compact')
                       and os.environ.get('URE_TOUCH_AHEAD', '1') != '0')
+        # touch_mode 3 (csrc/mf_index.h): epochs of more than 63 steps -- the epoch's slots are sorted by step at its start and a step
+        # launches over exactly the rows it trains (64-step windows look at every work unit in every step).  URE_TOUCH_INDEX=0 keeps windows.
+        self.index = (self.touch and not self.ahead and max(steps_all) <= INDEX_MAX_STEPS and
+                      (touch == 'index' or (max(steps_all) > TOUCH_AHEAD_MAX_STEPS and os.environ.get('URE_TOUCH_INDEX', '1') != '0')))
         # end-of-epoch snapshots: 'compact' keeps the n_active rows with interactions only (every other row is a_e * w0 and is
         # rebuilt where it is read: ure_eval_series_compact; needs lazy_rows), True / 'full' keeps complete tables
         self.snapshots = ('compact' if self.lazy_rows else 'full') if snapshots == 'compact' else ('full' if snapshots else False)
@@ -365,7 +376,13 @@ class TrainJob:
             D = descs[s]
             for name in ('ent_oid', 'ent_r', 'ent_tag', 'ent_src', 'file_tag', 'inv_stage', 'inv_off', 'sched'):
                 setattr(D, name, nv.ptr(getattr(sh, name)))
-            if self.touch:
+            if self.index:
+                # no work units: the step's items come from the epoch's index.  Rows by weight class (slots per step on average)
+                nnz, st_s = sh._sched_host[:min(sh.n_active, INDEX_HEAVY_MAX), 3], steps_all[s]
+                D.n_multi = int(np.count_nonzero(nnz >= INDEX_HEAVY_SLOTS * st_s))
+                D.n_split = min(D.n_multi, int(np.count_nonzero(nnz >= INDEX_SPLIT_SLOTS * st_s)))
+                units, n_units = sh.sched, 0
+            elif self.touch:
                 # epochs of several windows (more than 64 steps): a row of up to TOUCH_ROW_PASSES scan passes stays ONE work item -- its
                 # lane group skips the passes without a slot of the step (csrc/mf_touch.h: pass masks) -- instead of one unit per pass
                 long_epochs = max(steps_all) > 64
@@ -384,7 +401,7 @@ class TrainJob:
             D.N, D.n_user, D.n_item, D.d = sh.N, sh.n_user, sh.n_item, self.d
             D.batch, D.epochs = self.batch, self.epochs
             D.lam, D.mu = float(lam), float(momentum)
-            D.touch_mode = (2 if self.ahead else 1) if self.touch else 0
+            D.touch_mode = (3 if self.index else 2 if self.ahead else 1) if self.touch else 0
             if self.snapshots:
                 snap_a = small[1 + s]
                 self.state[-1].update(snap_a=snap_a)
@@ -575,6 +592,18 @@ class TrainJob:
         out, win = np.zeros(len(self.shards), dtype=np.int64), np.zeros(len(self.shards), dtype=np.int64)
         nv.check(nv.lib().ure_job_touch_rows(self._job, out.ctypes.data, win.ctypes.data), 'ure_job_touch_rows')
         return [float(n) / max(int(w), 1) for n, w in zip(out, win)]
+
+    _INDEX_ARRAYS = {'step_begin': (0, np.uint32, 1), 'step_item': (1, np.uint32, 1), 'items': (2, np.int32, 4), 'sslot': (3, np.uint32, 4),
+                     'W': (4, np.uint64, 1), 'heavy_cnt': (5, np.uint32, 1), 'heavy_cum': (6, np.uint32, 257)}
+
+    def index_array(self, s, name):
+        """Test aid (touch_mode 3): one array of shard s's slot index of its current epoch as a host array (ure_job_index_read; synchronises)."""
+        which, dtype, cols = self._INDEX_ARRAYS[name]
+        n = ctypes.c_int64()
+        nv.check(nv.lib().ure_job_index_read(self._job, s, which, None, 0, ctypes.byref(n)), 'ure_job_index_read')
+        out = np.empty(n.value // np.dtype(dtype).itemsize, dtype=dtype)
+        nv.check(nv.lib().ure_job_index_read(self._job, s, which, out.ctypes.data, out.nbytes, ctypes.byref(n)), 'ure_job_index_read')
+        return out.reshape(-1, cols) if cols > 1 else out
 
     def epoch_sse(self, s):
         """Per-epoch sum of squared training errors (host float64 array; synchronises)."""

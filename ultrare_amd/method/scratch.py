@@ -111,7 +111,7 @@ class Scratch(object):
         snap_mode = 'compact' if engine.LAZY_ROWS else 'full'
         series = queued and engine.TrainJob.snapshot_bytes([shard], self.epochs, self.k, snap_mode) <= snapshot_limit()
         job = engine.TrainJob([shard], [init], [perms], self.k, batch, self.epochs, self.lr, self.lam, self.momentum,
-                              self.lr_decay, snapshots=snap_mode if series else False, final_only=series)
+                              self.lr_decay, snapshots=snap_mode if series else False, final_only=series, epoch_reads=True)       # (tables are read at epoch ends only)
         rng.release(perms)                                  # uploaded: the host buffer goes back to the pool
         test_ev = as_loader(test_data).eval_set()
         total_ev = as_loader(test_total).eval_set() if has_total else None
