@@ -282,7 +282,7 @@ def roofline_of(a, leg, d, batch):
         # own duration comes from the pass with one event pair per launch (kernels of ~0.5 ms: the events cost nothing)
         avg_ms = step_ms / n_step
     traffic, traffic_src, traffic_note = None, None, None
-    kernel_name = 'mf_touch_step_kernel' if job.touch else 'mf_step_kernel'
+    kernel_name = 'mf_index_step_kernel' if getattr(job, 'index', False) else 'mf_touch_step_kernel' if job.touch else 'mf_step_kernel'
     import glob
     import re
     tag = f'{a.workload}_s{len(leg["all_sizes"])}_d{d}_b{batch}'
@@ -317,7 +317,7 @@ def roofline_of(a, leg, d, batch):
             'launches_timed': n_launch,
             'per_launch_event_us': round(step_ms / max(n_step, 1) * 1e3, 2),
             'dense_rows_streamed_per_shard': rows_streamed if len(rows_streamed) <= 8 else {'shards': len(rows_streamed), 'mean': round(float(np.mean(rows_streamed)), 1)},
-            'lazy_rows': bool(job.lazy_rows), 'touch_mode': bool(job.touch), 'source_hash': here,
+            'lazy_rows': bool(job.lazy_rows), 'touch_mode': (3 if getattr(job, 'index', False) else 2 if job.ahead else 1) if job.touch else 0, 'source_hash': here,
             'note': 'frac = algorithmic bytes (SURVEY 8d) / time / 8 TB/s; fabric_frac = PMC bytes that crossed the L2 / time / 8 TB/s '
                     '(ml-1m tables are cache resident, so fabric_frac is the HBM-side utilisation)'}
 

@@ -36,7 +36,7 @@ def source_hash(extra=()):
     return h.hexdigest()[:16]
 
 
-STEP_KERNEL_FILES = ['mf_train.hip', 'mf_touch.h', 'tag_prep.h', 'tag_prep.hip', 'ure_internal.h']
+STEP_KERNEL_FILES = ['mf_train.hip', 'mf_touch.h', 'mf_index.h', 'tag_prep.h', 'tag_prep.hip', 'ure_internal.h']
 
 
 def step_kernel_hash():

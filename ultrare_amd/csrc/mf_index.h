@@ -484,6 +484,15 @@ __global__ __launch_bounds__(kIdxHeavyMax) void idx_heavy_kernel(const ure_shard
     uint32_t *cum = A.heavy_cum + (size_t)s * (kIdxHeavyMax + 1);
     if (k == 0) stg(cum, 0u);
     stg(cum + k + 1, scan[k]);
+    // ... and for every workgroup of the step's heavy range the item and the part it takes (a search through `cum` in the step
+    // kernel was a chain of up to 256 dependent loads: the step's critical path)
+    uint32_t *map = A.heavy_map + (size_t)s * A.idx_hw;
+    const unsigned first = scan[k] - parts;
+    for (unsigned p = 0; p < parts && first + p < (unsigned)A.idx_hw; ++p) stg(map + first + p, (unsigned)k | (p << 9) | (parts << 20));
+    if (k == kIdxHeavyMax - 1) {
+        stg(A.heavy_wg + s, min(scan[k], (unsigned)A.idx_hw));
+        stg_u4(A.step_desc + s, make_uint4(item0, item1, n_heavy, min(scan[k], (unsigned)A.idx_hw)));
+    }
 }
 
 // ---- epoch start 9: every active row from "valid at the end of the last epoch" (buffer end_par) to "valid at its first step of this
@@ -546,6 +555,8 @@ __device__ __forceinline__ void idx_finish_row(const ure_shard_t &S, const shard
     RowVec<V4> nw, nm;
     idx_sgd<LPR, V4>(w, m4, acc, S.lam, S.mu, lr, nw, nm);
     if (gap > 0) row_advance<V4>(nw, nm, A.ptab[(size_t)epoch * A.ptab_stride + gap]);
+    // (written through the L2 with sc1 -- so that the 38 MB of rows a step rewrites are not left dirty for the kernel's end -- the
+    // launch took 27.4 us against 26.1 with plain stores: profiles/r04/NOTES.md)
     row_store<LPR, V4>((is_user ? S.mU : S.mV) + row_off, sub, nm);
     row_store<LPR, V4>((is_user ? S.U[buf ^ 1] : S.V[buf ^ 1]) + row_off, sub, nw);
     if (is_user && sub == 0 && sse != 0.f) {
@@ -620,17 +631,19 @@ __device__ __forceinline__ void mf_index_step(const ure_shard_t *__restrict__ sh
     const int sub = lane & (LPR - 1), grp = lane / LPR;
     const int local = wave * G + grp;
     const float lr = ldg(S.lr + epoch);
-    const unsigned i0 = ldg(A.step_item + s), i1 = ldg(A.step_item + s + 1), n_heavy = ldg(A.heavy_cnt + s);
+    const uint4 sd = ldg_u4(A.step_desc + s);              // {first item, end, heavy items, workgroups of the heavy items}
+    const unsigned i0 = sd.x, i1 = sd.y, n_heavy = sd.z;
     const int4 *__restrict__ items = A.items;
+#if defined(URE_INDEX_EXP) && URE_INDEX_EXP == 1
+    if (i0 != 0xFFFFFFFFu) return;
+#endif
     if ((int)blockIdx.x < A.idx_hw) {
         // ---- a heavy item (or one part of a split one): the workgroup's lane groups take its slots round robin
-        const uint32_t *__restrict__ cum = A.heavy_cum + (size_t)s * (kIdxHeavyMax + 1);
         const unsigned b = blockIdx.x;
-        if (b >= ldg(cum + n_heavy)) return;
-        unsigned k = 0;
-        while (ldg(cum + k + 1) <= b) ++k;                                   // (workgroup-uniform; at most 256 entries)
-        const unsigned c0 = ldg(cum + k), c1 = ldg(cum + k + 1);
-        const int part = (int)(b - c0), n_parts = (int)(c1 - c0);
+        if (b >= sd.w) return;
+        const unsigned hm = ldg(A.heavy_map + (size_t)s * A.idx_hw + b);     // item of the heavy prefix | part << 9 | parts << 20
+        const unsigned k = hm & 0x1FFu;
+        const int part = (int)((hm >> 9) & 0x7FFu), n_parts = (int)(hm >> 20);
         const int4 e = ldg_i4(reinterpret_cast<const int32_t *>(items + i0 + k));
         const int row_id = e.x & 0x7FFFFFFF, buf = (int)((unsigned)e.x >> 31), gap = e.w & 0xFFFF;
         const int first = n_parts > 1 ? e.y + part * kIdxPart : e.y;
@@ -684,7 +697,18 @@ __device__ __forceinline__ void mf_index_step(const ure_shard_t *__restrict__ sh
         m4 = row_load<LPR, V4>((is_user ? S.mU : S.mV) + row_off, sub);
     }
     float sse = 0.f;
+#if defined(URE_INDEX_EXP) && URE_INDEX_EXP == 2
+    e.z = e.y;
+#endif
+#if defined(URE_INDEX_EXP) && URE_INDEX_EXP == 4
+    if (have) { acc = w; sse = m4.q[0].x; }
+    if (sse == 12345.f && have) idx_finish_row<LPR, V4>(S, A, epoch, row_id, buf, gap, w, m4, acc, sse, lr, sub);
+    return;
+#endif
     idx_gather<LPR, V4>(S, A, is_user, w, e.y, e.z, 1, have, sub, acc, sse);
+#if defined(URE_INDEX_EXP) && URE_INDEX_EXP == 3
+    if (sse == 12345.f)
+#endif
     if (have) idx_finish_row<LPR, V4>(S, A, epoch, row_id, buf, gap, w, m4, acc, sse, lr, sub);
 }
 

@@ -771,6 +771,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
                               (S.touch_mode == 2 && S.snap && !S.row_slot) ? "touch_mode 2 needs row_slot with snap" :
                               (S.touch_mode == 3 && job->aux_host[k].steps > kIdxMaxSteps) ? "touch_mode 3 takes at most 1008 steps per epoch (16 mask words of 63 steps)" :
                               (S.touch_mode == 3 && (S.n_multi > kIdxHeavyMax || S.n_split < 0 || S.n_split > S.n_multi)) ? "touch_mode 3: 0 <= n_split <= n_multi <= 256" :
+                              (S.touch_mode == 3 && S.batch > 200000) ? "touch_mode 3 takes batches of at most 200,000 (the parts of a split row are numbered in 11 bits)" :
                               !S.lazy_rows ? "it needs lazy_rows" :
                               job->aux_host[k].steps > kTouchMaxSteps ? "more than 32000 steps per epoch (the step number shares the 16-bit batch tag with the buffer bit)" :
                               (S.epochs != shards[0].epochs || S.lam != shards[0].lam || S.mu != shards[0].mu ||
@@ -826,6 +827,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             const size_t o_ss = take(slots * 16), o_rf = take((slots / 64 + 2) * 8), o_bc = take((slots / kIdxFlagBlock + 2) * 4);
             const size_t o_it = take(((size_t)std::min<int64_t>(2 * (int64_t)S.N, S.n_slots) + 1) * 16), o_si = take((steps + 2) * 4), o_hc = take(steps * 4);
             const size_t o_cum = take(steps * (kIdxHeavyMax + 1) * 4), o_pa = take((size_t)A.idx_hw * (S.d + 4) * 4);
+            const size_t o_map = take(steps * (size_t)A.idx_hw * 4), o_wg = take(steps * 4), o_sd = take(steps * 16);
             void *mem = nullptr;
             e = hipMalloc(&mem, at);
             if (e != hipSuccess) break;
@@ -848,6 +850,9 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             A.heavy_cnt = reinterpret_cast<uint32_t *>(b + o_hc);
             A.heavy_cum = reinterpret_cast<uint32_t *>(b + o_cum);
             A.partial = reinterpret_cast<float *>(b + o_pa);
+            A.heavy_map = reinterpret_cast<uint32_t *>(b + o_map);
+            A.heavy_wg = reinterpret_cast<uint32_t *>(b + o_wg);
+            A.step_desc = reinterpret_cast<uint4 *>(b + o_sd);
             job->index_split = job->index_split || S.n_split > 0;
         }
         for (int k = 0; k < n_shards && e == hipSuccess && !job->index; ++k) {

@@ -226,6 +226,9 @@ struct shard_aux {
     uint32_t *step_item;           // [steps + 2] first item of each step
     uint32_t *heavy_cnt;           // [steps] items of the step that whole workgroups take (a prefix of its items)
     uint32_t *heavy_cum;           // [steps][257] workgroups of the step's heavy items, cumulative
+    uint32_t *heavy_map;           // [steps][idx_hw] workgroup of the heavy range -> item of the prefix | part << 9 | parts << 20
+    uint32_t *heavy_wg;            // [steps] workgroups the step's heavy items take in all
+    uint4 *step_desc;              // [steps] {first item, end, heavy items, heavy workgroups}: what a workgroup of the step kernel reads first
     float *partial;                // [idx_hw][d + 4] partial gradient sums of the rows split over several workgroups
 };
 

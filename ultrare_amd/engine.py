@@ -319,7 +319,7 @@ class TrainJob:
                       and os.environ.get('URE_TOUCH_AHEAD', '1') != '0')
         # touch_mode 3 (csrc/mf_index.h): epochs of more than 63 steps -- the epoch's slots are sorted by step at its start and a step
         # launches over exactly the rows it trains (64-step windows look at every work unit in every step).  URE_TOUCH_INDEX=0 keeps windows.
-        self.index = (self.touch and not self.ahead and max(steps_all) <= INDEX_MAX_STEPS and
+        self.index = (self.touch and not self.ahead and max(steps_all) <= INDEX_MAX_STEPS and self.batch <= 200000 and
                       (touch == 'index' or (max(steps_all) > TOUCH_AHEAD_MAX_STEPS and os.environ.get('URE_TOUCH_INDEX', '1') != '0')))
         # end-of-epoch snapshots: 'compact' keeps the n_active rows with interactions only (every other row is a_e * w0 and is
         # rebuilt where it is read: ure_eval_series_compact; needs lazy_rows), True / 'full' keeps complete tables
