@@ -185,8 +185,8 @@ int ure_job_touch_rows(ure_job_t *job, int64_t *pairs, int64_t *window_steps);
 /* Test aid, touch_mode 3 (synchronises): copies one array of shard `shard`'s slot index of its current epoch to HOST memory `out`
  * (capacity bytes; out == NULL: only *bytes is set).  which: 0 step_begin u32 [steps + 1] (first sorted slot of every step, then
  * their number) | 1 step_item u32 [steps + 1] | 2 items int32 [n][4] {row id | buffer << 31, first sorted slot, end, steps until
- * the row's next own step | class << 16} | 3 sorted slots u32 [n][4] {opposite id | buffer << 31, rating bits, schedule index of
- * the row | item row << 31, step} | 4 W u64 [words][rows] | 5 heavy_cnt u32 [steps] | 6 heavy_cum u32 [steps][257].           */
+ * the row's next own step | class << 16} | 3 sorted slots u32 [n][4] {opposite id | buffer << 31, rating bits, row id,
+ * step | class << 16} | 4 W u64 [words][rows] | 5 heavy_cnt u32 [steps] | 6 heavy_cum u32 [steps][257].           */
 int ure_job_index_read(ure_job_t *job, int shard, int which, void *out, int64_t capacity, int64_t *bytes);
 /* Measurement aid (bench.py's roofline leg): the same ticks, each kernel launch
  * bracketed by a pair of HIP events on `stream`; synchronises the stream and returns

@@ -158,6 +158,10 @@ def test_unlearn_16_shards_properties(ml1m, tmp_path):
 
 
 def test_ml1m_size_vs_reference_golden(ml1m, tmp_path):
+    check_ml1m_size_against_reference(ml1m, tmp_path)
+
+
+def check_ml1m_size_against_reference(ml1m, tmp_path):
     """BASELINE configs[0] and [1] at full ml-1m size against the REAL reference (one epoch,
     tests/golden/ml1m_synth.npz): Scratch.train (full MF) and Sisa.learn (5 shards, d=32),
     sequential and shard-parallel, including the per-epoch group / total test series."""

@@ -75,6 +75,12 @@ def _sisa_inputs(S, del_user=()):
 @pytest.mark.parametrize('S,E', [(3, 2), (4, 3)])
 @pytest.mark.parametrize('parallel', [False, True])
 def test_sisa_learn_unlearn_matches_reference(S, E, parallel, tmp_path):
+    check_sisa_against_reference(S, E, parallel, tmp_path)
+
+
+def check_sisa_against_reference(S, E, parallel, tmp_path):
+    """Sisa.learn and two Sisa.unlearn calls against the goldens of the real reference (sisa.py:25-118); also run by
+    tests/test_gpu_surface_touch.py with the engine forced into its touch modes."""
     import copy
     from ultrare_amd.method.sisa import Sisa
     g = np.load(os.path.join(G, 'sisa_toy.npz'))

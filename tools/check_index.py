@@ -37,12 +37,10 @@ def check(job, s, part, perm, B):
     assert np.array_equal(sb, exp_sb), ('step_begin', sb[:8], exp_sb[:8])
     ss = job.index_array(s, 'sslot')
     assert len(ss) == len(st)
-    assert np.array_equal(ss[:, 3], st), 'sorted slots: steps'
+    assert np.array_equal(ss[:, 3] & 0xFFFF, st), 'sorted slots: steps'
     assert np.array_equal(ss[:, 0] & 0x7FFFFFFF, opp), 'sorted slots: opposite ids'
     assert np.array_equal(ss[:, 1].view(np.float32), rat), 'sorted slots: ratings'
-    row_of_sched = sh._sched_host[:, 0]
-    assert np.array_equal(row_of_sched[ss[:, 2] & 0x7FFFFFFF], rows), 'sorted slots: rows'
-    assert np.array_equal(ss[:, 2] >> 31, (rows >= sh.n_user).astype(np.uint32)), 'sorted slots: item-row flag'
+    assert np.array_equal(ss[:, 2], rows), 'sorted slots: rows'
     # runs
     start = np.ones(len(st), dtype=bool)
     start[1:] = (st[1:] != st[:-1]) | (rows[1:] != rows[:-1])

@@ -156,6 +156,14 @@ __global__ __launch_bounds__(kBlock) void idx_parity_kernel(const ure_shard_t *_
         }
         stg(A.first_step + row_id, (uint16_t)first);
         stg(A.end_par[epoch & 1] + row_id, (uint8_t)par);
+        // next_first[w][row] = the row's first own step in the words after w (steps: none): what the item of a row's LAST step of
+        // word w needs to know how long the row then waits (idx_emit_kernel)
+        int nxt = A.steps;
+        for (int w = A.idx_words - 1; w >= 0; --w) {
+            stg(A.next_first + (size_t)w * n_all + row_id, (uint16_t)nxt);
+            const unsigned long long v = ldg(A.W + (size_t)w * n_all + row_id) & kIdxBits;
+            if (v) nxt = w * kIdxWin + __ffsll((long long)v) - 1;
+        }
     }
 }
 
@@ -279,13 +287,15 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_kernel(const ure_shard_t *
     for (int64_t p0 = lo; p0 < hi; p0 += kWave) {
         const int64_t p = p0 + lane;
         unsigned tag = 0xFFFFu;
-        int oid = 0, row = 0;
+        int oid = 0, row = 0, cls = 0;
         float r = 0.f;
         if (p < hi) {
             tag = ldg(ent_tag + p);
             oid = ldg(S.ent_oid + p);
             r = ldg(S.ent_r + p);
-            row = ldg(A.grp_row + (p >> 3));
+            const int idx = ldg(A.grp_row + (p >> 3)) & 0x7FFFFFFF;
+            row = ldg(S.sched + 4 * (size_t)idx);                       // (the schedule is 3.5 MB at the 25 M shape: L2 resident)
+            cls = idx < S.n_split ? kIdxSplit : idx < S.n_multi ? kIdxHeavy : kIdxLight;
         }
         const bool valid = tag < (unsigned)steps;
         unsigned long long peers = __ballot(valid);
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_kernel(const ure_shard_t *
             const unsigned base = mine[tag];                            // (all peers read before their first lane writes: LDS runs a wave's accesses in order)
             const int rank = __popcll(peers & below);
             if (rank == 0) mine[tag] = base + (unsigned)__popcll(peers);
-            stg_u4(A.sslot + (size_t)(base + rank), make_uint4((unsigned)oid, __builtin_bit_cast(unsigned, r), (unsigned)row, tag));
+            stg_u4(A.sslot + (size_t)(base + rank), make_uint4((unsigned)oid, __float_as_uint(r), (unsigned)row, tag | ((unsigned)cls << 16)));
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -324,8 +334,8 @@ __global__ __launch_bounds__(kBlock) void idx_mark_kernel(const ure_shard_t *__r
         bool start = false;
         if (q < total) {
             uint4 rec = ldg_u4(A.sslot + q);
-            const unsigned st = rec.w;
-            const int other = (rec.z >> 31) ? (int)rec.x : S.n_user + (int)rec.x;              // this slot's row is an item row: the opposite row is a user
+            const unsigned st = rec.w & 0xFFFFu;
+            const int other = (int)rec.z >= S.n_user ? (int)rec.x : S.n_user + (int)rec.x;     // this slot's row is an item row: the opposite row is a user
             const unsigned long long word = ldg(A.W + (size_t)(st / kIdxWin) * n_all + other);
             rec.x |= (unsigned)idx_buffer_at(word, (int)(st % kIdxWin)) << 31;
             stg_u4(A.sslot + q, rec);
@@ -390,46 +400,50 @@ __device__ __forceinline__ unsigned idx_item_of(const shard_aux &A, int64_t q)
 // ---- epoch start 7: one item per run.  Workgroup b takes the sorted slots [2048 b, 2048 (b + 1)).
 __global__ __launch_bounds__(kBlock) void idx_emit_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
 {
+    __shared__ unsigned before[kIdxFlagBlock / 64];             // runs that start in the block before each of its 64-slot words
     const ure_shard_t &S = shards[blockIdx.y];
     const shard_aux &A = aux[blockIdx.y];
     if (idx_epoch_start(S, A, tick) < 0) return;
     const int64_t total = ldg(A.step_begin + A.steps);
     const int64_t q_lo = (int64_t)blockIdx.x * kIdxFlagBlock;
     if (q_lo >= total) return;
-    const int n_all = S.n_user + S.n_item, steps = A.steps, words = A.idx_words;
+    const int n_all = S.n_user + S.n_item;
     const int lane = threadIdx.x & 63;
+    const int64_t n_words = (total + 63) >> 6;
+    if (threadIdx.x == 0) {
+        unsigned run = ldg(A.blk_cnt + blockIdx.x);
+        for (int w = 0; w < kIdxFlagBlock / 64; ++w) {
+            before[w] = run;
+            const int64_t wi = (q_lo >> 6) + w;
+            if (wi < n_words) run += (unsigned)__popcll(ldg(A.runflag + wi));
+        }
+    }
+    __syncthreads();
     for (int it = 0; it < kIdxFlagBlock / kBlock; ++it) {
         const int64_t q = q_lo + it * kBlock + threadIdx.x;
         if (q >= total) continue;
-        if (!((ldg(A.runflag + (q >> 6)) >> lane) & 1ull)) continue;
-        const unsigned i = idx_item_of(A, q);
+        const int64_t wi = q >> 6;
+        const unsigned long long flags = ldg(A.runflag + wi);
+        if (!((flags >> lane) & 1ull)) continue;
+        const unsigned i = before[(int)(wi - (q_lo >> 6))] + (unsigned)__popcll(flags & mask_below(lane));
         const uint4 rec = ldg_u4(A.sslot + q);
-        const int idx = (int)(rec.z & 0x7FFFFFFFu), st = (int)rec.w;
-        const int row_id = ldg(S.sched + 4 * (size_t)idx);
+        const int row_id = (int)rec.z, st = (int)(rec.w & 0xFFFFu), cls = (int)(rec.w >> 16);
         const int w = st / kIdxWin, b = st % kIdxWin;
         const unsigned long long word = ldg(A.W + (size_t)w * n_all + row_id);
+        const int nxt = (int)ldg(A.next_first + (size_t)w * n_all + row_id);
+        // where the run ends: the next run start (a few words on for the runs of the heaviest rows)
+        unsigned long long later = lane < 63 ? flags >> (lane + 1) : 0ull;
+        int64_t end = later ? q + 1 + (__ffsll((long long)later) - 1) : -1;
+        for (int64_t w2 = wi + 1; end < 0; ++w2) {
+            if (w2 >= n_words) { end = total; break; }
+            const unsigned long long f2 = ldg(A.runflag + w2);
+            if (f2) end = (w2 << 6) + (__ffsll((long long)f2) - 1);
+        }
         const int buf = idx_buffer_at(word, b);
         // steps that pass between this step and the row's next own step (none: until the epoch ends)
-        const unsigned long long rest = b + 1 < 64 ? (word & kIdxBits) >> (b + 1) : 0ull;
-        int gap;
-        if (rest) gap = __ffsll((long long)rest) - 1;
-        else {
-            gap = steps - 1 - st;
-            for (int w2 = w + 1; w2 < words; ++w2) {
-                const unsigned long long v = ldg(A.W + (size_t)w2 * n_all + row_id) & kIdxBits;
-                if (v) { gap = w2 * kIdxWin + __ffsll((long long)v) - 1 - st - 1; break; }
-            }
-        }
-        const int cls = idx < S.n_split ? kIdxSplit : idx < S.n_multi ? kIdxHeavy : kIdxLight;
-        int *e = reinterpret_cast<int *>(A.items + i);
-        stg(e + 0, row_id | (buf << 31));
-        stg(e + 1, (int)q);
-        stg(e + 3, gap | (cls << 16));
-        if (i > 0) stg(reinterpret_cast<int *>(A.items + (i - 1)) + 2, (int)q);        // the run before this one ends here
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const unsigned n_items = ldg(A.blk_cnt + (total + kIdxFlagBlock - 1) / kIdxFlagBlock);
-        if (n_items > 0) stg(reinterpret_cast<int *>(A.items + (n_items - 1)) + 2, (int)total);
+        const unsigned long long rest = (word & kIdxBits) >> (b + 1);
+        const int gap = rest ? __ffsll((long long)rest) - 1 : nxt - st - 1;
+        stg_i4(A.items + i, make_int4(row_id | (buf << 31), (int)q, (int)min(end, total), gap | (cls << 16)));
     }
 }
 

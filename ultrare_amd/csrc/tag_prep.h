@@ -216,10 +216,11 @@ struct shard_aux {
                                    // its weights are in at step 63 w
     uint8_t *end_par[2];           // [n_user + n_item] buffer of the row at the end of an epoch, by epoch parity
     uint16_t *first_step;          // [n_user + n_item] the row's first step of the epoch (steps: none)
+    uint16_t *next_first;          // [idx_words][n_user + n_item] the row's first step in the words after w (steps: none)
     uint32_t *hist;                // [idx_chunks][steps + 1] slots per (chunk, step) -> after the scan: where the chunk's run of the step starts
     uint32_t *seg;                 // [32][steps + 1] scan scratch
     uint32_t *step_begin;          // [steps + 2] first sorted slot of each step; [steps] = sorted slots in all
-    uint4 *sslot;                  // [n_slots] slots sorted by (step, row, file order): {opposite id | buffer << 31, rating, row, step}
+    uint4 *sslot;                  // [n_slots] slots sorted by (step, row, file order): {opposite id | buffer << 31, rating, row id, step | class << 16}
     unsigned long long *runflag;   // [n_slots / 64 + 1] bit = the sorted slot starts a (step, row) run
     uint32_t *blk_cnt;             // [n_slots / 2048 + 2] runs that start in each block of 2048 sorted slots -> exclusive prefix
     int4 *items;                   // [2 N + 1] one per (step, row) run, steps ascending: {row id | buffer << 31, first sorted slot, end, gap | class << 16}

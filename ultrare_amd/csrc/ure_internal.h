@@ -95,6 +95,7 @@ __device__ __forceinline__ float4 ldg_f4(const float *p) { const ure_f4 v = *(co
 __device__ __forceinline__ int4 ldg_i4(const int32_t *p) { const ure_i4 v = *(const ure_i4 URE_AS1 *)p; return make_int4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ uint4 ldg_u4(const void *p) { const ure_u4 v = *(const ure_u4 URE_AS1 *)p; return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void stg_f4(float *p, float4 v) { ure_f4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(ure_f4 URE_AS1 *)p = t; }
+__device__ __forceinline__ void stg_i4(void *p, int4 v) { ure_i4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(ure_i4 URE_AS1 *)p = t; }
 __device__ __forceinline__ void stg_u4(void *p, uint4 v) { ure_u4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(ure_u4 URE_AS1 *)p = t; }
 
 // A lane's share of a table row: V4 float4 pieces.  Lane `sub` of the LPR lanes that share a row
