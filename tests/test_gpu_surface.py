@@ -283,3 +283,37 @@ def test_late_permutation_chunks_do_not_change_results(monkeypatch):
     assert torch.equal(out[0][1], out[1][1])
     assert out[0][2]['train_loss'] == out[1][2]['train_loss'] and out[0][2]['total_ndcg'] == out[1][2]['total_ndcg']
     assert out[0][3] == out[1][3]
+
+
+def test_cli_default_trains_shards_side_by_side_and_prints_the_same_lines(tmp_path, capsys):
+    """main.py:60-70.  `python main.py --group 3` takes the shard-parallel path by default: models, logs, log0 and
+    the per-epoch lines of scratch.py:99-118 equal those of `--parallel 0`, which trains shard after shard as the reference does."""
+    import re
+    import shutil
+    from ultrare_amd.main import main, parser
+    assert parser.get_default('parallel') == 1
+    data = tmp_path / 'data'
+    (data / 'toy').mkdir(parents=True)
+    shutil.copy(TRAIN, data / 'toy' / '0_train.csv')
+    shutil.copy(TEST, data / 'toy' / '0_test.csv')
+    main(['--dataset', 'toy', '--epoch', '2', '--group', '0', '--data-dir', str(data), '--save-dir', str(tmp_path / 'r0'), '--verbose', '0'])
+    shutil.copytree(tmp_path / 'r0', tmp_path / 'r1')
+    outs = []
+    for par, save in (('0', 'r0'), (None, 'r1')):
+        capsys.readouterr()
+        main(['--dataset', 'toy', '--epoch', '2', '--group', '3', '--data-dir', str(data), '--save-dir', str(tmp_path / save)] +
+             (['--parallel', par] if par is not None else []))
+        outs.append([re.sub(r'time: \S+', 'time: -', ln) for ln in capsys.readouterr().out.splitlines() if ln.startswith(('Epoch', 'Using'))])
+    assert outs[0] == outs[1] and sum(ln.startswith('Epoch') for ln in outs[0]) >= 3 * 2
+    for run in ('MF_emb-ot_sisa_learn', 'MF_emb-ot_sisa_unlearn'):
+        a, b = (tmp_path / r / '2' / 'rand' / 'toy_g3' / run for r in ('r0', 'r1'))
+        assert np.load(a / 'log0.npy', allow_pickle=True).item() == np.load(b / 'log0.npy', allow_pickle=True).item()
+        for i in (1, 2, 3):
+            if (a / f'item_mat{i}.npy').exists():
+                assert np.array_equal(np.load(a / f'item_mat{i}.npy'), np.load(b / f'item_mat{i}.npy'))
+                la, lb = (np.load(x / f'log{i}.npy', allow_pickle=True).item() for x in (a, b))
+                # (verbose 1: the sequential path reads every epoch's per-user results back and reduces them with numpy, the parallel
+                # path reduces on the device in a fixed order -- equal to rounding; bit-identical at verbose 0, test_parallel_equals_...)
+                for k in la:
+                    if k != 'time':
+                        np.testing.assert_allclose(la[k], lb[k], rtol=1e-6, err_msg=k)

@@ -10,7 +10,6 @@ C ABI:  include/ultrare_hip.h  ->  ultrare_amd/libultrare_hip.so  (python -m ult
 """
 __version__ = '0.1.0'
 
-# (see rng.limit_torch_threads: torch's CPU thread pool must respect the container's CPU quota)
-from . import rng as _rng  # noqa: E402
-
-_rng.limit_torch_threads()
+# Nothing process-global changes at import.  torch's intra-op pool is capped for the DURATION of a request only
+# (rng.torch_threads(): Scratch.train, Sisa.learn / unlearn, Instance.run*) and restored afterwards; URE_TORCH_THREADS=0
+# leaves torch alone, =n sets n (conventions).

@@ -132,7 +132,9 @@ def lib():
 def check(rc, what):
     if rc != 0:
         msg = lib().ure_last_error().decode(errors='replace')
-        raise NativeError(f'{what} failed (code {rc}): {msg}')
+        err = NativeError(f'{what} failed (code {rc}): {msg}')
+        err.code = rc
+        raise err
 
 
 def ptr(t):

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -33,6 +34,7 @@
 
 namespace ure {
 int fail(int code, const char *fmt, ...);
+char *err_buf();
 int host_threads();
 }
 
@@ -195,7 +197,7 @@ static int build_layout_t(const IdT *uid, const IdT *iid, const RT *rating, int6
     std::vector<int64_t> nnz(n_rows, 0);
     for (int64_t j = 0; j < n; ++j) {
         if (uid[j] < 0 || uid[j] >= n_user || iid[j] < 0 || iid[j] >= n_item)
-            return ure::fail(-1, "ure_host_build_layout: interaction %lld has an id outside [0,%d) x [0,%d)", (long long)j, n_user, n_item);
+            return ure::fail(-2, "ure_host_build_layout: interaction %lld has an id outside [0,%d) x [0,%d)", (long long)j, n_user, n_item);
         ++nnz[uid[j]];
         ++nnz[n_user + iid[j]];
     }
@@ -210,7 +212,7 @@ static int build_layout_t(const IdT *uid, const IdT *iid, const RT *rating, int6
     int64_t slots = 0;
     for (int64_t r = 0; r < n_rows; ++r) slots += (nnz[r] + 7) / 8 * 8;
     slots = std::max<int64_t>(slots, 8);
-    if (slots >= ((int64_t)1 << 31)) return ure::fail(-1, "ure_host_build_layout: shard too large for 32-bit slot indices");
+    if (slots >= ((int64_t)1 << 31)) return ure::fail(-3, "ure_host_build_layout: shard too large for 32-bit slot indices (%lld slots)", (long long)slots);
     if (packed) {
         // one region: ent_oid [k] | ent_r [k] | ent_src [k] | sched [rows][4] | row_slot [rows], k = the slot count (known by now)
         ent_r = reinterpret_cast<float *>(ent_oid + slots);
@@ -326,11 +328,12 @@ static int build_layouts_impl(int n_shards, const int64_t *const *uid, const int
     std::atomic<int> next{0}, rc{0};
     // (ure::fail keeps its message per thread: a worker's failure is re-reported on the calling thread below)
     std::vector<int> bad(n_shards, 0);
+    std::vector<std::string> why(n_shards);
     auto work = [&]() {
         for (int s = next.fetch_add(1); s < n_shards; s = next.fetch_add(1)) {
             const int r = build_layout_t(uid[s], iid[s], rating[s], n[s], n_user, n_item, region[s], (float *)nullptr, (int32_t *)nullptr,
                                          (int32_t *)nullptr, (int32_t *)nullptr, n_slots + s, n_active + s, (int32_t *)nullptr, (int32_t *)nullptr, true);
-            if (r) { bad[s] = r; rc.store(r); continue; }
+            if (r) { bad[s] = r; why[s] = ure::err_buf(); rc.store(r); continue; }
             if (units_d) {
                 // the work units of this table width right behind the layout, so that ONE copy takes both to the device:
                 // region = layout (3 k + 5 rows words) | pad to 8 words | units [n_units][4].  -1: they did not fit (the caller asks
@@ -355,7 +358,7 @@ static int build_layouts_impl(int n_shards, const int64_t *const *uid, const int
     }
     if (rc.load())
         for (int s = 0; s < n_shards; ++s)
-            if (bad[s]) return ure::fail(bad[s], "ure_host_build_layouts: shard %d has an id outside [0,%d) x [0,%d) or is too large", s, n_user, n_item);
+            if (bad[s]) return ure::fail(bad[s], "ure_host_build_layouts: shard %d: %s", s, why[s].c_str());      // -2: an id outside its range, -3: too large
     return 0;
 }
 

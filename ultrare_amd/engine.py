@@ -144,15 +144,31 @@ def build_shards(triples, n_user, n_item, device=None, keep_positions=False, uni
     stage = rng.STAGING.take((sum(words),), torch.int32)
     host = stage.numpy()
     off = np.concatenate([[0], np.cumsum(words)]).astype(np.int64)
+    handed_back = False
     try:
-        built = nv.build_layouts(cols, n_user, n_item, [host[off[s]:off[s + 1]] for s in range(S)], threads=min(S, rng.host_cpus()), units_d=d_units)
+        try:
+            built = nv.build_layouts(cols, n_user, n_item, [host[off[s]:off[s + 1]] for s in range(S)], threads=min(S, rng.host_cpus()), units_d=d_units)
+        except nv.NativeError as e:
+            if getattr(e, 'code', None) == -2:             # (-3: a shard beyond 2^31 slots -- reported as it is)
+                raise ValueError(f'user or item id outside [0, n_user) x [0, n_item): {e}') from None
+            raise
         n_slots, n_active = built[0], built[1]
         n_units = built[2] if d_units else [-1] * S
-    except nv.NativeError as e:
-        rng.STAGING.give(stage, None)
-        if 'outside' in str(e):
-            raise ValueError(f'user or item id outside [0, n_user) x [0, n_item): {e}') from None
-        raise
+        out, ready, pinned = _upload_layouts(stage, host, off, cols, n_slots, n_active, n_units, d_units, n_user, n_item, dev, on_gpu, keep_positions)
+        rng.STAGING.give(stage, ready if pinned else None)
+        handed_back = True
+    finally:
+        if not handed_back:
+            rng.STAGING.give(stage, None)                  # whatever went wrong, the pooled staging buffer goes back
+    with ShardData._count_lock:
+        ShardData.built += S
+    return out
+
+
+def _upload_layouts(stage, host, off, cols, n_slots, n_active, n_units, d_units, n_user, n_item, dev, on_gpu, keep_positions):
+    from . import rng
+    S, rows = len(cols), n_user + n_item
+    al = lambda x: (x + 7) // 8 * 8
     units_at = [al(3 * int(k) + 5 * rows) for k in n_slots]                       # where a shard's units start inside its region (when built)
     used = [a + (al(4 * int(u)) if u > 0 else 0) for a, u in zip(units_at, n_units)]
     d_off = np.concatenate([[0], np.cumsum(used)]).astype(np.int64)
@@ -202,12 +218,9 @@ def build_shards(triples, n_user, n_item, device=None, keep_positions=False, uni
     if on_gpu:
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
-    rng.STAGING.give(stage, ready if pinned else None)
     for sh in out:
         sh.ready = ready
-    with ShardData._count_lock:
-        ShardData.built += S
-    return out
+    return out, ready, pinned
 
 
 class ShardData:

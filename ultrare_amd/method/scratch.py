@@ -56,6 +56,20 @@ def prepare_shard(train_loader, n_user, n_item, k, epochs, has_total, given_mode
     return loader.shard_data(n_user, n_item), (U0, V0), perms
 
 
+def print_epoch(verbose, t, epochs, train_loss, test, total, has_total, epoch_time):
+    """The per-epoch lines of scratch.py:99-118 (verbose 1 and 2).  test / total = (rmse, ndcg, hr)."""
+    if verbose == 2:
+        print(f'Epoch: [{t+1:>3d}/{epochs:>3d}] --------------------')
+        print(f'Test - RMSE: {test[0]:>.4f}, NDCG: {test[1]:>.3f}, HR: {test[2]:>.3f}')
+        print('Time:', epoch_time)
+    elif verbose == 1:
+        msg = (f'Epoch: [{t+1:>2d}/{epochs:>2d}]' + f' train loss: {train_loss:>.9f},' +
+               f' train RMSE: {train_loss:>.4f},' + f' test RMSE: {test[0]:>.4f},')
+        if has_total:
+            msg += f' total RMSE: {total[0]:>.4f},'
+        print(msg + ' time:', epoch_time)
+
+
 class Scratch(object):
     def __init__(self, param, model_type):
         # model param
@@ -99,6 +113,10 @@ class Scratch(object):
         return list(getattr(self, 'model_list', [])) if self.__class__.__name__ == 'Sisa' else []
 
     def train(self, train_data, test_data, test_total=[], verbose=1, save_dir='', id=0, given_model=''):
+        with rng.torch_threads():          # (torch's intra-op pool capped for the duration of the request, restored afterwards)
+            return self._train(train_data, test_data, test_total, verbose, save_dir, id, given_model)
+
+    def _train(self, train_data, test_data, test_total, verbose, save_dir, id, given_model):
         print('Using device:', self.device)
         seed_all(self.seed)                                 # scratch.py:54
         has_total = not _is_empty(test_total)
@@ -134,8 +152,6 @@ class Scratch(object):
             res = res.transpose(0, 1).contiguous()
             times = ['00:00:00'] * self.epochs
         for t in range(0 if not series else self.epochs, self.epochs):
-            if verbose == 2:
-                print(f'Epoch: [{t+1:>3d}/{self.epochs:>3d}] --------------------')
             epoch_start = time.time()
             job.run_epochs(1)                               # baseTrain (utils.py:46-111) + scheduler.step()
             models = before + [job.padded_tables(0)]        # scratch.py:83-86
@@ -150,17 +166,8 @@ class Scratch(object):
             else:
                 total_rmse, total_ndcg, total_hr = test_rmse, test_ndcg, test_hr
             train_loss = float(np.sqrt(job.epoch_sse(0)[t] / n_train))
-            train_rmse = train_loss
             epoch_time = time.strftime('%H:%M:%S', time.gmtime(time.time() - epoch_start))
-            if verbose == 2:
-                print(f'Test - RMSE: {test_rmse:>.4f}, NDCG: {test_ndcg:>.3f}, HR: {test_hr:>.3f}')
-                print('Time:', epoch_time)
-            elif verbose == 1:
-                msg = (f'Epoch: [{t+1:>2d}/{self.epochs:>2d}]' + f' train loss: {train_loss:>.9f},' +
-                       f' train RMSE: {train_rmse:>.4f},' + f' test RMSE: {test_rmse:>.4f},')
-                if has_total:
-                    msg += f' total RMSE: {total_rmse:>.4f},'
-                print(msg + ' time:', epoch_time)
+            print_epoch(verbose, t, self.epochs, train_loss, (test_rmse, test_ndcg, test_hr), (total_rmse, total_ndcg, total_hr), has_total, epoch_time)
 
             self.log['train_loss'].append(train_loss)
             self.log['test_rmse'].append(test_rmse)

@@ -45,13 +45,15 @@ def assign_shards(sizes, world):
     return owner
 
 
-def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_device=True, foreign_u0=None):
-    """Host part of a parallel call.  Every rank replays the WHOLE RNG stream in shard
+def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_device=True):
+    """Host part of a parallel call.  Every rank walks the WHOLE RNG stream in shard
     order (the draws are data independent: 4 fills + 4 seeds per epoch per shard,
-    SURVEY.md 3.4) and keeps the init / permutations of its own shards only, so shard
-    i starts from exactly the state it would have in a sequential single-process run.
-    foreign_u0: dict that receives U0 of the shards other ranks own (the full pre-merge user
-    table of such a shard is its exchanged own rows + the closed form of U0 elsewhere)."""
+    SURVEY.md 3.4) but DRAWS only for its own shards: the generator is moved past everything
+    a shard of another rank would draw (ure_host_mt_advance), so shard i starts from exactly
+    the state it would have in a sequential single-process run and no rank makes a normal it
+    does not train on.  (Round 3 drew the full U0 of every foreign shard on every rank -- the
+    reference's per-epoch logs need the earlier shards' full user tables -- ; those now come
+    from their owners with the path's one exchange: exchange_tables(full_u=True).)"""
     from .. import rng
     prepared = {}
     # the HBM layouts of the owned shards -- which training needs first -- are built at once on a worker: ONE native call for
@@ -92,9 +94,6 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
                                       tags_batch=loader.batch_size if os.environ.get('URE_HOST_TAGS', '1') != '0' else 0,
                                       chunk_epochs=chunk_epochs))
                     order.append(i)
-                elif foreign_u0 is not None:
-                    specs.append(dict(base, n_rows=0, shuffle=False, want_perms=False))
-                    order.append(i)
             # few workers, several shards each (rng.draws_batch_async): the expansion threads of a worker's native calls share
             # the rank's CPUs
             W = max(1, min(len(specs), int(os.environ.get('URE_DRAW_WORKERS', '0')) or max(2, rng.host_cpus() // 2)))
@@ -108,10 +107,7 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
         for pos, i in enumerate(ids):
             if i not in futures:
                 continue
-            if owner[pos] == rank:
-                prepared[i] = (shards[i], futures[i].init(), futures[i].perms())     # the permutations may still be arriving (chunks)
-            else:
-                foreign_u0[i] = futures[i].init()[0]
+            prepared[i] = (shards[i], futures[i].init(), futures[i].perms())         # the permutations may still be arriving (chunks)
         engine.mark('inits')
         return prepared
     if layouts is not None:
@@ -125,10 +121,6 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
                 seeds = rng.epoch_seeds(epochs, True)
                 n = len(as_loader(train_dlist[i]).dataset)
                 prepared[i] = (None, (U0, V0), rng.epoch_perms(seeds, n))
-        elif foreign_u0 is not None:
-            U0, _ = rng.mf_init(n_user, n_item, k)
-            foreign_u0[i] = U0
-            rng.epoch_seeds(epochs, True)
         else:
             rng.skip_model(n_user, n_item, k, epochs, True)
     for i, (shard, init, perms) in list(prepared.items()):      # permutations expanded in the background: collect
@@ -141,6 +133,7 @@ def exchange_plan(ids, owner, group_sizes, n_item, k, world):
     """Layout of the path's one collective.  A rank's segment holds, for each shard it owns (in `ids`
     order), that shard's OWN user rows [len(group_index[i]), k] followed by its item table
     [n_item, k]; segments are padded to the longest (all-gather-v as one all_gather_into_tensor).
+    With full user tables (exchange_tables(full_u=True)) pass n_user for every group size.
     -> ({shard: (rank, offset in floats)}, floats per segment)."""
     fill = [0] * world
     where = {}
@@ -151,14 +144,19 @@ def exchange_plan(ids, owner, group_sizes, n_item, k, world):
     return where, max(max(fill), 1)
 
 
-def exchange_tables(models, ids, owner, rank, rows, n_item, k, device, dist):
+def exchange_tables(models, ids, owner, rank, rows, n_item, k, device, dist, full_u=0):
     """After isolated training: ONE all-gather over RCCL/xGMI.  Every rank contributes, per shard it
     owns, the rows of U_i that belong to the shard's own users (sisa.py:55-56 reads nothing else of
     U_i) and V_i (utils.py:140-145 needs every model's item table); payloads are padded to the
     longest segment.  `rows[i]` = device int64 tensor of group_index[i].
-    -> {shard: (U rows of its own users [len(rows[i]), k], V [n_item, k])}, device tensors."""
+    full_u = n_user: the WHOLE pre-merge user table of every shard travels instead of its own rows --
+    what the reference's per-epoch logs (scratch.py:83-86 averages the earlier models as they are) and
+    user_mat{id}.npy need of a foreign shard.  S x n_user x k floats in all: 3.9 MB at ml-1m / 5 shards,
+    2.6 GB at BASELINE.json configs[3] (~30 ms on a ring of 8 over xGMI), against 28 x 20.7 M normals
+    drawn per rank to rebuild them from the init stream (round 3).
+    -> {shard: (U rows of its own users [len(rows[i]), k] | U [n_user, k], V [n_item, k])}, device tensors."""
     world = dist.get_world_size()
-    sizes = [int(rows[i].numel()) for i in ids]
+    sizes = [int(full_u) if full_u else int(rows[i].numel()) for i in ids]
     where, seg = exchange_plan(ids, owner, sizes, n_item, k, world)
     send = torch.zeros(seg, dtype=torch.float32, device=device)
     for pos, i in enumerate(ids):
@@ -166,7 +164,7 @@ def exchange_tables(models, ids, owner, rank, rows, n_item, k, device, dist):
             U, V = models[i]
             o = where[i][1]
             nu = sizes[pos] * k
-            send[o:o + nu] = U.index_select(0, rows[i]).reshape(-1)
+            send[o:o + nu] = (U if full_u else U.index_select(0, rows[i])).reshape(-1)
             send[o + nu:o + nu + n_item * k] = V.reshape(-1)
     recv = torch.empty(world * seg, dtype=torch.float32, device=device)
     if dist.get_backend() == 'nccl':
@@ -202,7 +200,14 @@ class Sisa(Scratch):
         self.model_list = []
 
     def test(self, test_data, verbose, save_dir):
-        rmse, ndcg, hr = baseTest(test_data, self.model_list, nn.MSELoss(reduction='sum'), self.device, verbose)
+        dist = _dist()
+        if dist is not None and self.parallel:
+            # several ranks hold the same merged models: rank 0 tests, the three numbers travel (every rank ran this test in round 3)
+            box = [baseTest(test_data, self.model_list, nn.MSELoss(reduction='sum'), self.device, verbose) if dist.get_rank() == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            rmse, ndcg, hr = box[0]
+        else:
+            rmse, ndcg, hr = baseTest(test_data, self.model_list, nn.MSELoss(reduction='sum'), self.device, verbose)
         log = {'total_rmse': rmse,
                'total_ndcg': ndcg,
                'total_hr': hr}
@@ -215,10 +220,25 @@ class Sisa(Scratch):
         return torch.as_tensor(np.asarray(self.group_index[i], dtype=np.int64))
 
     def _rows_dev(self, i):
-        """group_index[i] as a device int64 tensor; all groups go up together, once per object."""
-        if getattr(self, '_group_rows', None) is None:
-            self._group_rows = engine.upload_many([np.asarray(g, dtype=np.int64) for g in self.group_index], engine._device())
+        """group_index[i] as a device int64 tensor; all groups go up together, once per (group_index object, its group sizes, device):
+        the reference reads self.group_index at every merge (sisa.py:55-56), so a reassigned list or another current device must not
+        find the rows of the old one.  (Groups edited in place at equal length are not detected: call forget_rows().)"""
+        dev = engine._device()
+        key = (id(self.group_index), tuple(len(g) for g in self.group_index), str(dev))
+        if getattr(self, '_group_rows_key', None) != key:
+            self._group_rows = engine.upload_many([np.asarray(g, dtype=np.int64) for g in self.group_index], dev)
+            self._group_rows_key = key
         return self._group_rows[i]
+
+    def forget_rows(self):
+        self._group_rows_key = None
+
+    def _check_closed(self):
+        """The job of the last request is destroyed on a worker (ure_job_destroy waits for the device); a failure there surfaces at the
+        start of the next request or here."""
+        fut, self._closing = getattr(self, '_closing', None), None
+        if fut is not None:
+            fut.result()
 
     def _merge(self, merged, ids):
         """sisa.py:52-58 / 107-113: merged[group_index[i]] = U_i[group_index[i]]."""
@@ -235,6 +255,7 @@ class Sisa(Scratch):
         that epoch) are computed afterwards, so log{id}.npy carries the same series as a
         sequential run."""
         seed_all(self.seed)
+        self._check_closed()
         engine.mark('start')
         # The shards' worker threads (draws, permutation chunks, uploads) run short pieces of Python between native calls; with
         # CPython's default switch interval (5 ms) this thread can wait that long for the GIL every time it comes back from a
@@ -242,8 +263,10 @@ class Sisa(Scratch):
         import sys
         switch = sys.getswitchinterval()
         sys.setswitchinterval(float(os.environ.get('URE_SWITCH_INTERVAL', '2e-4')))
+        from .. import rng
         try:
-            return self._train_parallel_body(ids, train_dlist, test_dlist, test_data, verbose, save_dir, unlearning)
+            with rng.torch_threads():
+                return self._train_parallel_body(ids, train_dlist, test_dlist, test_data, verbose, save_dir, unlearning)
         finally:
             sys.setswitchinterval(switch)
 
@@ -255,10 +278,8 @@ class Sisa(Scratch):
         owner = assign_shards(sizes, world)
         # full pre-merge user tables of other ranks' shards are needed for the reference's per-epoch logs
         # (scratch.py:83-86 averages the earlier models as they are) and for user_mat{id}.npy on rank 0
-        want_full = bool(dist) and (self.epoch_logs or (rank == 0 and len(save_dir) > 0))
-        foreign_u0 = {} if want_full else None
-        prepared = prepare_owned(ids, owner, rank, train_dlist, self.n_user, self.n_item, self.k, self.epochs,
-                                 foreign_u0=foreign_u0)
+        want_full = bool(dist) and (self.epoch_logs or len(save_dir) > 0)          # (the same on every rank: it sizes the collective)
+        prepared = prepare_owned(ids, owner, rank, train_dlist, self.n_user, self.n_item, self.k, self.epochs)
         mine = [i for pos, i in enumerate(ids) if owner[pos] == rank]
         snap_mode = 'compact' if engine.LAZY_ROWS else 'full'
         snap_bytes = engine.TrainJob.snapshot_bytes([prepared[i][0] for i in mine], self.epochs, self.k, snap_mode)
@@ -297,19 +318,16 @@ class Sisa(Scratch):
             # the only exchange of the path (sisa.py:52-58): own user rows + item table of every shard, one all-gather
             dev = engine._device()
             rows = {i: self._rows_dev(i) for i in ids}
-            got = exchange_tables(models, ids, owner, rank, rows, self.n_item, self.k, dev, dist)
-            batch = as_loader(train_dlist[ids[0]]).batch_size
+            got = exchange_tables(models, ids, owner, rank, rows, self.n_item, self.k, dev, dist, full_u=self.n_user if want_full else 0)
             for pos, i in enumerate(ids):
                 if owner[pos] == rank:
                     continue
                 Ur, V = got[i]
-                if want_full:      # rows of other shards' users never train in shard i: closed form of U0 (engine lazy rows)
-                    steps = (sizes[pos] + batch - 1) // batch
-                    a = untouched_scale(self.lr, self.lr_decay, self.epochs, steps, self.lam, self.momentum)
-                    U = foreign_u0[i].to(dev) * float(a)
+                if want_full:      # the owner's whole pre-merge table (rows of other shards' users included: they only decayed there)
+                    U = Ur.clone()
                 else:              # only the shard's own rows are ever read again (merge + final test)
                     U = torch.zeros(self.n_user, self.k, dtype=torch.float32, device=dev)
-                U.index_copy_(0, rows[i], Ur)
+                    U.index_copy_(0, rows[i], Ur)
                 models[i] = (U, V.clone())
         out = {i: MF.from_tables(*models[i]) for i in ids}
 
@@ -364,13 +382,21 @@ class Sisa(Scratch):
             # the job's device memory is returned by a worker: ure_job_destroy waits for the device and takes 0.2-0.4 ms, and
             # nothing below needs it (the models are copies, the logs are on the host)
             from .. import rng
-            rng.worker_pool().submit(job.close)
+            self._closing = rng.worker_pool().submit(job.close)
         engine.mark('job_closed')
         if dist:
             gathered = [None] * world
             dist.all_gather_object(gathered, logs)
             logs = {k: v for part in gathered for k, v in part.items()}
         for i in ids:
+            if rank == 0 and verbose in (1, 2):
+                # the lines the sequential path prints while it trains (scratch.py:99-118), shard after shard in the reference's order
+                from .scratch import print_epoch
+                print('Using device:', self.device)
+                e = logs[i]
+                for t in range(self.epochs):
+                    print_epoch(verbose, t, self.epochs, e['train_loss'][t], (e['test_rmse'][t], e['test_ndcg'][t], e['test_hr'][t]),
+                                (e['total_rmse'][t], e['total_ndcg'][t], e['total_hr'][t]), True, '00:00:00')
             for key, vals in logs[i].items():
                 self.log[key] += vals
             self.log['time'] += ['00:00:00'] * self.epochs

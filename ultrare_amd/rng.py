@@ -63,6 +63,31 @@ def limit_torch_threads():
     return torch.get_num_threads()
 
 
+_THREADS_LOCK = threading.Lock()
+_THREADS_DEPTH = [0, None]        # nesting depth of torch_threads(), torch's thread count before the outermost one
+
+
+class torch_threads:
+    """Context of one request (Scratch.train, Sisa.learn / unlearn): torch's intra-op pool capped as limit_torch_threads() describes,
+    and set back to what the host program had when the outermost request ends -- importing this package changes nothing
+    process-global.  Nested requests (Sisa -> Scratch) share one cap."""
+
+    def __enter__(self):
+        with _THREADS_LOCK:
+            if _THREADS_DEPTH[0] == 0:
+                _THREADS_DEPTH[1] = torch.get_num_threads()
+                limit_torch_threads()
+            _THREADS_DEPTH[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        with _THREADS_LOCK:
+            _THREADS_DEPTH[0] -= 1
+            if _THREADS_DEPTH[0] == 0 and _THREADS_DEPTH[1] is not None and torch.get_num_threads() != _THREADS_DEPTH[1]:
+                torch.set_num_threads(_THREADS_DEPTH[1])
+        return False
+
+
 def perm_threads():
     """Host threads of the permutation expander per SISA call: URE_PERM_THREADS, else every CPU of the rank up to 64
     (250 Fisher-Yates permutations of 0.5 ms each are half of a 5-shard, 50-epoch call's wall time on 16 threads)."""
@@ -81,9 +106,13 @@ def fill_draws(n):
     return n + (16 if n % 16 else 0)
 
 
+STATS = {'normals': 0, 'skipped_draws': 0}      # host work of this process: N(0, 1) values computed / generator outputs skipped
+
+
 def advance_state(state, n_draws):
     """A copy of a torch CPU generator state moved past n_draws 32-bit outputs (ure_host_mt_advance)."""
     from . import _native as nv
+    STATS['skipped_draws'] += int(n_draws)
     out = state.clone()
     nv.check(nv.lib().ure_host_mt_advance(out.data_ptr(), out.numel(), int(n_draws)), 'ure_host_mt_advance')
     return out
@@ -114,6 +143,7 @@ def mf_init(n_user, n_item, k, generator=None):
         g.set_state(advance_state(g.get_state(), draws[0]))
     U0 = torch.empty(n_user, k).normal_(0, 1, generator=g)
     V0 = torch.empty(n_item, k).normal_(0, 1, generator=g)
+    STATS['normals'] += (n_user + n_item) * k * (1 if draws is not None else 2)
     return U0, V0
 
 
