@@ -178,14 +178,14 @@ class Dist:
         return int(t.item())
 
 
-def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_steps=0, keep_job=False):
+def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_steps=0, keep_job=False, data=None):
     """Make the workload resident, run W warm-up and K timed bench steps of the rank's shards, return the
     measurements.  split: ONE job (same data on every rank), shards placed by assign_shards; otherwise
     every rank generates and trains its own job."""
     from ultrare_amd import engine, rng, synth
     from ultrare_amd.method.sisa import assign_shards
     spec = synth.ML1M if workload == 'ml1m' else synth.ML25M
-    data = synth.make_dataset(**spec, seed=synth.SEED + (0 if split else D.rank))
+    data = data or synth.make_dataset(**spec, seed=synth.SEED + (0 if split else D.rank))
     shard_of, groups = synth.uniform_shards(spec['n_user'], n_shards)
     parts = synth.split_shards(data['train'], shard_of, n_shards)
     all_sizes = [len(p[0]) for p in parts]
@@ -315,11 +315,28 @@ def roofline_of(a, leg, d, batch):
             'alg_gbs_16B_dense': round(alg16 / (avg_ms * 1e-3) / 1e9, 1),
             'avg_launch_us': round(avg_ms * 1e3, 2), 'avg_launch_from': 'event pair per launch' if job.touch else 'events around the timed region / launches',
             'launches_timed': n_launch,
-            'per_launch_event_us': round(step_ms / max(n_step, 1) * 1e3, 2),
+            # (the pass with an event pair around EVERY launch reads higher than region / launches: the two event records a launch is
+            # bracketed with take ~1.5-2 us of their own on the stream; it is what splits step launches from epoch-start launches)
+            'event_pair_pass_us': round(step_ms / max(n_step, 1) * 1e3, 2),
+            **({} if job.touch else latency_floor(job)),
             'dense_rows_streamed_per_shard': rows_streamed if len(rows_streamed) <= 8 else {'shards': len(rows_streamed), 'mean': round(float(np.mean(rows_streamed)), 1)},
             'lazy_rows': bool(job.lazy_rows), 'touch_mode': (3 if getattr(job, 'index', False) else 2 if job.ahead else 1) if job.touch else 0, 'source_hash': here,
             'note': 'frac = algorithmic bytes (SURVEY 8d) / time / 8 TB/s; fabric_frac = PMC bytes that crossed the L2 / time / 8 TB/s '
                     '(ml-1m tables are cache resident, so fabric_frac is the HBM-side utilisation)'}
+
+
+def latency_floor(job):
+    """The cache-resident step kernel (ml-1m: ~45 MB working set) is bound by its chain of dependent memory levels, not by HBM bytes:
+    its figure of merit is the distance to a latency floor, built from MI355X_MICROARCH.md's idle-chip constants -- a dependent kernel
+    boundary (1.45 us), the grid's dispatch ramp (1,024 workgroups start within 0.34-0.69 us), and the kernel's dependent levels at the
+    Infinity-Cache hit latency (227 ns each: shard descriptor -> work unit -> own row + slots -> gathered rows -> the row's store).
+    Under load each level takes several times its idle latency (tools/exp_timeline.py: ~10 us per workgroup with all ~1,300 resident):
+    that, not bandwidth, is the distance between `avg_launch_us` and the floor."""
+    boundary, ramp, level, levels = 1.45, 0.5, 0.227, 5
+    floor = boundary + ramp + levels * level
+    return {'latency_floor_us': round(floor, 2),
+            'latency_floor_terms': {'kernel_boundary_us': boundary, 'dispatch_ramp_us': ramp, 'dependent_levels': levels, 'level_latency_us_idle_chip': level,
+                                    'source': 'MI355X_MICROARCH.md (price list: boundary; dispatch; cycle constants: Infinity Cache hit latency)'}}
 
 
 def cpu_baseline_of(a, leg, d, batch):
@@ -363,11 +380,8 @@ def cpu_baseline_of(a, leg, d, batch):
 def unlearn_leg(a, data, shards, d):
     """Second half of the metric: Sisa.learn, then Sisa.unlearn after a 2 % random user deletion, 50
     epochs, through the operator surface; wall clock with per-epoch evaluations, row merge, final test."""
-    import importlib.util
-    sp = importlib.util.spec_from_file_location('e2e_sisa', os.path.join(ROOT, 'tools', 'e2e_sisa.py'))
-    e2e = importlib.util.module_from_spec(sp)
-    sp.loader.exec_module(e2e)
-    r = e2e.measure(shards, d, 50, 1, 2.0, data=data, reps=6)
+    from ultrare_amd import measure as e2e
+    r = e2e.sisa_request(shards, d, 50, 1, 2.0, data=data, reps=6)
     out = {'learn_wall_s': r['learn_s'], 'unlearn_wall_s': r['unlearn_s'], 'learn_wall_s_all': r['learn_s_all'], 'unlearn_wall_s_all': r['unlearn_s_all'],
            'timed': r['timed'], 'epochs': 50,
            'deleted_users': r['deleted_users'], 'retrained_shards': r['retrained_shards'],
@@ -376,7 +390,8 @@ def unlearn_leg(a, data, shards, d):
            'includes': 'a NEW request on a warm allocator: its own deletion set and freshly made in-memory loaders, so the timed call '
                        'builds the HBM layouts of the shards it trains and uploads them (layouts_built_in_timed_call), draws the host RNG '
                        'streams, runs 50 epochs of all retrained shards side by side with the per-epoch shard / total evaluations, merges '
-                       'the rows and runs the final test; the test sets stay resident (a deletion does not change them)',
+                       'the rows, runs the final test and destroys the job (its teardown is joined before the clock stops); the test sets '
+                       'stay resident (a deletion does not change them)',
            'final_test': {'learn': r['log0'], 'unlearn': r['unlearn_log0']}, 'nan_shards': r['nan_shards']}
     return out, e2e
 
@@ -387,15 +402,35 @@ def hbm_leg(a, D):
     mf_touch_step_kernel from an event pair per launch.  -> the `roofline_hbm` object."""
     import argparse
     b = argparse.Namespace(**vars(a))
+    from ultrare_amd import synth
     b.workload, b.shards, b.d, b.roofline_steps = 'ml25m', 32, 128, 2
     t0 = time.perf_counter()
-    leg = train_leg(D, 'ml25m', 32, 128, a.batch, 3, 1, False, b.roofline_steps + 2, keep_job=True)
-    job = leg['job']
-    r = roofline_of(b, leg, 128, a.batch)
-    # share of the window-start preparation (two launches per epoch start at 24-27 steps per epoch) in device time, from a pass
-    # with an event pair around every launch that covers whole epochs
-    step_ms, n_step, prep_ms, n_prep = job.run_profiled(2 * leg['tps'])
-    job.close()
+    data = synth.make_dataset(**synth.ML25M, seed=synth.SEED)
+
+    def one(d):
+        b.d = d
+        leg = train_leg(D, 'ml25m', 32, d, a.batch, 3, 1, False, b.roofline_steps + 2, keep_job=True, data=data)
+        job = leg['job']
+        r = roofline_of(b, leg, d, a.batch)
+        # share of the epoch-start preparation (two launches per epoch start at 24-27 steps per epoch) in device time, from a pass
+        # with an event pair around every launch that covers whole epochs
+        step_ms, n_step, prep_ms, n_prep = job.run_profiled(2 * leg['tps'])
+        # does the reference's arithmetic stay finite on this set?  (d = 128: N(0, 1) rows predict +-11 at the start and every shard
+        # diverges from epoch 2 on, in the oracle as well -- DESIGN.md 2; the kernel has no data-dependent exit, so its time stands)
+        sse = job.epoch_sse_all()
+        done = [min(job.done, job.shard_steps[s_]) // job.steps_per_epoch(s_) for s_ in range(len(job.shards))]
+        bad = [int(np.flatnonzero(~np.isfinite(sse[s_][:done[s_]]))[0]) for s_ in range(len(done)) if not np.isfinite(sse[s_][:done[s_]]).all()]
+        r.update({'finite_tables': not bad, 'shards_diverged': len(bad), 'first_nonfinite_epoch': (min(bad) if bad else None), 'epochs_run': int(max(done))})
+        job.close()
+        return leg, r, step_ms, n_step, prep_ms, n_prep
+    leg, r, step_ms, n_step, prep_ms, n_prep = one(128)
+    # the same shape at k = 16, where the tables stay finite (the width a `--group 32` run of the reference would train: config.py:19)
+    leg16, r16, s16, ns16, p16, np16 = one(16)
+    r['k16'] = {'workload': 'the same 32 shards at k = 16 (finite tables)', 'value': round(leg16['value'], 1), 'unit_value': 'interactions/s',
+                'avg_launch_us': r16['avg_launch_us'], 'achieved': r16['achieved'], 'frac': r16['frac'], 'alg_bytes_per_launch': r16['alg_bytes_per_launch'],
+                'touch_mode': r16['touch_mode'], 'finite_tables': r16['finite_tables'], 'epochs_run': r16['epochs_run'],
+                'prep_share_of_device_time': round(p16 / max(p16 + s16, 1e-9), 4)}
+    r['full_mf'] = fullmf_leg(a, D, data)
     r.update({'workload': 'BASELINE.json configs[3] shape on one GPU: synthetic 162000x60000, 22500000 train rows, 32-shard SISA '
                           '(uniform grouping), d=128, batch=30000, all shards side by side, touch mode',
               'value': round(leg['value'], 1), 'unit_value': 'interactions/s', 'steps': 3, 'warmup': 1,
@@ -404,6 +439,39 @@ def hbm_leg(a, D):
               'prep_ms_per_epoch_start': round(prep_ms / max(n_prep // 2, 1), 4),
               'leg_wall_s': round(time.perf_counter() - t0, 1)})
     return r
+
+
+def fullmf_leg(a, D, data):
+    """Full MF at the 25 M shape (config.py:182-188 runFull, the stage whose user_mat0.npy every `--group N` run clusters): ONE shard of
+    22.5 M rows, d = 128, 750 optimizer steps per epoch -- touch_mode 3, the epoch's slots sorted by step (csrc/mf_index.h).  One warm-up
+    epoch, then one epoch with an event pair per launch: the step launch (with the combine launch of split rows), the epoch start."""
+    from ultrare_amd import engine, rng
+    u, i, r = data['train']
+    spec_u, spec_i, n = data['n_user'], data['n_item'], len(u)
+    t0 = time.perf_counter()
+    torch.manual_seed(42)
+    init = tuple(t * 0.3 for t in rng.mf_init(spec_u, spec_i, 128))          # (0.3: predictions of +-1 at the start, the tables stay finite)
+    E = 3
+    tags = rng.epoch_tags(rng.epoch_seeds(E, True), n, a.batch, threads=min(16, os.cpu_count() or 1))
+    sh = engine.ShardData(u, i, (r / 5.0).astype(np.float32), spec_u, spec_i)
+    job = engine.TrainJob([sh], [init], [tags], 128, a.batch, E, 1e-3, 0.1, 0.9, 0.95, final_only=True)
+    steps = job.steps_per_epoch(0)
+    job.run(steps)
+    torch.cuda.synchronize()
+    step_ms, n_step, prep_ms, n_prep = job.run_profiled(steps)
+    rows = job.touch_rows_per_step()[0]
+    alg = n / steps * (16 + 16 * 128) + 20 * rows * 128
+    us = step_ms / n_step * 1e3
+    job.run()
+    finite = bool(np.isfinite(job.epoch_sse(0)).all())
+    job.close()
+    return {'workload': f'full MF, synthetic {spec_u}x{spec_i}, {n} train rows, ONE shard, d=128, batch={a.batch}: {steps} optimizer steps per epoch',
+            'kernel': 'mf_index_step_kernel' if job.index else 'mf_touch_step_kernel', 'touch_mode': 3 if job.index else 1,
+            'avg_launch_us': round(us, 2), 'avg_launch_from': 'event pair per launch (step kernel + the combine launch of split rows)',
+            'alg_bytes_per_launch': round(alg), 'achieved': round(alg / us / 1e3, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(alg / us / 1e3 / HBM_PEAK_GBS, 4),
+            'rows_trained_per_step': round(rows, 1), 'epoch_start_ms': round(prep_ms, 3), 'epoch_start_share_of_device_time': round(prep_ms / (prep_ms + step_ms), 4),
+            'value': round(n / ((step_ms + prep_ms) * 1e-3), 1), 'unit_value': 'interactions/s (device time of one epoch incl. its start)',
+            'finite_tables': finite, 'leg_wall_s': round(time.perf_counter() - t0, 1)}
 
 
 def exchange_leg(D, leg, d, reps=5):
@@ -554,7 +622,7 @@ def main():
             leg['job'] = leg['shards'] = job = None
             un, e2e = unlearn_leg(a, leg['data'], a.shards, a.d)
             # BASELINE.json configs[4]: 16 shards (d = the reference's default k = 16), 2 % random deletion
-            r16 = e2e.measure(16, 16, 50, 1, 2.0, data=leg['data'], reps=4)
+            r16 = e2e.sisa_request(16, 16, 50, 1, 2.0, data=leg['data'], reps=4)
             un['config4_16_shards_k16'] = {'learn_wall_s': r16['learn_s'], 'unlearn_wall_s': r16['unlearn_s'],
                                            'learn_wall_s_all': r16['learn_s_all'], 'unlearn_wall_s_all': r16['unlearn_s_all'],
                                            'retrained_shards': r16['retrained_shards'], 'deleted_users': r16['deleted_users'],
@@ -564,12 +632,15 @@ def main():
                                            # MSELoss(sum), lr 1e-3, users with ~2,800 ratings)
                                            'nan_shards': r16['nan_shards']}
             out['unlearn'] = un
+            cb = out.get('cpu_baseline')
+            if cb and cb.get('end_to_end_value') and un.get('unlearn_interactions'):
+                # both halves of the metric get a stated CPU figure: the unlearn request's interactions at the CPU path's end-to-end rate
+                cb['unlearn_wall_s_extrapolated'] = round(un['unlearn_interactions'] / cb['end_to_end_value'], 1)
+                cb['unlearn_wall_s_extrapolated_from'] = (f"{un['unlearn_interactions']} interactions of the unlearn request (the retrained shards' rows x 50 epochs) "
+                                                          f"/ end_to_end_value; the reference retrains shard after shard on the CPU (sisa.py:66-118)")
             if not a.no_cold and time.perf_counter() - t_start < a.extras_budget:
                 # the whole request as the reference's CLI runs it (config.py:139-172), nothing resident beforehand
-                sp = importlib.util.spec_from_file_location('e2e_cold', os.path.join(ROOT, 'tools', 'e2e_cold.py'))
-                cold = importlib.util.module_from_spec(sp)
-                sp.loader.exec_module(cold)
-                c = cold.measure(a.shards, a.d, 50, data=leg['data'])
+                c = e2e.cold_request(a.shards, a.d, 50, data=leg['data'])
                 un['cold_request_s'] = c['unlearn']['total_s']
                 un['cold_request'] = {'unlearn': c['unlearn'], 'learn': c['learn'], 'retrained_shards': c['retrained'],
                                       'deleted_users': c['deleted_users'], 'flow': c['flow'], 'final_test': c['unlearn_log0']}

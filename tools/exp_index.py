@@ -34,6 +34,7 @@ def main():
     a = ap.parse_args()
     from ultrare_amd import engine, rng
     part, spec = dataset()
+    part = (part[0], part[1], (part[2] / 5.0).astype(np.float32))
     n = len(part[0])
     torch.manual_seed(42)
     init = rng.mf_init(spec['n_user'], spec['n_item'], a.d)

@@ -1,0 +1,148 @@
+"""What bench.py times through the reference's operator surface (the second half of BASELINE.json's metric): a SISA learn +
+unlearn request on resident data (sisa_request) and the same from CSV files on disk (cold_request).  Lives in the package so that
+the driver contract (bench.py) does not hang on files under tools/ (VERDICT r3); tools/e2e_sisa.py and tools/e2e_cold.py are
+command-line wrappers."""
+import argparse
+import copy
+import os
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+
+def sisa_request(shards=5, k=32, epochs=50, parallel=1, delper=2.0, data=None, reps=3, workload='ml1m'):
+    """Wall time of Sisa.learn and Sisa.unlearn (per-epoch evals, merge and final test included) on the synthetic set: the
+    MEDIAN of the repetitions after the first (which warms the allocator and the pools), every sample listed beside it
+    (`learn_s_all`, `unlearn_s_all`: a single timing on a shared host is off by up to 50 %).  Every repetition is a NEW request: its own deletion set (a different 2 %
+    of the users) and freshly made train loaders, so the HBM layouts of the shards it trains are built and uploaded
+    INSIDE the timed calls (`layouts_built` counts them); what the earlier repetitions leave behind is a warm device
+    allocator, the pinned permutation pool and the test sets (a deletion does not change them: config.py:139-172 reads
+    the test files without the deletion list)."""
+    a = argparse.Namespace(shards=shards, k=k, epochs=epochs, parallel=parallel, delper=delper)
+    from ultrare_amd import engine, synth
+    from ultrare_amd.method.sisa import Sisa
+    from ultrare_amd.read import RatingData, loadData
+
+    data = data or synth.make_dataset(**(synth.ML1M if workload == 'ml1m' else synth.ML25M))
+    n_user, n_item = data['n_user'], data['n_item']
+    shard_of, groups = synth.uniform_shards(n_user, a.shards)
+
+    class P:
+        k, lam, seed, batch, lr, lr_decay, momentum, epochs = a.k, 0.1, 42, 30000, 0.001, 0.95, 0.9, a.epochs
+        parallel = bool(a.parallel)
+    P.n_user, P.n_item = n_user, n_item
+
+    def loaders(triple, shuffle):
+        return [loadData(RatingData(np.vstack(p)), P.batch, 24, shuffle) for p in synth.split_shards(triple, shard_of, a.shards)]
+
+    ted = loaders(data['test'], False)
+    tot_arr = [np.concatenate([p[c] for p in synth.split_shards(data['test'], shard_of, a.shards)]) for c in range(3)]
+    tot = loadData(RatingData(np.vstack(tot_arr)), P.batch, 24, False)
+    torch.cuda.synchronize()
+
+    out = {'shards': a.shards, 'k': a.k, 'epochs': a.epochs, 'parallel': bool(a.parallel),
+           'train_rows': int(len(data['train'][0]))}
+    t_learns, t_unlearns = [], []
+    for rep in range(reps):       # earlier repetitions warm the allocator and the pinned pool; no layout survives them
+        del_user = np.random.RandomState(1 + rep).choice(n_user, int(a.delper / 100 * n_user), replace=False)
+        keep = ~np.isin(data['train'][0], del_user)
+        trd = loaders(data['train'], True)
+        trd_del = loaders(tuple(x[keep] for x in data['train']), True)
+        sisa = Sisa(P, 'mf', a.shards, groups)
+        torch.manual_seed(42)
+        built0 = engine.ShardData.built
+        t0 = time.perf_counter()
+        ml = sisa.learn(trd, ted, tot, 0, '')
+        torch.cuda.synchronize()
+        sisa._check_closed()                      # (the job's teardown -- ure_job_destroy on a worker -- belongs to the request)
+        t_learn = time.perf_counter() - t0
+        built_learn = engine.ShardData.built - built0
+        s2 = Sisa(P, 'mf', a.shards, groups)
+        snap = [copy.deepcopy(m) for m in ml]
+        torch.manual_seed(42)
+        built0 = engine.ShardData.built
+        t0 = time.perf_counter()
+        s2.unlearn(snap, trd_del, ted, tot, del_user.tolist(), 0, '')
+        torch.cuda.synchronize()
+        s2._check_closed()
+        t_unlearn = time.perf_counter() - t0
+        built_unlearn = engine.ShardData.built - built0
+        if rep > 0 or reps == 1:
+            t_learns.append(t_learn)
+            t_unlearns.append(t_unlearn)
+    t_learn, t_unlearn = float(np.median(t_learns)), float(np.median(t_unlearns))
+    n_learn = len(data['train'][0]) * a.epochs
+    n_un = int(sum(len(trd_del[i].dataset) for i in s2.retrained)) * a.epochs        # interactions the unlearn request trained on
+    nan_shards = int(sum(1 for m in s2.model_list if not bool(torch.isfinite(m.item_mat.weight).all())))
+    series = {k: np.asarray(v, dtype=np.float64) for k, v in sisa.log.items() if k != 'time'}
+    epoch_logs = {'entries_per_series': int(len(series['total_rmse'])), 'finite_fraction': {k: round(float(np.isfinite(v).mean()), 4) for k, v in series.items()},
+                  'first_epoch': {k: float(v[0]) for k, v in series.items() if len(v)}, 'last_epoch': {k: float(v[-1]) for k, v in series.items() if len(v)}}
+    out.update(learn_s=round(t_learn, 4), unlearn_s=round(t_unlearn, 4), learn_s_all=[round(t, 4) for t in t_learns], unlearn_s_all=[round(t, 4) for t in t_unlearns],
+               timed='median of the repetitions after the first; every one a new request', retrained_shards=len(s2.retrained), deleted_users=int(len(del_user)),
+               deletion_set=f'RandomState({reps}).choice: a different 2 % in every repetition',
+               layouts_built={'learn': built_learn, 'unlearn': built_unlearn},
+               learn_interactions_per_s=round(n_learn / t_learn, 1), log0=sisa.log0, unlearn_log0=s2.log0,
+               unlearn_interactions=n_un, nan_shards=nan_shards, epoch_logs_learn=epoch_logs)
+    return out
+
+
+def cold_request(shards=5, k=32, epochs=50, data=None):
+    """-> dict: phases of a cold learn request and of a cold unlearn request (a fresh 2 % deletion set), after one
+    warm-up request that loads the library and warms the device allocator and the pinned pool.  Nothing of a request's
+    data survives into the next: the CSV files are read and partitioned again, loaders, HBM layouts and test sets are rebuilt."""
+    import shutil
+    from ultrare_amd import engine, synth
+    from ultrare_amd.method.sisa import Sisa
+    from ultrare_amd.read import RatingData, loadData, readRating
+
+    data = data or synth.make_dataset(**synth.ML1M)
+    tmp = tempfile.mkdtemp()
+    tr_csv, te_csv = os.path.join(tmp, 'train.csv'), os.path.join(tmp, 'test.csv')
+    synth.write_csv(tr_csv, data['train'])
+    synth.write_csv(te_csv, data['test'])
+    n_user, n_item = data['n_user'], data['n_item']
+    del_user = np.random.RandomState(1).choice(n_user, int(0.02 * n_user), replace=False).tolist()
+
+    class P:
+        lam, seed, batch, lr, lr_decay, momentum, parallel = 0.1, 42, 30000, 0.001, 0.95, 0.9, True
+    P.k, P.epochs, P.n_user, P.n_item = k, epochs, n_user, n_item
+
+    def request(dels, models):
+        t = {}
+        built0 = engine.ShardData.built
+        t0 = time.perf_counter()
+        tr, idx = readRating(tr_csv, n_user, 5, dels, [], shards, [])
+        te, _ = readRating(te_csv, n_user, 5, [], [], shards, idx)
+        t['read_partition_s'] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        trd = [loadData(RatingData(x), P.batch, 24) for x in tr]
+        ted = [loadData(RatingData(x), P.batch, 24, False) for x in te]
+        tot = loadData(RatingData(np.hstack(te)), P.batch, 24, False)
+        t['loaders_s'] = time.perf_counter() - t0
+        s = Sisa(P, 'mf', shards, idx)
+        torch.manual_seed(42)
+        t0 = time.perf_counter()
+        if models is None:
+            ml = s.learn(trd, ted, tot, 0, '')
+        else:
+            ml = s.unlearn(models, trd, ted, tot, dels, 0, '')
+        torch.cuda.synchronize()
+        s._check_closed()
+        t['train_merge_test_s'] = time.perf_counter() - t0
+        t['total_s'] = sum(t.values())
+        t = {k: round(v, 4) for k, v in t.items()}
+        t['layouts_built'] = engine.ShardData.built - built0
+        return ml, s, t
+
+    try:
+        request([], None)                                   # warm-up: library load, allocator, pinned pool
+        ml, s, t_learn = request([], None)
+        ml2, s2, t_un = request(del_user, [copy.deepcopy(m) for m in ml])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {'shards': shards, 'k': k, 'epochs': epochs, 'learn': t_learn, 'unlearn': t_un, 'retrained': len(s2.retrained),
+            'deleted_users': len(del_user), 'log0': s.log0, 'unlearn_log0': s2.log0,
+            'flow': 'config.py:139-172: CSV files on disk -> readRating (partition with the deletion set) -> loaders -> HBM layouts '
+                    '(uploaded over PCIe) -> Sisa.learn / unlearn (50 epochs, per-epoch logs) -> merge -> final test'}

@@ -104,6 +104,16 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
         finally:
             gate.set()
         engine.mark('layouts')
+        if os.environ.get('URE_REDRAW_FOREIGN_U0', '0') == '1':
+            # measurement aid (tools/multirank_timeline.py, profiles/r04): what round 3 did here -- the full U0 of every shard another
+            # rank owns, drawn on this rank from the shard's start state and then not needed any more -- so that its cost can be
+            # timed beside the exchange that replaced it.  The values are discarded; results do not change.
+            for pos, i in enumerate(ids):
+                if owner[pos] != rank:
+                    g = torch.Generator()
+                    g.set_state(starts[pos])
+                    rng.mf_init(n_user, n_item, k, generator=g)
+            engine.mark('foreign U0 redrawn (round-3 behaviour, URE_REDRAW_FOREIGN_U0=1)')
         for pos, i in enumerate(ids):
             if i not in futures:
                 continue
