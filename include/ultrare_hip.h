@@ -277,13 +277,14 @@ int ure_score(const float *const *U_tables, const float *const *V_tables, int n_
  * >= 4/5), ndcg[t] = the reference's positional NDCG@10 (utils.py:190-210).
  * `log2_tab` [10] (device, float64) = log2(2..10) followed by the ideal DCG computeDCG(ones(10)),
  * both computed by the host with numpy so that every division matches the reference bit for bit. */
-/* Users [0, n_wide) get one wavefront each (segments of any length); users [n_wide, n_users) MUST have at most 16
- * entries and share wavefronts four by four (n_wide = n_users: every user a wavefront).  top_rating (optional, device
+/* Users [0, n_wide) get one wavefront each (segments of any length); users [n_wide, n_wide + n_half) MUST have at most 32
+ * entries and share wavefronts two by two (ABI 6); the others MUST have at most 16 and share them four by four
+ * (n_wide = n_users: every user a wavefront).  top_rating (optional, device
  * [n_users][10]): the top-10 positions of the RATINGS, which do not depend on the model -- ure_eval_rank_ratings
  * computes them once per test set; NULL = ranked inside the call.  With top_rating the call is two launches (rank, then
  * metrics by one thread per user); between them `hits` / `ndcg` hold the packed positions of the ranking.          */
 int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const float *rating,
-                   const double *log2_tab, int32_t *hits, double *ndcg, const int32_t *top_rating, int32_t n_wide, void *stream);
+                   const double *log2_tab, int32_t *hits, double *ndcg, const int32_t *top_rating, int32_t n_wide, int32_t n_half, void *stream);
 int ure_eval_rank_ratings(const int32_t *off, int32_t n_users, const float *rating, int32_t *top_rating, void *stream);
 
 /* utils.py:163,183-184: out3 (device, 3 doubles) = { sqrt(sum(sse[0..URE_SCORE_PARTIALS)) / n_rows), mean(ndcg), mean(hits / 10) }
@@ -303,7 +304,7 @@ int ure_eval_series(const float *const *U_fixed, const float *const *V_fixed, in
                     const float *V_series, int64_t stride_u, int64_t stride_v, int n_series, const int32_t *uid, const int32_t *iid,
                     const float *rating, int64_t n, int d, const int32_t *off, int32_t n_users, const double *log2_tab, float *base,
                     float *pred, double *sse, int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide,
-                    void *stream);
+                    int32_t n_half, void *stream);
 
 /* The same series on COMPACT end-of-epoch snapshots (struct ure_shard: snap): member e's own model is
  * row r -> row_slot[r] >= 0 ? snap[e * stride + row_slot[r] * d ..] : snap_a[e] * (U0 | V0)[r], with row ids
@@ -314,7 +315,7 @@ int ure_eval_series_compact(const float *const *U_fixed, const float *const *V_f
                             const int32_t *row_slot, const float *U0, const float *V0, const float *snap_a, int32_t n_user_rows,
                             int n_series, const int32_t *uid, const int32_t *iid, const float *rating, int64_t n, int d,
                             const int32_t *off, int32_t n_users, const double *log2_tab, float *base, float *pred, double *sse,
-                            int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide, void *stream);
+                            int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide, int32_t n_half, void *stream);
 
 /* The same series in two halves, so that the first can run beside training.  ure_score_own_compact: own[e][j] = the score of
  * pair j under the shard's own model after epoch e alone, for n_series consecutive epochs whose compact snapshots exist (snap,
@@ -326,7 +327,7 @@ int ure_score_own_compact(const float *snap, int64_t stride, const int32_t *row_
 int ure_eval_series_own(const float *const *U_fixed, const float *const *V_fixed, int n_fixed, const float *own, int n_series, const int32_t *uid,
                         const int32_t *iid, const float *rating, int64_t n, int d, const int32_t *off, int32_t n_users, const double *log2_tab,
                         float *base, float *pred, double *sse, int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide,
-                        void *stream);
+                        int32_t n_half, void *stream);
 
 /* sisa.py:55-56,110-111: dst[rows[t]][:] = src[rows[t]][:]. */
 int ure_merge_rows(float *dst, const float *src, const int64_t *rows, int64_t n_rows, int d, void *stream);

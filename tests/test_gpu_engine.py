@@ -427,7 +427,7 @@ def test_two_launch_ranking_handles_ties_nans_and_every_segment_class():
     one-launch kernel (no cached ranking) and the means against the oracle."""
     from ultrare_amd import engine, _native as nv
     rs = np.random.RandomState(11)
-    lengths = [1, 3, 10, 16, 17, 40, 64, 65, 128, 300, 512, 513, 700] * 3 + list(rs.randint(1, 90, 400))
+    lengths = [1, 3, 10, 16, 17, 18, 31, 32, 33, 40, 64, 65, 128, 300, 512, 513, 700] * 3 + list(rs.randint(1, 90, 400))
     uid = np.repeat(rs.permutation(len(lengths)), lengths).astype(np.int32)
     uid = uid[rs.permutation(len(uid))]                         # interleaved: first-appearance order is not sorted order
     n = len(uid)
@@ -443,7 +443,7 @@ def test_two_launch_ranking_handles_ties_nans_and_every_segment_class():
             ev.hits.fill_(-7)
             ev.ndcg.fill_(-7.0)
             nv.check(L.ure_eval_users(nv.ptr(ev.off), ev.n_users, nv.ptr(ev.pred), nv.ptr(ev.rating), nv.ptr(ev.log2), nv.ptr(ev.hits), nv.ptr(ev.ndcg),
-                                      nv.ptr(ev.top_rating) if cached else None, ev.n_wide, st), 'ure_eval_users')
+                                      nv.ptr(ev.top_rating) if cached else None, ev.n_wide, ev.n_half, st), 'ure_eval_users')
             out[cached] = (ev.hits.cpu().numpy().copy(), ev.ndcg.cpu().numpy().copy())
         assert np.array_equal(out[True][0], out[False][0]), name
         assert np.array_equal(out[True][1], out[False][1]), name          # the same arithmetic in the same order: bit for bit

@@ -18,7 +18,7 @@ def run(cnt, users, reps=20):
     es.pred.copy_(torch.from_numpy(rng.standard_normal(len(uid)).astype(np.float32)))
     L, st = nv.lib(), nv.stream_handle()
     call = lambda: nv.check(L.ure_eval_users(nv.ptr(es.off), es.n_users, nv.ptr(es.pred), nv.ptr(es.rating), nv.ptr(es.log2), nv.ptr(es.hits),
-                                             nv.ptr(es.ndcg), nv.ptr(es.top_rating), es.n_wide, st), 'ure_eval_users')
+                                             nv.ptr(es.ndcg), nv.ptr(es.top_rating), es.n_wide, es.n_half, st), 'ure_eval_users')
     for _ in range(3):
         call()
     torch.cuda.synchronize()
@@ -28,7 +28,7 @@ def run(cnt, users, reps=20):
         call()
     b.record()
     torch.cuda.synchronize()
-    waves = es.n_wide + (es.n_users - es.n_wide + 3) // 4
+    waves = es.n_wide + (es.n_half + 1) // 2 + (es.n_users - es.n_wide - es.n_half + 3) // 4
     us = a.elapsed_time(b) * 1e3 / reps
     return dict(cnt=cnt, users=users, waves=waves, us_per_call=round(us, 2), ns_per_wave_x_1024=round(us * 1e3 / waves * 1024, 1))
 

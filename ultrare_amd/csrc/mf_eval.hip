@@ -632,6 +632,31 @@ __device__ __forceinline__ unsigned row_sum_u32(unsigned v)
     return v;
 }
 
+// ---- users of 17 .. 32 entries: two per wavefront (a half wave each), round 4.  Lane s of a half holds entry s; its rank is counted
+// over its own 16-lane row by DPP rotations and over the half's other row through one cross-row move followed by the same rotations
+// (a wavefront each -- `cnt` scalar broadcasts for one user -- was what such users cost before: a fifth of a 10 % hold-out of ml-1m).
+template <int N>
+__device__ __forceinline__ void half_other_steps_strict(const int ovi, const float val, int &rank)
+{
+    const int r = N == 0 ? ovi : __builtin_amdgcn_update_dpp(0, ovi, 0x120 + (N == 0 ? 1 : N), 0xF, 0xF, false);
+    rank += __builtin_bit_cast(float, r) > val ? 1 : 0;
+    if constexpr (N < 15) half_other_steps_strict<N + 1>(ovi, val, rank);
+}
+template <int N>
+__device__ __forceinline__ void half_other_steps(const int ovi, const int os, const int cnt, const float val, const int s, int &rank)
+{
+    const int rv = N == 0 ? ovi : __builtin_amdgcn_update_dpp(0, ovi, 0x120 + (N == 0 ? 1 : N), 0xF, 0xF, false);
+    const int rs = N == 0 ? os : __builtin_amdgcn_update_dpp(0, os, 0x120 + (N == 0 ? 1 : N), 0xF, 0xF, false);
+    rank += (rs < cnt && key_gt(__builtin_bit_cast(float, rv), rs, val, s)) ? 1 : 0;
+    if constexpr (N < 15) half_other_steps<N + 1>(ovi, os, cnt, val, s, rank);
+}
+// sum over the 32 lanes of a half wave (every lane ends with the total)
+__device__ __forceinline__ unsigned half_sum_u32(unsigned v)
+{
+    v = row_sum_u32(v);
+    return v + (unsigned)__shfl_xor((int)v, 16, kWave);
+}
+
 // The ranking half: one member per wave.  What a wave of each class costs was measured on test sets of users with equal
 // segment lengths (tools/exp_eval_classes.py, profiles/r03/NOTES.md): the launch sits at the knee of VALU issue (12 cycles per
 // entry of an in-register ranking) and of latency times occupancy (two dependent accesses per wave, 8 waves per SIMD).  Several
@@ -640,7 +665,7 @@ __device__ __forceinline__ unsigned row_sum_u32(unsigned v)
 // cut: wave-uniform segment bounds (a scalar loop and scalar ballots instead of exec-masked ones), the ten positions packed on
 // the scalar unit; a quarter wave does not search the lane of every rank (ten ballots, each unpacked per row) but lets every
 // lane ADD its position into the field of its rank, with a count and a rank sum that expose equal keys.
-__global__ __launch_bounds__(kBlock) void eval_rank_kernel(const int32_t *__restrict__ off, int32_t n_users, int32_t n_wide,
+__global__ __launch_bounds__(kBlock) void eval_rank_kernel(const int32_t *__restrict__ off, int32_t n_users, int32_t n_wide, int32_t n_half,
                                                            const float *__restrict__ pred, const float *__restrict__ rating,
                                                            const int32_t *__restrict__ top_rating, const double *__restrict__ log2_tab,
                                                            int32_t *__restrict__ hits, double *__restrict__ ndcg, int64_t pred_stride)
@@ -675,8 +700,42 @@ __global__ __launch_bounds__(kBlock) void eval_rank_kernel(const int32_t *__rest
         }
         return;
     }
-    const int user = n_wide + (wave - n_wide) * 4 + (lane >> 4);
-    if (n_wide + (wave - n_wide) * 4 >= n_users) return;
+    const int half_waves = (n_half + 1) / 2;
+    if (wave < n_wide + half_waves) {
+        // ---- two users of at most 32 entries each
+        const int first = n_wide + (wave - n_wide) * 2;
+        const int user = first + (lane >> 5);
+        const bool have = user < n_wide + n_half;
+        const int s = lane & 31;
+        const int beg = have ? off[user] : 0, cnt = have ? off[user + 1] - beg : 0;       // cnt <= 32 by the caller's ordering
+        const float pv = s < cnt ? nan_last(pred[beg + s]) : -__builtin_inff();
+        const int n_top = cnt < K ? cnt : K;
+        const int pvi = __builtin_bit_cast(int, pv);
+        const int ovi = __shfl_xor(pvi, 16, kWave);                                        // the entry at the same place of the half's other row
+        int rank = 0;
+        quarter_rank_steps_strict<1>(pvi, pv, rank);
+        half_other_steps_strict<0>(ovi, pv, rank);
+        bool in_top = s < cnt && rank < n_top;
+        // positions 0-5 in w0, 6-9 in w1 (5 bits each); chk as below
+        unsigned w0 = half_sum_u32(in_top && rank < 6 ? (unsigned)s << (5 * rank) : 0u);
+        unsigned w1 = half_sum_u32(in_top && rank >= 6 ? (unsigned)s << (5 * (rank - 6)) : 0u);
+        const unsigned chk = half_sum_u32(in_top ? 0x10000u + (unsigned)rank : 0u);
+        const bool tie = chk != ((unsigned)n_top << 16) + (unsigned)(n_top * (n_top - 1) / 2);
+        if (__builtin_amdgcn_ballot_w64(tie) != 0) {
+            rank = 0;
+            quarter_rank_steps<1>(pvi, s, cnt, pv, rank);
+            half_other_steps<0>(ovi, s ^ 16, cnt, pv, s, rank);
+            in_top = s < cnt && rank < n_top;
+            w0 = half_sum_u32(in_top && rank < 6 ? (unsigned)s << (5 * rank) : 0u);
+            w1 = half_sum_u32(in_top && rank >= 6 ? (unsigned)s << (5 * (rank - 6)) : 0u);
+        }
+        if (have && s == 0) ndcg[user] = __builtin_bit_cast(double, (unsigned long long)w0 | ((unsigned long long)w1 << 30));
+        return;
+    }
+    const int q0 = n_wide + n_half;                                                       // first user of the quarter class
+    const int qwave = wave - n_wide - half_waves;
+    const int user = q0 + qwave * 4 + (lane >> 4);
+    if (q0 + qwave * 4 >= n_users) return;
     const bool have = user < n_users;
     const int s = lane & 15;
     const int beg = have ? off[user] : 0, cnt = have ? off[user + 1] - beg : 0;       // cnt <= 16 by the caller's ordering
@@ -702,7 +761,7 @@ __global__ __launch_bounds__(kBlock) void eval_rank_kernel(const int32_t *__rest
     if (have && s == 0) ndcg[user] = __builtin_bit_cast(double, (unsigned long long)w0 | ((unsigned long long)w1 << 20));
 }
 
-__global__ __launch_bounds__(kBlock) void eval_metrics_kernel(const int32_t *__restrict__ off, int32_t n_users, int32_t n_wide,
+__global__ __launch_bounds__(kBlock) void eval_metrics_kernel(const int32_t *__restrict__ off, int32_t n_users, int32_t n_wide, int32_t n_half,
                                                               const float *__restrict__ rating, const int32_t *__restrict__ top_rating,
                                                               const double *__restrict__ log2_tab, int32_t *hits, double *ndcg)
 {
@@ -721,6 +780,9 @@ __global__ __launch_bounds__(kBlock) void eval_metrics_kernel(const int32_t *__r
         for (int k = 0; k < 7; ++k) tp[k] = (int)((lo >> (9 * k)) & 511);
 #pragma unroll
         for (int k = 7; k < K; ++k) tp[k] = (int)((hi >> (9 * (k - 7))) & 511);
+    } else if (user < n_wide + n_half) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) tp[k] = (int)((lo >> (5 * k)) & 31);
     } else {
 #pragma unroll
         for (int k = 0; k < K; ++k) tp[k] = (int)((lo >> (4 * k)) & 15);
@@ -872,25 +934,26 @@ int ure_score(const float *const *U_tables, const float *const *V_tables, int n_
 
 // (A wave keeping its user(s) for a run of 5 members of a series -- segment bounds and rating ranks fetched once -- was measured:
 // 69 -> 82 us per series call; a fifth of the waves hides less latency than the saved loads cost.  One member per wave.)
-static unsigned eval_user_blocks(int32_t n_users, int32_t n_wide)
+static unsigned eval_user_blocks(int32_t n_users, int32_t n_wide, int32_t n_half)
 {
-    const int64_t waves = (int64_t)n_wide + ((int64_t)(n_users - n_wide) + 3) / 4;
+    const int64_t waves = (int64_t)n_wide + ((int64_t)n_half + 1) / 2 + ((int64_t)(n_users - n_wide - n_half) + 3) / 4;
     return (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
 }
 
 // HR / NDCG of every user for n_series members (member m: pred + m * pred_stride, hits / ndcg + m * n_users).
-static void launch_eval_users(const int32_t *off, int32_t n_users, int32_t n_wide, const float *pred, const float *rating,
+static void launch_eval_users(const int32_t *off, int32_t n_users, int32_t n_wide, int32_t n_half, const float *pred, const float *rating,
                               const int32_t *top_rating, const double *log2_tab, int32_t *hits, double *ndcg, int64_t pred_stride,
                               int n_series, hipStream_t st)
 {
-    const dim3 grid(eval_user_blocks(n_users, n_wide), (unsigned)n_series);
-    if (!top_rating) {                  // no cached ranking of the ratings: the one-launch form ranks them too
-        hipLaunchKernelGGL(eval_users_kernel, grid, dim3(kBlock), 0, st, off, n_users, n_wide, pred, rating, top_rating, log2_tab, hits, ndcg, pred_stride);
+    if (!top_rating) {                  // no cached ranking of the ratings: the one-launch form ranks them too (a wavefront for every user of more than 16 entries)
+        const dim3 grid(eval_user_blocks(n_users, n_wide + n_half, 0), (unsigned)n_series);
+        hipLaunchKernelGGL(eval_users_kernel, grid, dim3(kBlock), 0, st, off, n_users, n_wide + n_half, pred, rating, top_rating, log2_tab, hits, ndcg, pred_stride);
         return;
     }
-    hipLaunchKernelGGL(eval_rank_kernel, grid, dim3(kBlock), 0, st, off, n_users, n_wide, pred, rating, top_rating, log2_tab, hits, ndcg, pred_stride);
+    const dim3 grid(eval_user_blocks(n_users, n_wide, n_half), (unsigned)n_series);
+    hipLaunchKernelGGL(eval_rank_kernel, grid, dim3(kBlock), 0, st, off, n_users, n_wide, n_half, pred, rating, top_rating, log2_tab, hits, ndcg, pred_stride);
     hipLaunchKernelGGL(eval_metrics_kernel, dim3((unsigned)((n_users + kBlock - 1) / kBlock), (unsigned)n_series), dim3(kBlock), 0, st, off, n_users,
-                       n_wide, rating, top_rating, log2_tab, hits, ndcg);
+                       n_wide, n_half, rating, top_rating, log2_tab, hits, ndcg);
 }
 
 int ure_eval_rank_ratings(const int32_t *off, int32_t n_users, const float *rating, int32_t *top_rating, void *stream)
@@ -904,11 +967,11 @@ int ure_eval_rank_ratings(const int32_t *off, int32_t n_users, const float *rati
 }
 
 int ure_eval_users(const int32_t *off, int32_t n_users, const float *pred, const float *rating, const double *log2_tab,
-                   int32_t *hits, double *ndcg, const int32_t *top_rating, int32_t n_wide, void *stream)
+                   int32_t *hits, double *ndcg, const int32_t *top_rating, int32_t n_wide, int32_t n_half, void *stream)
 {
-    URE_ARG(off && pred && rating && log2_tab && hits && ndcg && n_users >= 0 && n_wide >= 0 && n_wide <= n_users);
+    URE_ARG(off && pred && rating && log2_tab && hits && ndcg && n_users >= 0 && n_wide >= 0 && n_half >= 0 && n_wide + n_half <= n_users);
     if (n_users == 0) return 0;
-    launch_eval_users(off, n_users, n_wide, pred, rating, top_rating, log2_tab, hits, ndcg, 0, 1, static_cast<hipStream_t>(stream));
+    launch_eval_users(off, n_users, n_wide, n_half, pred, rating, top_rating, log2_tab, hits, ndcg, 0, 1, static_cast<hipStream_t>(stream));
     URE_HIP(hipGetLastError());
     return 0;
 }
@@ -926,9 +989,10 @@ int ure_eval_reduce(const int32_t *hits, const double *ndcg, int32_t n_users, co
 int ure_eval_series(const float *const *U_fixed, const float *const *V_fixed, int n_fixed, const float *U_series,
                     const float *V_series, int64_t stride_u, int64_t stride_v, int n_series, const int32_t *uid, const int32_t *iid,
                     const float *rating, int64_t n, int d, const int32_t *off, int32_t n_users, const double *log2_tab, float *base,
-                    float *pred, double *sse, int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide, void *stream)
+                    float *pred, double *sse, int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide, int32_t n_half,
+                    void *stream)
 {
-    URE_ARG(n_wide >= 0 && n_wide <= n_users);
+    URE_ARG(n_wide >= 0 && n_half >= 0 && n_wide + n_half <= n_users);
     URE_ARG(n_fixed >= 0 && (n_fixed == 0 || (U_fixed && V_fixed && base)) && U_series && V_series && n_series > 0 && n_series <= 65535);
     URE_ARG(uid && iid && rating && n > 0 && pow2(d) && d >= 4 && d <= 256 && off && n_users >= 0 && log2_tab && pred && sse && hits &&
             ndcg && out);
@@ -951,7 +1015,7 @@ int ure_eval_series(const float *const *U_fixed, const float *const *V_fixed, in
         default: return fail(-1, "ure_eval_series: unsupported d=%d", d);
     }
     if (n_users > 0)
-        launch_eval_users(off, n_users, n_wide, pred, rating, top_rating, log2_tab, hits, ndcg, n, n_series, st);
+        launch_eval_users(off, n_users, n_wide, n_half, pred, rating, top_rating, log2_tab, hits, ndcg, n, n_series, st);
     hipLaunchKernelGGL(eval_reduce_kernel, dim3((unsigned)n_series), dim3(1024), 0, st, hits, ndcg, n_users, sse, n, out);
     URE_HIP(hipGetLastError());
     return 0;
@@ -961,7 +1025,7 @@ int ure_eval_series_compact(const float *const *U_fixed, const float *const *V_f
                             const int32_t *row_slot, const float *U0, const float *V0, const float *snap_a, int32_t n_user_rows,
                             int n_series, const int32_t *uid, const int32_t *iid, const float *rating, int64_t n, int d,
                             const int32_t *off, int32_t n_users, const double *log2_tab, float *base, float *pred, double *sse,
-                            int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide, void *stream)
+                            int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide, int32_t n_half, void *stream)
 {
     URE_ARG(snap && row_slot && U0 && V0 && snap_a && n_user_rows > 0 && stride >= 0 && n_series > 0 && n_series <= 65535);
     URE_ARG(uid && iid && n > 0 && pow2(d) && d >= 4 && d <= 256 && pred);
@@ -969,7 +1033,7 @@ int ure_eval_series_compact(const float *const *U_fixed, const float *const *V_f
     // and the ranking exactly as ure_eval_series_own does them (in place)
     if (int rc = ure_score_own_compact(snap, stride, row_slot, U0, V0, snap_a, n_user_rows, n_series, uid, iid, n, d, pred, stream)) return rc;
     return ure_eval_series_own(U_fixed, V_fixed, n_fixed, pred, n_series, uid, iid, rating, n, d, off, n_users, log2_tab, base, pred, sse, hits, ndcg,
-                               out, top_rating, n_wide, stream);
+                               out, top_rating, n_wide, n_half, stream);
 }
 
 int ure_score_own_compact(const float *snap, int64_t stride, const int32_t *row_slot, const float *U0, const float *V0, const float *snap_a,
@@ -1004,9 +1068,9 @@ int ure_score_own_compact(const float *snap, int64_t stride, const int32_t *row_
 int ure_eval_series_own(const float *const *U_fixed, const float *const *V_fixed, int n_fixed, const float *own, int n_series, const int32_t *uid,
                         const int32_t *iid, const float *rating, int64_t n, int d, const int32_t *off, int32_t n_users, const double *log2_tab,
                         float *base, float *pred, double *sse, int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide,
-                        void *stream)
+                        int32_t n_half, void *stream)
 {
-    URE_ARG(n_wide >= 0 && n_wide <= n_users);
+    URE_ARG(n_wide >= 0 && n_half >= 0 && n_wide + n_half <= n_users);
     URE_ARG(n_fixed >= 0 && (n_fixed == 0 || (U_fixed && V_fixed && base)) && own && n_series > 0 && n_series <= 65535);
     URE_ARG(uid && iid && rating && n > 0 && pow2(d) && d >= 4 && d <= 256 && off && n_users >= 0 && log2_tab && pred && sse && hits &&
             ndcg && out);
@@ -1036,7 +1100,7 @@ int ure_eval_series_own(const float *const *U_fixed, const float *const *V_fixed
     }
 #undef URE_COMBINE
     if (n_users > 0)
-        launch_eval_users(off, n_users, n_wide, pred, rating, top_rating, log2_tab, hits, ndcg, n, n_series, st);
+        launch_eval_users(off, n_users, n_wide, n_half, pred, rating, top_rating, log2_tab, hits, ndcg, n, n_series, st);
     hipLaunchKernelGGL(eval_reduce_kernel, dim3((unsigned)n_series), dim3(1024), 0, st, hits, ndcg, n_users, sse, n, out);
     URE_HIP(hipGetLastError());
     return 0;

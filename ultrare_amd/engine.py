@@ -657,18 +657,19 @@ class EvalSet:
         rating = np.ascontiguousarray(rating, dtype=np.float32)
         self.n = len(uid)
         self.device = device or _device()
-        self.n_wide = 0
+        self.n_wide = self.n_half = 0
         if self.n:
             _, first = np.unique(uid, return_index=True)
             users = uid[np.sort(first)]                       # first-appearance order (utils.py:156-163) ...
             rank = np.empty(int(uid.max()) + 1, dtype=np.int64)
             rank[users] = np.arange(len(users))
             counts = np.bincount(rank[uid], minlength=len(users))
-            # ... inside two classes: users with more than 16 test items first (a wavefront each in the ranking kernel),
-            # then the others (four per wavefront).  The metrics are means over users: their order does not enter.
-            wide = counts > 16
-            self.n_wide = int(wide.sum())
-            cls = np.argsort(~wide, kind='stable')
+            # ... inside three classes: users with more than 32 test items first (a wavefront each in the ranking kernel), then those
+            # with 17 .. 32 (two per wavefront), then the others (four per wavefront).  The metrics are means over users: their order
+            # does not enter.
+            klass = np.where(counts > 32, 0, np.where(counts > 16, 1, 2))
+            self.n_wide, self.n_half = int((klass == 0).sum()), int((klass == 1).sum())
+            cls = np.argsort(klass, kind='stable')
             users, counts = users[cls], counts[cls]
             rank[users] = np.arange(len(users))
             order = np.argsort(rank[uid], kind='stable')
@@ -712,7 +713,7 @@ class EvalSet:
                                  nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating), self.n, d,
                                  nv.ptr(self.pred), nv.ptr(self.sse), st), 'ure_score')
         nv.check(L.ure_eval_users(nv.ptr(self.off), self.n_users, nv.ptr(self.pred), nv.ptr(self.rating),
-                                  nv.ptr(self.log2), nv.ptr(self.hits), nv.ptr(self.ndcg), nv.ptr(self.top_rating), self.n_wide, st),
+                                  nv.ptr(self.log2), nv.ptr(self.hits), nv.ptr(self.ndcg), nv.ptr(self.top_rating), self.n_wide, self.n_half, st),
                  'ure_eval_users')
         if out is not None:
             # queued evaluation: (rmse, ndcg, hr) land in `out` (device, 3 float64); nothing synchronises
@@ -759,7 +760,7 @@ class EvalSet:
                                        V_series.stride(0), m, nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating), self.n, d,
                                        nv.ptr(self.off), self.n_users, nv.ptr(self.log2), nv.ptr(b['base']), nv.ptr(b['pred']),
                                        nv.ptr(b['sse']), nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating),
-                                       self.n_wide, st),
+                                       self.n_wide, self.n_half, st),
                      'ure_eval_series')
         return out
 
@@ -784,7 +785,7 @@ class EvalSet:
                                                nv.ptr(snap_a[e0:]), int(n_user_rows), m, nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating),
                                                self.n, d, nv.ptr(self.off), self.n_users, nv.ptr(self.log2), nv.ptr(b['base']), nv.ptr(b['pred']),
                                                nv.ptr(b['sse']), nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating),
-                                               self.n_wide, st), 'ure_eval_series_compact')
+                                               self.n_wide, self.n_half, st), 'ure_eval_series_compact')
         return out
 
     def evaluate_series_own(self, fixed, own, d, out, stream=None):
@@ -801,7 +802,7 @@ class EvalSet:
             m = min(per_call, E - e0)
             nv.check(L.ure_eval_series_own(Up, Vp, len(fixed), nv.ptr(own[e0]), m, nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating), self.n, d,
                                            nv.ptr(self.off), self.n_users, nv.ptr(self.log2), nv.ptr(b['base']), nv.ptr(b['pred']), nv.ptr(b['sse']),
-                                           nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating), self.n_wide, st),
+                                           nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating), self.n_wide, self.n_half, st),
                      'ure_eval_series_own')
         return out
 
