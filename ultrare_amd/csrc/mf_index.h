@@ -24,8 +24,8 @@
 //            weight buffers with each of its own steps); the row's first step; its buffer at the epoch's end.
 //   sort     histogram per (chunk of 4,096 slots, step) -> exclusive scan over (step, chunk) -> every wavefront scatters its chunk
 //            in slot order (equal tags inside a batch of 64 are ranked by lane with ten ballots: stable).
-//   mark     per sorted slot: the buffer its OPPOSITE row is in at that step (a gather from one column of W, which an XCD's L2
-//            holds: a step's slots all read the same word index), and the bitmap of run starts.
+//            Every slot travels with the buffer its OPPOSITE row is in at that step (a gather from W in the scatter).
+//   mark     the bitmap of run starts of the sorted slots.
 //   items    scan of the run starts -> one entry per run; per step the heavy prefix and its workgroup counts.
 //   advance  every active row from "valid at the end of the last epoch" to "valid at its first step", into buffer 0 (dense, once
 //            per EPOCH; the windows of touch_mode 1 pay it every 64 steps).
@@ -284,20 +284,37 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_kernel(const ure_shard_t *
     const uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, epoch);
     const int64_t lo = (int64_t)c * kIdxChunk, hi = min(lo + kIdxChunk, S.n_slots);
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int64_t p0 = lo; p0 < hi; p0 += kWave) {
-        const int64_t p = p0 + lane;
-        unsigned tag = 0xFFFFu;
-        int oid = 0, row = 0, cls = 0;
-        float r = 0.f;
+    const int n_all = S.n_user + S.n_item;
+    // what a batch reads of the row-major arrays is requested one batch ahead (nothing of it depends on the running offsets)
+    unsigned n_tag = 0xFFFFu;
+    int n_oid = 0, n_idx = 0;
+    float n_r = 0.f;
+    auto fetch = [&](int64_t p) {
+        n_tag = 0xFFFFu;
         if (p < hi) {
-            tag = ldg(ent_tag + p);
-            oid = ldg(S.ent_oid + p);
-            r = ldg(S.ent_r + p);
-            const int idx = ldg(A.grp_row + (p >> 3)) & 0x7FFFFFFF;
-            row = ldg(S.sched + 4 * (size_t)idx);                       // (the schedule is 3.5 MB at the 25 M shape: L2 resident)
-            cls = idx < S.n_split ? kIdxSplit : idx < S.n_multi ? kIdxHeavy : kIdxLight;
+            n_tag = ldg(ent_tag + p);
+            n_oid = ldg(S.ent_oid + p);
+            n_r = ldg(S.ent_r + p);
+            n_idx = ldg(A.grp_row + (p >> 3)) & 0x7FFFFFFF;
         }
+    };
+    fetch(lo + lane);
+    for (int64_t p0 = lo; p0 < hi; p0 += kWave) {
+        const unsigned tag = n_tag;
+        int oid = n_oid;
+        const int idx = n_idx;
+        const float r = n_r;
+        fetch(p0 + kWave + lane);
         const bool valid = tag < (unsigned)steps;
+        int row = 0;
+        if (valid) {
+            row = ldg(S.sched + 4 * (size_t)idx);                       // (the schedule is 3.5 MB at the 25 M shape: L2 resident)
+            // the buffer the slot's OPPOSITE row is in at that step (this slot's row is an item row: the opposite row is a user)
+            const int other = row >= S.n_user ? oid : S.n_user + oid;
+            const unsigned long long word = ldg(A.W + (size_t)(tag / kIdxWin) * n_all + other);
+            oid |= idx_buffer_at(word, (int)(tag % kIdxWin)) << 31;
+        }
+        const int cls = idx < S.n_split ? kIdxSplit : idx < S.n_multi ? kIdxHeavy : kIdxLight;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 10; ++b) {
@@ -315,8 +332,9 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_kernel(const ure_shard_t *
     }
 }
 
-// ---- epoch start 6: per sorted slot the buffer of its opposite row at that step, and the bitmap of run starts.
-// Workgroup b takes the sorted slots [2048 b, 2048 (b + 1)).
+// ---- epoch start 6: the bitmap of run starts (a sorted slot whose row or step differs from its predecessor's) and their number per
+// block of 2,048 sorted slots.  (The buffer of a slot's opposite row, a gather from W, is marked by the scatter itself: round 4
+// had a pass of its own here that rewrote all 720 MB of sorted slots.)
 __global__ __launch_bounds__(kBlock) void idx_mark_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
 {
     __shared__ unsigned wave_cnt[kWavesPerBlock];
@@ -326,23 +344,18 @@ __global__ __launch_bounds__(kBlock) void idx_mark_kernel(const ure_shard_t *__r
     const int64_t total = ldg(A.step_begin + A.steps);
     const int64_t q_lo = (int64_t)blockIdx.x * kIdxFlagBlock;
     if (q_lo >= total) return;                                      // (workgroup-uniform)
-    const int n_all = S.n_user + S.n_item;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned starts = 0;
     for (int it = 0; it < kIdxFlagBlock / kBlock; ++it) {
         const int64_t q = q_lo + it * kBlock + threadIdx.x;
         bool start = false;
         if (q < total) {
-            uint4 rec = ldg_u4(A.sslot + q);
-            const unsigned st = rec.w & 0xFFFFu;
-            const int other = (int)rec.z >= S.n_user ? (int)rec.x : S.n_user + (int)rec.x;     // this slot's row is an item row: the opposite row is a user
-            const unsigned long long word = ldg(A.W + (size_t)(st / kIdxWin) * n_all + other);
-            rec.x |= (unsigned)idx_buffer_at(word, (int)(st % kIdxWin)) << 31;
-            stg_u4(A.sslot + q, rec);
+            const ure_u2 key = *(const ure_u2 URE_AS1 *)(reinterpret_cast<const unsigned *>(A.sslot + q) + 2);            // {row id, step | class << 16}
             if (q == 0) start = true;
             else {
-                const uint4 prev = ldg_u4(A.sslot + q - 1);
-                start = prev.z != rec.z || prev.w != rec.w;
+                const ure_u2 prev = *(const ure_u2 URE_AS1 *)(reinterpret_cast<const unsigned *>(A.sslot + q - 1) + 2);
+                const unsigned kx = key.x, ky = key.y, px = prev.x, py = prev.y;
+                start = kx != px || ky != py;
             }
         }
         const unsigned long long vote = __ballot(start);
