@@ -281,27 +281,9 @@ def roofline_of(a, leg, d, batch):
         # touch mode: the timed region also holds the three preparation launches of every epoch start, so the step kernel's
         # own duration comes from the pass with one event pair per launch (kernels of ~0.5 ms: the events cost nothing)
         avg_ms = step_ms / n_step
-    traffic, traffic_src, traffic_note = None, None, None
     kernel_name = 'mf_index_step_kernel' if getattr(job, 'index', False) else 'mf_touch_step_kernel' if job.touch else 'mf_step_kernel'
-    import glob
-    import re
-    tag = f'{a.workload}_s{len(leg["all_sizes"])}_d{d}_b{batch}'
-    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', f'*pmc_hbm_traffic*{tag}*.json')) +
-                   (glob.glob(os.path.join(ROOT, 'profiles', 'r*', '*pmc_hbm_traffic.json')) if tag == 'ml1m_s5_d32_b30000' else []),
-                   key=lambda f: [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', os.path.relpath(f, ROOT))])
     here = source_hash()
-    for f in reversed(cands):
-        try:
-            with open(f) as fh:
-                j = json.load(fh)
-            if j.get('source_hash') != here:
-                traffic_note = f'{os.path.relpath(f, ROOT)} was taken at source hash {j.get("source_hash")}, tree is {here}: not quoted'
-                continue
-            k = [v for n, v in j['kernels'].items() if kernel_name + '<' in n][0]
-            traffic, traffic_src, traffic_note = k['traffic_bytes_per_launch'], os.path.relpath(f, ROOT), None
-            break
-        except Exception:
-            continue
+    traffic, traffic_src, traffic_note = pmc_traffic_of(f'{a.workload}_s{len(leg["all_sizes"])}_d{d}_b{batch}', kernel_name)
     achieved = alg20 / (avg_ms * 1e-3) / 1e9
     fabric = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
     # the ml-1m working set (~45 MB) is cache resident: the step kernel is bound by its three dependent memory levels, not by
@@ -323,6 +305,29 @@ def roofline_of(a, leg, d, batch):
             'lazy_rows': bool(job.lazy_rows), 'touch_mode': (3 if getattr(job, 'index', False) else 2 if job.ahead else 1) if job.touch else 0, 'source_hash': here,
             'note': 'frac = algorithmic bytes (SURVEY 8d) / time / 8 TB/s; fabric_frac = PMC bytes that crossed the L2 / time / 8 TB/s '
                     '(ml-1m tables are cache resident, so fabric_frac is the HBM-side utilisation)'}
+
+
+def pmc_traffic_of(tag, kernel_name):
+    """HBM-side bytes per launch of `kernel_name` from the newest committed rocprofv3 PMC file of workload `tag` (tools/pmc_traffic.py ->
+    profiles/rNN/) -- quoted only when the file's source hash equals this tree's step-kernel sources.  -> (bytes or None, file, note)."""
+    import glob
+    import re
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', f'*pmc_hbm_traffic*{tag}*.json')) +
+                   (glob.glob(os.path.join(ROOT, 'profiles', 'r*', '*pmc_hbm_traffic.json')) if tag == 'ml1m_s5_d32_b30000' else []),
+                   key=lambda f: [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', os.path.relpath(f, ROOT))])
+    here, note = source_hash(), None
+    for f in reversed(cands):
+        try:
+            with open(f) as fh:
+                j = json.load(fh)
+            if j.get('source_hash') != here:
+                note = note or f'{os.path.relpath(f, ROOT)} was taken at source hash {j.get("source_hash")}, tree is {here}: not quoted'
+                continue
+            k = [v for n, v in j['kernels'].items() if kernel_name + '<' in n][0]
+            return k['traffic_bytes_per_launch'], os.path.relpath(f, ROOT), None
+        except Exception:
+            continue
+    return None, None, note
 
 
 def latency_floor(job):
@@ -465,7 +470,11 @@ def fullmf_leg(a, D, data):
     job.run()
     finite = bool(np.isfinite(job.epoch_sse(0)).all())
     job.close()
+    traffic, traffic_src, traffic_note = pmc_traffic_of(f'ml25m_s1_d128_b{a.batch}', 'mf_index_step_kernel' if job.index else 'mf_touch_step_kernel')
     return {'workload': f'full MF, synthetic {spec_u}x{spec_i}, {n} train rows, ONE shard, d=128, batch={a.batch}: {steps} optimizer steps per epoch',
+            'traffic': traffic, 'traffic_source': traffic_src, 'traffic_note': traffic_note,
+            'traffic_over_algorithmic': round(traffic / alg, 3) if traffic else None,
+            'fabric_frac': round(traffic / us / 1e3 / HBM_PEAK_GBS, 4) if traffic else None,
             'kernel': 'mf_index_step_kernel' if job.index else 'mf_touch_step_kernel', 'touch_mode': 3 if job.index else 1,
             'avg_launch_us': round(us, 2), 'avg_launch_from': 'event pair per launch (step kernel + the combine launch of split rows)',
             'alg_bytes_per_launch': round(alg), 'achieved': round(alg / us / 1e3, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(alg / us / 1e3 / HBM_PEAK_GBS, 4),

@@ -42,7 +42,7 @@ def main():
     shards = opt('--shards', '5' if workload == 'ml1m' else '32')
     d = opt('--d', '32' if workload == 'ml1m' else '128')
     batch = opt('--batch', '30000')
-    tail = ['--no-cpu-baseline', '--no-unlearn'] + ([] if '--steps' in bench_args else ['--steps', '5']) + ([] if '--warmup' in bench_args else ['--warmup', '1'])
+    tail = ['--no-cpu-baseline', '--no-unlearn', '--no-hbm-leg'] + ([] if '--steps' in bench_args else ['--steps', '5']) + ([] if '--warmup' in bench_args else ['--warmup', '1'])
     cmd_tail = ['python3', os.path.join(ROOT, 'bench.py')] + bench_args + tail
     env = dict(os.environ, TMPDIR='/tmp')
     sums = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
