@@ -826,6 +826,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             const size_t o_hist = take((size_t)A.idx_chunks * (steps + 1) * 4), o_seg = take((size_t)kIdxSeg * (steps + 1) * 4), o_sb = take((steps + 2) * 4);
             const size_t o_ss = take(slots * 16), o_rf = take((slots / 64 + 2) * 8), o_bc = take((slots / kIdxFlagBlock + 2) * 4);
             const size_t o_it = take(((size_t)std::min<int64_t>(2 * (int64_t)S.N, S.n_slots) + 1) * 16), o_si = take((steps + 2) * 4), o_hc = take(steps * 4);
+            const size_t o_it2 = take(((size_t)std::min<int64_t>(2 * (int64_t)S.N, S.n_slots) + 1) * 16);
             const size_t o_cum = take(steps * (kIdxHeavyMax + 1) * 4), o_pa = take((size_t)A.idx_hw * (S.d + 4) * 4);
             const size_t o_map = take(steps * (size_t)A.idx_hw * 4), o_wg = take(steps * 4), o_sd = take(steps * 16);
             void *mem = nullptr;
@@ -847,6 +848,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             A.runflag = reinterpret_cast<unsigned long long *>(b + o_rf);
             A.blk_cnt = reinterpret_cast<uint32_t *>(b + o_bc);
             A.items = reinterpret_cast<int4 *>(b + o_it);
+            A.items2 = reinterpret_cast<uint4 *>(b + o_it2);
             A.step_item = reinterpret_cast<uint32_t *>(b + o_si);
             A.heavy_cnt = reinterpret_cast<uint32_t *>(b + o_hc);
             A.heavy_cum = reinterpret_cast<uint32_t *>(b + o_cum);

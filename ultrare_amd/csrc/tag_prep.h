@@ -188,6 +188,7 @@ struct shard_aux {
     int32_t ride_m;         // steps / 3, or 0 when the shard's tags are prepared by standalone launches
     int32_t ride_ab;        // workgroups of phase A (and of B) carried by one step = ceil(ranges / m)
     int32_t ride_c;         // the same for phase C
+    int32_t ride_only_c;    // 1: epochs of fewer than three steps with host-made tags -- phase C alone, spread over all steps of the epoch
     int32_t ranges;         // tag_ranges(N)
     int32_t derive_blocks;  // tag_derive_blocks(n_slots)
     // touch mode (mf_touch.h); library-owned device memory, NULL otherwise.  An epoch is cut into WINDOWS of 64 steps
@@ -224,6 +225,7 @@ struct shard_aux {
     unsigned long long *runflag;   // [n_slots / 64 + 1] bit = the sorted slot starts a (step, row) run
     uint32_t *blk_cnt;             // [n_slots / 2048 + 2] runs that start in each block of 2048 sorted slots -> exclusive prefix
     int4 *items;                   // [2 N + 1] one per (step, row) run, steps ascending: {row id | buffer << 31, first sorted slot, end, gap | class << 16}
+    uint4 *items2;                 // [2 N + 1] the first two sorted slots of every item's run: {opposite id | buffer << 31, rating, the same of the second}
     uint32_t *step_item;           // [steps + 2] first item of each step
     uint32_t *heavy_cnt;           // [steps] items of the step that whole workgroups take (a prefix of its items)
     uint32_t *heavy_cum;           // [steps][257] workgroups of the step's heavy items, cumulative
@@ -238,6 +240,19 @@ constexpr int kTouchWindowBits = 6;
 // global index of the last window of `epoch` (the window whose masks say in which buffer a row's weights are at the epoch's end)
 __host__ __device__ inline int64_t touch_last_window(const shard_aux &a, int64_t epoch) { return (epoch + 1) * a.windows - 1; }
 
+// Does the shard's tag preparation ride on its steps although an epoch has fewer than three of them?  (Host-made tags only: no partition phases.)
+__host__ __device__ inline bool tag_short_riders(const ure_shard_t &S)
+{
+    const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
+    return steps < 3 && S.file_tags != nullptr && S.touch_mode != 3;
+}
+// ... and does it ride at all (otherwise: standalone launches at every epoch start)
+__host__ __device__ inline bool tag_riders(const ure_shard_t &S)
+{
+    const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
+    return ((steps >= 3 && tag_partitioned(S.N)) || tag_short_riders(S)) && S.touch_mode != 3;
+}
+
 inline shard_aux make_shard_aux(const ure_shard_t &S)
 {
     shard_aux a{};
@@ -250,6 +265,12 @@ inline shard_aux make_shard_aux(const ure_shard_t &S)
     if (a.ride_m) {
         a.ride_ab = (a.ranges + a.ride_m - 1) / a.ride_m;
         a.ride_c = (a.derive_blocks + a.ride_m - 1) / a.ride_m;
+    } else if (tag_short_riders(S)) {
+        // epochs of one or two steps with host-made batch tags (BASELINE.json configs[4]: 16 shards of ~56 k rows, 2 steps per epoch):
+        // only the slot-order gather is left of the preparation, and every step carries its share of it -- as a launch of its
+        // own per epoch it was 19 % of that configuration's device time (profiles/r04/cfg4_d16_kernel_stats.csv before / after)
+        a.ride_only_c = 1;
+        a.ride_c = (a.derive_blocks + a.steps - 1) / a.steps;
     }
     return a;
 }
@@ -274,6 +295,13 @@ struct TagRide {
 __host__ __device__ inline TagRide tag_ride(const shard_aux &a, int s, bool has_next)
 {
     TagRide r{-1, 0, 0};
+    if (a.ride_only_c) {
+        if (!has_next) return r;
+        r.phase = 2;
+        r.first = s * a.ride_c;
+        r.count = max(0, min(a.ride_c, a.derive_blocks - r.first));
+        return r;
+    }
     const int m = a.ride_m;
     if (!has_next || m == 0 || s >= 3 * m) return r;
     const int p = s >= 2 * m ? 2 : s >= m ? 1 : 0;

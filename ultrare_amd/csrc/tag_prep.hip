@@ -12,7 +12,7 @@ __device__ __forceinline__ int standalone_epoch(const ure_shard_t &S, int64_t ti
 {
     const int steps = (S.N + S.batch - 1) / S.batch;
     if (tick >= (int64_t)steps * S.epochs || tick % steps != 0) return -1;      // not an epoch start
-    const bool riders = steps >= 3 && tag_partitioned(S.N) && S.touch_mode != 3;
+    const bool riders = tag_riders(S);
     const int epoch = (int)(tick / steps);
     if (S.touch_mode == 2) {
         if (pass == 0) return tick == 0 ? 0 : -1;
@@ -73,7 +73,7 @@ int tag_prep_needed(const ure_job *job, int64_t tick)
     for (const ure_shard_t &S : job->host) {
         const int64_t steps = ((int64_t)S.N + S.batch - 1) / S.batch;
         if (tick >= steps * S.epochs || tick % steps != 0) continue;
-        const bool riders = steps >= 3 && tag_partitioned(S.N) && S.touch_mode != 3;
+        const bool riders = tag_riders(S);
         if (S.touch_mode == 2) {
             if (tick == 0) need |= 1;
             if ((tick == 0 || !riders) && tick / steps + 1 < S.epochs) need |= 2;
