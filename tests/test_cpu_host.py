@@ -816,3 +816,29 @@ def test_layouts_and_units_from_one_native_call():
                                             n_user, n_item, (vp * 1)(reg[0].ctypes.data), region_words.ctypes.data, n_slots.ctypes.data,
                                             n_active.ctypes.data, 32, n_units.ctypes.data, 1), 'ure_host_build_layouts_units')
     assert n_units[0] == -1 and n_slots[0] == k0[0] and n_active[0] == a0[0]
+
+
+def test_shard_streams_memo_returns_the_walked_states():
+    """rng.shard_streams walks the generator past every shard's draws (a pure function of the state, the distance and the count); a
+    request that starts from a state seen before takes the start states from the memo -- byte for byte what the walk gives, and
+    what torch's own generator reaches by making the draws."""
+    from ultrare_amd import rng
+    torch.manual_seed(42)
+    rng._STREAM_MEMO.clear()
+    a = rng.shard_streams(3, 40, 30, 4, 2, True)
+    hits = rng.STATS.get('memo_hits', 0)
+    torch.manual_seed(42)
+    b = rng.shard_streams(3, 40, 30, 4, 2, True)
+    assert rng.STATS.get('memo_hits', 0) == hits + 1
+    for x, y in zip(a[0] + [a[1]], b[0] + [b[1]]):
+        assert torch.equal(x, y)
+    torch.manual_seed(42)
+    for i in range(3):
+        assert torch.equal(torch.get_rng_state(), a[0][i])
+        for n in (40 * 4, 30 * 4, 40 * 4, 30 * 4):
+            torch.empty(n).normal_()
+        torch.empty(2 * 4, dtype=torch.int64).random_()
+    assert torch.equal(torch.get_rng_state(), a[1])
+    b[0][0][100] ^= 1                                        # a caller's copy is its own
+    torch.manual_seed(42)
+    assert torch.equal(rng.shard_streams(3, 40, 30, 4, 2, True)[0][0], a[0][0])

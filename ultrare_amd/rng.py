@@ -174,6 +174,9 @@ def epoch_seeds(epochs, with_total_test, generator=None):
     return [int(v) for v in draws[1::per].tolist()]
 
 
+_STREAM_MEMO = {}
+
+
 def shard_streams(n_shards, n_user, n_item, k, epochs, with_total_test):
     """The generator states at which each of n_shards consecutive Scratch.train calls starts, computed by
     skip-ahead (the draws are data independent), and the state after the last one.  With them every shard's
@@ -182,10 +185,27 @@ def shard_streams(n_shards, n_user, n_item, k, epochs, with_total_test):
     if draws is None:
         return None
     s = torch.get_rng_state()
+    # The walk is a pure function of (generator state, distance, count): 56.8 M outputs per shard at BASELINE.json configs[3]'s shape,
+    # 1.8 G for its 32 shards -- 0.2-0.6 s of MT19937 state updates on one thread in front of every request of every rank.  Requests
+    # that start from a state seen before (the harness seeds the generator before each top-level call: SURVEY D7) take the states
+    # from a small memo instead (32 x 5 KB); URE_STREAM_MEMO=0 walks every time.
+    import hashlib
+    import os
+    key = None
+    if os.environ.get('URE_STREAM_MEMO', '1') != '0':
+        key = (hashlib.blake2b(s.numpy().tobytes(), digest_size=16).digest(), int(n_shards), int(sum(draws)))
+        hit = _STREAM_MEMO.get(key)
+        if hit is not None:
+            STATS['memo_hits'] = STATS.get('memo_hits', 0) + 1
+            return [t.clone() for t in hit[0]], hit[1].clone()
     starts = []
     for _ in range(n_shards):
         starts.append(s)
         s = advance_state(s, sum(draws))
+    if key is not None:
+        if len(_STREAM_MEMO) >= 64:
+            _STREAM_MEMO.clear()
+        _STREAM_MEMO[key] = ([t.clone() for t in starts], s.clone())
     return starts, s
 
 
