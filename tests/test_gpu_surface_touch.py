@@ -90,18 +90,31 @@ def test_scratch_train_with_long_epochs_in_touch_mode_3(verbose, tmp_path, monke
         np.testing.assert_allclose(sc.log[key], log[key], rtol=1e-4, err_msg=key)
 
 
-def test_configs3_shape_through_sisa_parallel_against_the_oracle(monkeypatch, jobs_seen):
+_ML25M = []
+
+
+def _ml25m():
+    from ultrare_amd import synth
+    if not _ML25M:
+        _ML25M.append(synth.make_dataset(**synth.ML25M))
+    return _ML25M[0]
+
+
+@pytest.mark.parametrize('index_env', ['1', '0'])
+def test_configs3_shape_through_sisa_parallel_against_the_oracle(index_env, monkeypatch, jobs_seen):
     """BASELINE.json configs[3]'s shape (162,000 x 60,000, 22.5 M ratings, 32 shards) through Sisa(parallel) at k = 16, where the
-    reference's arithmetic stays finite: the auto rule puts the job into touch_mode 2 (373 MB of live rows, tables read at the end), the
-    per-epoch logs come from compact snapshots through ure_eval_series_compact, the shards' own rows are merged.  Shards 0 and 1 are
+    reference's arithmetic stays finite: the auto rule puts the job into touch mode (373 MB of live rows, tables read at the end) -- touch_mode 3
+    at this row width (engine.INDEX_SHORT_EPOCH_MAX_D), touch_mode 2 in the second case (URE_TOUCH_INDEX=0) --, the per-epoch logs come from
+    compact snapshots through ure_eval_series_compact, the shards' own rows are merged.  Shards 0 and 1 are
     checked against the oracle's Scratch.train on the same stream: item tables, own user rows of the merged matrix, and both epochs of
     every log series (shard 1's tests average shard 0's final model in: scratch.py:83-86)."""
     from ultrare_amd import synth
     from ultrare_amd.method.sisa import Sisa
     from ultrare_amd.read import RatingData, loadData
     monkeypatch.delenv('URE_TOUCH', raising=False)
+    monkeypatch.setenv('URE_TOUCH_INDEX', index_env)
     spec = synth.ML25M
-    data = synth.make_dataset(**spec)
+    data = _ml25m()
     S, E, B, k = 32, 2, 30000, 16
 
     class P:
@@ -121,7 +134,8 @@ def test_configs3_shape_through_sisa_parallel_against_the_oracle(monkeypatch, jo
     sisa = Sisa(P, 'mf', S, groups)
     torch.manual_seed(42)
     ml = sisa.learn(trd, ted, tot, 0, '')
-    assert jobs_seen == [(True, True, False)], jobs_seen
+    # the auto rule: narrow rows (k = 16) take touch_mode 3 for short epochs too; without it touch_mode 2
+    assert jobs_seen == ([(True, False, True)] if index_env == '1' else [(True, True, False)]), jobs_seen
     assert len(sisa.log['train_loss']) == S * E and np.isfinite(sisa.log['total_rmse']).all()
 
     def f32(p):

@@ -40,6 +40,7 @@ INDEX_MAX_STEPS = 1008               # kIdxMaxSteps of csrc/mf_index.h (touch_mo
 INDEX_HEAVY_SLOTS = 16               # touch_mode 3: rows with at least this many slots per step on average get a workgroup per step ...
 INDEX_SPLIT_SLOTS = 384              # ... and with this many, one per 256 slots of the step
 INDEX_HEAVY_MAX = 256                # kIdxHeavyMax
+INDEX_SHORT_EPOCH_MAX_D = 64         # auto rule: epochs of at most 63 steps take touch_mode 3 up to this table width (beyond it touch_mode 2 / 1)
 TOUCH_MIN_TABLE_BYTES = 256 << 20    # auto rule: the job's live rows (w, m, second buffer) exceed the Infinity Cache
 
 
@@ -321,19 +322,27 @@ class TrainJob:
         # touch mode (csrc/mf_touch.h): a step visits only the rows it trains, the others are advanced in closed form when
         # they are next trained.  Pays when the tables do not fit the caches (configs[3]); URE_TOUCH=0/1 overrides the rule.
         steps_all = [(sh.N + self.batch - 1) // self.batch for sh in shards]
+        by_rule = False
         if touch is None:
             env = os.environ.get('URE_TOUCH', 'auto')
             live = sum(sh.n_active for sh in shards) * self.d * 12
-            touch = (env == '1') or (env == 'auto' and live > TOUCH_MIN_TABLE_BYTES and (final_only or epoch_reads))
+            by_rule = env == 'auto' and live > TOUCH_MIN_TABLE_BYTES and (final_only or epoch_reads)
+            touch = (env == '1') or by_rule
         self.touch = bool(touch) and self.lazy_rows and max(steps_all) <= TOUCH_MAX_STEPS
         # touch_mode 2 (csrc/mf_touch.h, "masks one epoch ahead"): no dense pass at the epoch starts; for callers that read the tables
         # only after the last epoch (final_only) and epochs of at most 63 steps.  URE_TOUCH_AHEAD=0 keeps mode 1.
+        # Short epochs (<= 63 steps) of NARROW rows: sorting the epoch's slots by step (touch_mode 3) costs ~3 ms per epoch whatever the row width, and saves the
+        # scan of every trained row's slots in every step -- most of the traffic at 64-byte rows.  BASELINE.json configs[3]'s shape (32 shards, 27 steps per
+        # epoch), epoch time in touch_mode 2 -> 3: d = 16 6.32 -> 4.95 ms, d = 32 6.25 -> 5.87, d = 64 8.36 -> 8.02, d = 128 12.18 -> 13.17
+        # (profiles/r04/exp_short_epochs_index.txt).  Under the auto rule touch_mode 3 is taken up to d = 64.
+        force_index = touch == 'index' or os.environ.get('URE_TOUCH_INDEX', '1') == '2' or (by_rule and self.d <= INDEX_SHORT_EPOCH_MAX_D and
+                                                                                             os.environ.get('URE_TOUCH_INDEX', '1') != '0')
         self.ahead = (self.touch and bool(final_only) and max(steps_all) <= TOUCH_AHEAD_MAX_STEPS and snapshots in (False, None, 'compact')
-                      and os.environ.get('URE_TOUCH_AHEAD', '1') != '0')
+                      and os.environ.get('URE_TOUCH_AHEAD', '1') != '0' and not force_index)
         # touch_mode 3 (csrc/mf_index.h): epochs of more than 63 steps -- the epoch's slots are sorted by step at its start and a step
         # launches over exactly the rows it trains (64-step windows look at every work unit in every step).  URE_TOUCH_INDEX=0 keeps windows.
         self.index = (self.touch and not self.ahead and max(steps_all) <= INDEX_MAX_STEPS and self.batch <= 200000 and
-                      (touch == 'index' or (max(steps_all) > TOUCH_AHEAD_MAX_STEPS and os.environ.get('URE_TOUCH_INDEX', '1') != '0')))
+                      (force_index or (max(steps_all) > TOUCH_AHEAD_MAX_STEPS and os.environ.get('URE_TOUCH_INDEX', '1') != '0')))
         # end-of-epoch snapshots: 'compact' keeps the n_active rows with interactions only (every other row is a_e * w0 and is
         # rebuilt where it is read: ure_eval_series_compact; needs lazy_rows), True / 'full' keeps complete tables
         self.snapshots = ('compact' if self.lazy_rows else 'full') if snapshots == 'compact' else ('full' if snapshots else False)
