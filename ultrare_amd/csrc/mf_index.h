@@ -78,7 +78,8 @@ __global__ __launch_bounds__(kBlock) void idx_grp_row_kernel(const ure_shard_t *
             if ((int64_t)ldg(S.sched + 4 * (size_t)mid + 1) <= 8 * g) lo = mid; else hi = mid - 1;
         }
         const int row_id = ldg(S.sched + 4 * (size_t)lo);
-        stg(A.grp_row + g, lo | (row_id >= S.n_user ? (int)0x80000000 : 0));
+        stg(A.grp_row + 2 * g, lo);                      // {schedule index, row id}: whoever walks the slots needs both, in one load
+        stg(A.grp_row + 2 * g + 1, row_id);
     }
 }
 
@@ -93,13 +94,13 @@ __global__ __launch_bounds__(kBlock) void idx_masks_kernel(const ure_shard_t *__
     const int words = A.idx_words, steps = A.steps;
     const int64_t n_grp = S.n_slots / 8;
     const int64_t g_lo = (int64_t)blockIdx.x * (kIdxChunk / 8), g_hi = min(g_lo + kIdxChunk / 8, n_grp);
-    const int idx0 = ldg(A.grp_row + g_lo) & 0x7FFFFFFF;
-    const int n_rows = (ldg(A.grp_row + g_hi - 1) & 0x7FFFFFFF) - idx0 + 1;
+    const int idx0 = ldg(A.grp_row + 2 * g_lo);
+    const int n_rows = ldg(A.grp_row + 2 * (g_hi - 1)) - idx0 + 1;
     for (int t = threadIdx.x; t < n_rows * words; t += kBlock) bits[t] = 0ull;
     __syncthreads();
     const uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, epoch);
     for (int64_t g = g_lo + threadIdx.x; g < g_hi; g += kBlock) {
-        const int local = (ldg(A.grp_row + g) & 0x7FFFFFFF) - idx0;
+        const int local = ldg(A.grp_row + 2 * g) - idx0;
         const uint4 t4 = ldg_u4(ent_tag + g * 8);
         const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void idx_clear_kernel(const ure_shard_t *__
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < (int64_t)A.idx_chunks * 2; t += (int64_t)gridDim.x * kBlock) {
         const int64_t c = t >> 1;
         const int64_t g = (t & 1) ? min((c + 1) * (kIdxChunk / 8), n_grp) - 1 : c * (kIdxChunk / 8);      // the chunk's first / last group
-        const int row_id = ldg(S.sched + 4 * (size_t)(ldg(A.grp_row + g) & 0x7FFFFFFF));
+        const int row_id = ldg(A.grp_row + 2 * g + 1);
         for (int w = 0; w < A.idx_words; ++w) stg(A.W + (size_t)w * n_all + row_id, 0ull);
     }
 }
@@ -285,35 +286,39 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_kernel(const ure_shard_t *
     const int64_t lo = (int64_t)c * kIdxChunk, hi = min(lo + kIdxChunk, S.n_slots);
     const unsigned long long below = (1ull << lane) - 1ull;
     const int n_all = S.n_user + S.n_item;
-    // what a batch reads of the row-major arrays is requested one batch ahead (nothing of it depends on the running offsets)
-    unsigned n_tag = 0xFFFFu;
-    int n_oid = 0, n_idx = 0;
-    float n_r = 0.f;
+    // Two stages ahead of the running offsets (nothing of either depends on them): what a batch reads of the row-major arrays is
+    // requested TWO batches ahead, the mask word of its slots' opposite rows -- a gather that needs the tag, the opposite id and the row --
+    // one batch ahead.  (Unpipelined, the two dependent levels sat in every one of a wave's 64 sequential iterations: 1.36 ms per epoch.)
+    struct Batch { unsigned tag; int oid, idx, row; float r; };
     auto fetch = [&](int64_t p) {
-        n_tag = 0xFFFFu;
+        Batch b{0xFFFFu, 0, 0, 0, 0.f};
         if (p < hi) {
-            n_tag = ldg(ent_tag + p);
-            n_oid = ldg(S.ent_oid + p);
-            n_r = ldg(S.ent_r + p);
-            n_idx = ldg(A.grp_row + (p >> 3)) & 0x7FFFFFFF;
+            b.tag = ldg(ent_tag + p);
+            b.oid = ldg(S.ent_oid + p);
+            b.r = ldg(S.ent_r + p);
+            const ure_i2 g = *(const ure_i2 URE_AS1 *)(A.grp_row + 2 * (p >> 3));
+            const int gi = g.x, gr = g.y;
+            b.idx = gi; b.row = gr;
         }
+        return b;
     };
-    fetch(lo + lane);
+    auto word_of = [&](const Batch &b) {
+        // the mask word of the slot's OPPOSITE row (this slot's row is an item row: the opposite row is a user)
+        if (b.tag >= (unsigned)steps) return 0ull;
+        const int other = b.row >= S.n_user ? b.oid : S.n_user + b.oid;
+        return ldg(A.W + (size_t)(b.tag / kIdxWin) * n_all + other);
+    };
+    Batch cur = fetch(lo + lane), nxt = fetch(lo + kWave + lane);
+    unsigned long long cur_word = word_of(cur);
     for (int64_t p0 = lo; p0 < hi; p0 += kWave) {
-        const unsigned tag = n_tag;
-        int oid = n_oid;
-        const int idx = n_idx;
-        const float r = n_r;
-        fetch(p0 + kWave + lane);
+        const Batch far = fetch(p0 + 2 * kWave + lane);
+        const unsigned long long nxt_word = word_of(nxt);
+        const unsigned tag = cur.tag;
+        const int idx = cur.idx, row = cur.row;
+        const float r = cur.r;
         const bool valid = tag < (unsigned)steps;
-        int row = 0;
-        if (valid) {
-            row = ldg(S.sched + 4 * (size_t)idx);                       // (the schedule is 3.5 MB at the 25 M shape: L2 resident)
-            // the buffer the slot's OPPOSITE row is in at that step (this slot's row is an item row: the opposite row is a user)
-            const int other = row >= S.n_user ? oid : S.n_user + oid;
-            const unsigned long long word = ldg(A.W + (size_t)(tag / kIdxWin) * n_all + other);
-            oid |= idx_buffer_at(word, (int)(tag % kIdxWin)) << 31;
-        }
+        const int oid = cur.oid | (valid ? idx_buffer_at(cur_word, (int)(tag % kIdxWin)) << 31 : 0);
+        cur = nxt; cur_word = nxt_word; nxt = far;
         const int cls = idx < S.n_split ? kIdxSplit : idx < S.n_multi ? kIdxHeavy : kIdxLight;
         unsigned long long peers = __ballot(valid);
 #pragma unroll

@@ -822,7 +822,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             A.idx_light = (int32_t)std::min<int64_t>(2 * (int64_t)S.batch, S.n_active);
             size_t at = 0;
             auto take = [&at](size_t bytes) { const size_t o = at; at += (bytes + 255) / 256 * 256; return o; };
-            const size_t o_grp = take(slots / 8 * 4), o_w = take((size_t)A.idx_words * n_all * 8), o_par = take(2 * n_all), o_first = take(n_all * 2 + (size_t)A.idx_words * n_all * 2);
+            const size_t o_grp = take(slots / 8 * 8), o_w = take((size_t)A.idx_words * n_all * 8), o_par = take(2 * n_all), o_first = take(n_all * 2 + (size_t)A.idx_words * n_all * 2);
             const size_t o_hist = take((size_t)A.idx_chunks * (steps + 1) * 4), o_seg = take((size_t)kIdxSeg * (steps + 1) * 4), o_sb = take((steps + 2) * 4);
             const size_t o_ss = take(slots * 16), o_rf = take((slots / 64 + 2) * 8), o_bc = take((slots / kIdxFlagBlock + 2) * 4);
             const size_t o_it = take(((size_t)std::min<int64_t>(2 * (int64_t)S.N, S.n_slots) + 1) * 16), o_si = take((steps + 2) * 4), o_hc = take(steps * 4);

@@ -212,7 +212,7 @@ struct shard_aux {
     int32_t idx_chunks;            // ceil(n_slots / 4096): one wavefront sorts one chunk
     int32_t idx_hw;                // workgroups of a step launch reserved for heavy rows (upper bound)
     int32_t idx_light;             // upper bound of a step's light items = min(2 B, n_active)
-    int32_t *grp_row;              // [n_slots / 8] schedule index of the row that owns the group of 8 slots | item row << 31 (static)
+    int32_t *grp_row;              // [n_slots / 8][2] {schedule index, row id} of the row that owns the group of 8 slots (static)
     unsigned long long *W;         // [idx_words][n_user + n_item] bit b of word w = the row is trained in step 63 w + b; bit 63 = the buffer
                                    // its weights are in at step 63 w
     uint8_t *end_par[2];           // [n_user + n_item] buffer of the row at the end of an epoch, by epoch parity

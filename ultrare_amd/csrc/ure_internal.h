@@ -87,6 +87,7 @@ typedef float ure_f4 __attribute__((ext_vector_type(4)));
 typedef int ure_i4 __attribute__((ext_vector_type(4)));
 typedef unsigned ure_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned ure_u2 __attribute__((ext_vector_type(2)));
+typedef int ure_i2 __attribute__((ext_vector_type(2)));
 template <typename T>
 __device__ __forceinline__ T ldg(const T *p) { return *(const T URE_AS1 *)p; }
 template <typename T>
