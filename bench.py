@@ -493,6 +493,8 @@ def exchange_leg(D, leg, d, reps=5):
     owner = [j // S for j in ids]
     dev = torch.device('cuda', torch.cuda.current_device())
     rows = {j: torch.as_tensor(np.asarray(leg['groups'][j % S], dtype=np.int64)).to(dev) for j in ids}
+    if job.touch:
+        job.run()          # (a job in touch mode keeps its rows valid for their NEXT step: the tables exist at the end of training / at epoch ends only)
     models = {D.rank * S + s: tuple(t.contiguous() for t in job.tables(s)) for s in range(S)}
     times = []
     for _ in range(reps + 1):

@@ -449,3 +449,38 @@ def test_two_launch_ranking_handles_ties_nans_and_every_segment_class():
         assert np.array_equal(out[True][1], out[False][1]), name          # the same arithmetic in the same order: bit for bit
         want = O.eval_from_pred(uid, r, pred, 3000)
         np.testing.assert_allclose([out[True][1].mean(), (out[True][0] / 10).mean()], want[1:], rtol=1e-12, err_msg=name)
+
+
+def test_auto_touch_only_for_callers_that_read_at_epoch_ends():
+    """a job above the touch threshold that makes no promise about WHEN it reads its tables must stay readable at any tick
+    (the default kernel); with epoch_reads / final_only the auto rule may take a touch mode, whose tables exist at epoch boundaries
+    (at the end of training in touch_mode 2) only -- reading them inside an epoch raises instead of returning rows that are valid
+    for another step."""
+    from ultrare_amd import engine, rng, _native as nv
+    rs = np.random.RandomState(4)
+    n_user, n_item, k, B, E, n = 3000, 2500, 16, 400, 2, 30000
+    key = np.unique(rs.randint(0, n_user, n).astype(np.int64) * n_item + rs.randint(0, n_item, n))
+    part = ((key // n_item).astype(np.int32), (key % n_item).astype(np.int32), (rs.randint(1, 6, len(key)) / 5).astype(np.float32))
+    torch.manual_seed(3)
+    init = rng.mf_init(n_user, n_item, k)
+    perms = rng.epoch_perms(rng.epoch_seeds(E, True), len(key))
+    old = engine.TOUCH_MIN_TABLE_BYTES
+    engine.TOUCH_MIN_TABLE_BYTES = 1 << 10           # the rule fires for this small job
+    try:
+        sh = engine.ShardData(*part, n_user, n_item)
+        free = engine.TrainJob([sh], [init], [perms], k, B, E, 1e-3, 0.1, 0.9, 0.95)
+        assert not free.touch
+        free.run(7)                                  # inside the first epoch (74 steps)
+        U_mid, _ = free.tables(0)
+        assert torch.isfinite(U_mid).all()
+        free.close()
+        bound = engine.TrainJob([sh], [init], [perms], k, B, E, 1e-3, 0.1, 0.9, 0.95, epoch_reads=True)
+        assert bound.touch and bound.index           # 74 steps per epoch: the slots sorted by step
+        bound.run(7)
+        with pytest.raises(nv.NativeError, match='inside an epoch'):
+            bound.tables(0)
+        bound.run(bound.steps_per_epoch(0) - 7)
+        assert torch.isfinite(bound.tables(0)[0]).all()
+        bound.close()
+    finally:
+        engine.TOUCH_MIN_TABLE_BYTES = old
