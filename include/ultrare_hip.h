@@ -329,6 +329,16 @@ int ure_eval_series_own(const float *const *U_fixed, const float *const *V_fixed
                         float *base, float *pred, double *sse, int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide,
                         int32_t n_half, void *stream);
 
+/* scratch.py:83-97 tests every epoch's ensemble on the shard's own test set and on the total test set, which config.py:144-148 builds
+ * as the shards' test sets side by side: the shard's set is the total set's rows of the shard's users.  After a series on the TOTAL
+ * set (ure_eval_series*: pred [n_series][pred_stride], hits / ndcg [n_series][n_users] still hold its per-pair predictions and per-user
+ * metrics) this reduces the same three numbers over a subset of its users: sub_users [n_sub] = their indices in the total set's
+ * user order, sub_pairs [n_pairs] = the indices of their pairs in the total set's pair order; out [n_series][3] = (sqrt(sum over
+ * those pairs of (pred - rating)^2 / n_pairs), mean ndcg, mean hits / 10).  The caller establishes that the subset's rows ARE the
+ * total set's rows of those users (ultrare_amd.engine.EvalSet.subset_of).                                                       */
+int ure_eval_subset(const int32_t *sub_users, int32_t n_sub, const int32_t *sub_pairs, int32_t n_pairs, const float *pred, const float *rating,
+                    const int32_t *hits, const double *ndcg, int64_t pred_stride, int32_t n_users, int n_series, double *out, void *stream);
+
 /* sisa.py:55-56,110-111: dst[rows[t]][:] = src[rows[t]][:]. */
 int ure_merge_rows(float *dst, const float *src, const int64_t *rows, int64_t n_rows, int d, void *stream);
 

@@ -484,3 +484,43 @@ def test_auto_touch_only_for_callers_that_read_at_epoch_ends():
         bound.close()
     finally:
         engine.TOUCH_MIN_TABLE_BYTES = old
+
+
+def test_one_series_on_the_total_set_yields_the_shard_sets_numbers_too():
+    """scratch.py:83-97 tests every epoch on the shard's own test set and on the total test set, which config.py:144-148 builds from the
+    shards' sets: EvalSet.subset_of recognises that, and ure_eval_subset reduces the shard's numbers from what the series on the total set
+    left behind.  Against a series of its own on the shard's set: NDCG and HR bit for bit (the same per-user values added in the same
+    order), RMSE to rounding; a set that is NOT the total set's rows of its users gets no plan."""
+    from ultrare_amd import engine
+    rs = np.random.RandomState(5)
+    n_user, n_item, d, E = 900, 700, 16, 4
+    lengths = rs.randint(1, 60, n_user)
+    uid = np.repeat(np.arange(n_user), lengths).astype(np.int32)
+    iid = rs.randint(0, n_item, len(uid)).astype(np.int32)
+    r = rs.choice([0.2, 0.4, 0.6, 0.8, 1.0], len(uid)).astype(np.float32)
+    groups = np.array_split(rs.permutation(n_user), 3)
+    parts = [np.flatnonzero(np.isin(uid, g)) for g in groups]
+    order = np.concatenate(parts)                                  # the total set = the shards' sets side by side
+    total = engine.EvalSet(uid[order], iid[order], r[order])
+    dev = total.device
+    U = torch.randn(E, n_user, d, device=dev)
+    V = torch.randn(E, n_item, d, device=dev)
+    fixed = [(torch.randn(n_user, d, device=dev), torch.randn(n_item, d, device=dev))]
+    out_total = torch.zeros(E, 3, dtype=torch.float64, device=dev)
+    for g, rows in enumerate(parts):
+        sub = engine.EvalSet(uid[rows], iid[rows], r[rows])
+        plan = sub.subset_of(total)
+        assert plan is not None and plan['n'] == len(groups[g])
+        assert sub.subset_of(total) is plan                        # kept
+        own = torch.zeros(E, 3, dtype=torch.float64, device=dev)
+        sub.evaluate_series(fixed, U, V, d, own)
+        via = torch.zeros(E, 3, dtype=torch.float64, device=dev)
+        total.evaluate_series(fixed, U, V, d, out_total, subset=(plan, via))
+        own, via = own.cpu().numpy(), via.cpu().numpy()
+        assert np.array_equal(own[:, 1:], via[:, 1:]), g
+        np.testing.assert_allclose(via[:, 0], own[:, 0], rtol=1e-6)
+    changed = r[parts[0]].copy()
+    changed[7] = 1.0 if changed[7] != 1.0 else 0.2
+    assert engine.EvalSet(uid[parts[0]], iid[parts[0]], changed).subset_of(total) is None
+    other_user = engine.EvalSet(np.full(3, n_user + 5, np.int32), np.zeros(3, np.int32), np.ones(3, np.float32))
+    assert other_user.subset_of(total) is None

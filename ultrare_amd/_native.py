@@ -84,6 +84,7 @@ _PROTOTYPES = {
     'ure_score_own_compact': (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, ctypes.c_int, _vp, _vp, _i64, ctypes.c_int, _vp, _vp]),
     'ure_eval_series_own': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _i64, ctypes.c_int,
                                            _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    'ure_eval_subset': (ctypes.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_int, _vp, _vp]),
     'ure_merge_rows': (ctypes.c_int, [_vp, _vp, _vp, _i64, ctypes.c_int, _vp]),
     'ure_ot_cost': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'ure_ot_cost_mfma': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp]),

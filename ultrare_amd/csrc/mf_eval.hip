@@ -863,6 +863,60 @@ __global__ __launch_bounds__(1024) void eval_reduce_kernel(const int32_t *__rest
     }
 }
 
+// The same three numbers for a SUBSET of a test set's users, from the per-pair predictions and per-user metrics a series on the whole set
+// left behind (ure_eval_subset).  scratch.py:83-97 tests every epoch's ensemble on the shard's own test set AND on the total test set; the
+// reference builds the total set as the shards' test sets side by side (config.py:144-148), so the shard's set is the total set's rows of
+// the shard's users: same models, same pairs, same per-user rankings -- a fifth of the evaluation work at five shards was computing them
+// twice.  One workgroup per member, reduced in a fixed order.
+__global__ __launch_bounds__(1024) void eval_subset_kernel(const int32_t *__restrict__ sub_users, int32_t n_sub, const int32_t *__restrict__ sub_pairs,
+                                                           int32_t n_pairs, const float *__restrict__ pred, const float *__restrict__ rating,
+                                                           const int32_t *__restrict__ hits, const double *__restrict__ ndcg, int64_t pred_stride,
+                                                           int32_t n_users, double *__restrict__ out3)
+{
+    pred += (size_t)blockIdx.x * pred_stride;
+    hits += (size_t)blockIdx.x * n_users;
+    ndcg += (size_t)blockIdx.x * n_users;
+    out3 += (size_t)blockIdx.x * 3;
+    __shared__ double sn[1024], ss[1024];
+    __shared__ long long sh[1024], sr[1024];
+    double an = 0.0, as = 0.0;
+    long long ah = 0;
+    const long long ar = threadIdx.x == 0 ? n_pairs : 0;
+    for (int t = threadIdx.x; t < n_sub; t += 1024) {
+        const int u = sub_users[t];
+        an += ndcg[u];
+        ah += hits[u];
+    }
+    // (a thread per pair, not a thread per user walking its pairs: 50 workgroups of dependent loads took 44 us per call)
+    for (int t0 = threadIdx.x; t0 < n_pairs; t0 += 8 * 1024) {     // (eight pairs in flight per thread; added in index order)
+        float e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k * 1024;
+            const int p = t < n_pairs ? sub_pairs[t] : -1;
+            e[k] = p >= 0 ? pred[p] - rating[p] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) as += (double)(e[k] * e[k]);
+    }
+    sn[threadIdx.x] = an; ss[threadIdx.x] = as; sh[threadIdx.x] = ah; sr[threadIdx.x] = ar;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sn[threadIdx.x] += sn[threadIdx.x + o];
+            ss[threadIdx.x] += ss[threadIdx.x + o];
+            sh[threadIdx.x] += sh[threadIdx.x + o];
+            sr[threadIdx.x] += sr[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out3[0] = sr[0] > 0 ? sqrt(ss[0] / (double)sr[0]) : 0.0;
+        out3[1] = n_sub > 0 ? sn[0] / (double)n_sub : 0.0;
+        out3[2] = n_sub > 0 ? ((double)sh[0] / 10.0) / (double)n_sub : 0.0;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void merge_rows_kernel(T *__restrict__ dst, const T *__restrict__ src,
                                                             const int64_t *__restrict__ rows, int64_t n_rows, int width)
@@ -1102,6 +1156,16 @@ int ure_eval_series_own(const float *const *U_fixed, const float *const *V_fixed
     if (n_users > 0)
         launch_eval_users(off, n_users, n_wide, n_half, pred, rating, top_rating, log2_tab, hits, ndcg, n, n_series, st);
     hipLaunchKernelGGL(eval_reduce_kernel, dim3((unsigned)n_series), dim3(1024), 0, st, hits, ndcg, n_users, sse, n, out);
+    URE_HIP(hipGetLastError());
+    return 0;
+}
+
+int ure_eval_subset(const int32_t *sub_users, int32_t n_sub, const int32_t *sub_pairs, int32_t n_pairs, const float *pred, const float *rating,
+                    const int32_t *hits, const double *ndcg, int64_t pred_stride, int32_t n_users, int n_series, double *out, void *stream)
+{
+    URE_ARG(sub_users && sub_pairs && pred && rating && hits && ndcg && out && n_sub >= 0 && n_pairs >= 0 && n_users >= 0 && n_series > 0 && n_series <= 65535);
+    hipLaunchKernelGGL(eval_subset_kernel, dim3((unsigned)n_series), dim3(1024), 0, static_cast<hipStream_t>(stream), sub_users, n_sub, sub_pairs, n_pairs,
+                       pred, rating, hits, ndcg, pred_stride, n_users, out);
     URE_HIP(hipGetLastError());
     return 0;
 }

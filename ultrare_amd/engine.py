@@ -578,14 +578,25 @@ class TrainJob:
         main.wait_event(h['event'])
         return h['ev'].evaluate_series_own(fixed, h['own'], self.d, out, stream)
 
-    def evaluate_series(self, s, eval_set, fixed, out, stream=None):
+    def evaluate_series(self, s, eval_set, fixed, out, stream=None, subset=None):
         """scratch.py:83-97 for every epoch of shard s on `eval_set`: member e = the ensemble `fixed` + the shard's model
-        after epoch e, from whichever kind of snapshots the job keeps.  out: device float64 [epochs, 3]."""
+        after epoch e, from whichever kind of snapshots the job keeps.  out: device float64 [epochs, 3].
+        subset = (EvalSet.subset_of plan, out_sub [epochs, 3]): the same numbers for a subset of the set's users as well."""
         st = self.state[s]
         if self.snapshots == 'compact':
             sh = self.shards[s]
-            return eval_set.evaluate_series_compact(fixed, st['snap'], sh.row_slot(), st['U0'], st['V0'], st['snap_a'], sh.n_user, self.d, out, stream)
-        return eval_set.evaluate_series(fixed, st['snapU'], st['snapV'], self.d, out, stream)
+            return eval_set.evaluate_series_compact(fixed, st['snap'], sh.row_slot(), st['U0'], st['V0'], st['snap_a'], sh.n_user, self.d, out, stream,
+                                                    subset=subset)
+        return eval_set.evaluate_series(fixed, st['snapU'], st['snapV'], self.d, out, stream, subset=subset)
+
+    def evaluate_series_pair(self, s, test_ev, total_ev, fixed, out_test, out_total, stream=None):
+        """The two per-epoch series of scratch.py:83-97 -- the shard's own test set and the total test set.  Where the first is a subset of
+        the second (the reference builds the total set from the shards' sets: config.py:144-148) ONE series on the total set yields both."""
+        plan = test_ev.subset_of(total_ev)
+        if plan is None:
+            self.evaluate_series(s, test_ev, fixed, out_test, stream)
+            return self.evaluate_series(s, total_ev, fixed, out_total, stream)
+        return self.evaluate_series(s, total_ev, fixed, out_total, stream, subset=(plan, out_test))
 
     def materialize(self, stream=None):
         """Bring the lazily advanced rows (lazy_rows) up to date in the current tables."""
@@ -696,11 +707,54 @@ class EvalSet:
         self.sse = torch.zeros(SCORE_PARTIALS, dtype=torch.float64, device=dev)
         self.log2 = to(_LOG2_TAB)
         self.order = order
+        # host copies in the set's own order: what subset_of() compares
+        self._h_iid, self._h_rating, self._h_off = iid[order], rating[order], off
+        self._subsets = {}
         # the ranking of the ratings is a property of the test set: once, here
         self.top_rating = torch.empty(max(self.n_users, 1) * 10, dtype=torch.int32, device=dev)
         if self.n_users:
             nv.check(nv.lib().ure_eval_rank_ratings(nv.ptr(self.off), self.n_users, nv.ptr(self.rating), nv.ptr(self.top_rating),
                                                     nv.stream_handle()), 'ure_eval_rank_ratings')
+
+    def subset_of(self, total):
+        """This set as a subset of `total`: -> {'users': device int32 [n_users] (this set's users as indices into total's user order), 'n': n_users,
+        'pairs': device int32 [n] (its pairs as indices into total's pair order), 'n_pairs': n}
+        when every user of this set is in `total` with exactly the same (item, rating) rows in the same order -- the reference's total test
+        set is the shards' test sets side by side (config.py:144-148) --, else None.  Checked on the host once per pair of sets and kept
+        (the sets live with their loaders).  With a plan, a series on `total` also yields this set's three numbers (ure_eval_subset)
+        instead of a second series on the same models and pairs.  URE_EVAL_SUBSET=0: never."""
+        if os.environ.get('URE_EVAL_SUBSET', '1') == '0' or total is self or self.n == 0 or total.n == 0:
+            return None
+        key = id(total)
+        hit = self._subsets.get(key)
+        if hit is not None and hit[0]() is total:
+            return hit[1]
+        import weakref
+        plan = None
+        pos = getattr(total, '_user_pos', None)
+        if pos is None:
+            pos = np.full(int(total.users.max()) + 1, -1, dtype=np.int64)
+            pos[total.users] = np.arange(total.n_users)
+            total._user_pos = pos
+        mine = self.users.astype(np.int64)
+        if mine.max() < len(pos):
+            at = pos[mine]
+            cnt = np.diff(self._h_off).astype(np.int64)
+            if (at >= 0).all() and np.array_equal(cnt, np.diff(total._h_off).astype(np.int64)[at]):
+                # the rows of every user, side by side in this set's order: equal items and ratings, in the same order
+                src = np.repeat(total._h_off[at].astype(np.int64) - self._h_off[:-1].astype(np.int64), cnt) + np.arange(self.n, dtype=np.int64)
+                if np.array_equal(total._h_iid[src], self._h_iid) and np.array_equal(total._h_rating[src], self._h_rating):
+                    up = upload_many([at.astype(np.int32), src.astype(np.int32)], self.device)
+                    plan = {'users': up[0], 'n': int(self.n_users), 'pairs': up[1], 'n_pairs': int(self.n)}
+        self._subsets[key] = (weakref.ref(total), plan)
+        return plan
+
+    def _subset_after(self, subset, m, e0, st):
+        """ure_eval_subset on the m members a series call just left in the scratch buffers (subset = (plan of subset_of, out [E, 3]))."""
+        plan, out_sub = subset
+        b = self._series
+        nv.check(nv.lib().ure_eval_subset(nv.ptr(plan['users']), plan['n'], nv.ptr(plan['pairs']), plan['n_pairs'], nv.ptr(b['pred']), nv.ptr(self.rating),
+                                          nv.ptr(b['hits']), nv.ptr(b['ndcg']), self.n, self.n_users, m, nv.ptr(out_sub[e0]), st), 'ure_eval_subset')
 
     def evaluate(self, models, d, stream=None, top_k=10, out=None):
         """baseTest (utils.py:115-187) for an ensemble: `models` = list of (U, V) device
@@ -748,7 +802,7 @@ class EvalSet:
             self._series_cap = per_call
         return self._series, per_call
 
-    def evaluate_series(self, fixed, U_series, V_series, d, out, stream=None):
+    def evaluate_series(self, fixed, U_series, V_series, d, out, stream=None, subset=None):
         """scratch.py:83-97 for every epoch of a shard in four launches (ure_eval_series): member e of
         the series is the ensemble `fixed` + [(U_series[e], V_series[e])]; out[e] (device float64
         [E, 3]) receives its (rmse, ndcg, hr).  Nothing synchronises."""
@@ -771,9 +825,11 @@ class EvalSet:
                                        nv.ptr(b['sse']), nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating),
                                        self.n_wide, self.n_half, st),
                      'ure_eval_series')
+            if subset is not None:
+                self._subset_after(subset, m, e0, st)
         return out
 
-    def evaluate_series_compact(self, fixed, snap, row_slot, U0, V0, snap_a, n_user_rows, d, out, stream=None):
+    def evaluate_series_compact(self, fixed, snap, row_slot, U0, V0, snap_a, n_user_rows, d, out, stream=None, subset=None):
         """evaluate_series on COMPACT snapshots (ure_eval_series_compact): snap [E, n_active, d] holds the rows with
         interactions in the shard, row_slot maps a row id to its place in it (-1: the row is snap_a[e] * (U0 | V0)[row])."""
         E = int(snap.shape[0])
@@ -795,6 +851,8 @@ class EvalSet:
                                                self.n, d, nv.ptr(self.off), self.n_users, nv.ptr(self.log2), nv.ptr(b['base']), nv.ptr(b['pred']),
                                                nv.ptr(b['sse']), nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating),
                                                self.n_wide, self.n_half, st), 'ure_eval_series_compact')
+            if subset is not None:
+                self._subset_after(subset, m, e0, st)
         return out
 
     def evaluate_series_own(self, fixed, own, d, out, stream=None):

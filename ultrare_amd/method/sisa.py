@@ -362,12 +362,11 @@ class Sisa(Scratch):
                 pos = mine.index(i)
                 # all epochs of the shard at once: the ensembles differ in their last model only
                 res = res_all[pos]
-                for which, ev in enumerate((test_ev, total_ev)):
-                    h = early.get(i, (None, None))[which]
-                    if h is not None:
-                        job.finish_series(h, before, res[which])
-                    else:
-                        job.evaluate_series(pos, ev, before, res[which])
+                if early.get(i, (None, None))[0] is None:
+                    job.evaluate_series_pair(pos, test_ev, total_ev, before, res[0], res[1])      # (one series where the shard's set is a subset of the total set)
+                else:
+                    for which, ev in enumerate((test_ev, total_ev)):
+                        job.finish_series(early[i][which], before, res[which])
                 queued[i] = pos
         engine.mark('series_queued')
         # two copies for the whole call (a copy per shard and kind was a synchronisation each; tools/ab_host.py medians of 6:
