@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define URE_ABI_VERSION 6
+#define URE_ABI_VERSION 7
 #define URE_MAX_MODELS_PER_CALL 32
 #define URE_SCORE_PARTIALS 2048       /* length of ure_score's sse buffer */
 
@@ -158,6 +158,12 @@ typedef struct ure_job ure_job_t;   /* a set of shards trained side by side */
 
 /* Copies the n descriptors to the device (small hipMalloc owned by the job). */
 int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out);
+
+/* ABI 7.  The start tables of a job's shards (utils.py:31-40: MF.init_weight) from where the host's draws were uploaded into the job's
+ * padded tables, all shards in ONE launch: table i is src[i] [rows[i]][k] (dense) -> dst[i] [rows[i]][d] and, where dst2 and dst2[i]
+ * are not NULL, dst2[i] (the copy ure_shard.U0 / V0 keep for the closed form).  Columns [k, d) are not written.  (csrc/job_io.hip) */
+int ure_copy_rows_batch(int32_t n, const float *const *src, float *const *dst, float *const *dst2, const int64_t *rows, int32_t k, int32_t d,
+                        void *stream);
 int ure_job_destroy(ure_job_t *job);
 /* Number of optimizer steps shard `s` needs in total = epochs * ceil(N/B), and
  * the maximum over the job's shards (the number of ticks to run). */

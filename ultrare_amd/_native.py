@@ -11,7 +11,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('URE_LIB') or os.path.join(_PKG, 'libultrare_hip.so')      # URE_LIB: experiment builds (tools/) only
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_MODELS_PER_CALL = 32
 
 _vp = ctypes.c_void_p
@@ -48,6 +48,7 @@ _PROTOTYPES = {
                                        ctypes.c_char_p, ctypes.c_int]),
     'ure_job_create': (ctypes.c_int, [ctypes.POINTER(UreShard), ctypes.c_int, ctypes.POINTER(_vp)]),
     'ure_job_destroy': (ctypes.c_int, [_vp]),
+    'ure_copy_rows_batch': (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     'ure_job_shard_steps': (_i64, [_vp, ctypes.c_int]),
     'ure_job_ticks': (_i64, [_vp]),
     'ure_job_train': (ctypes.c_int, [_vp, _i64, _i64, _vp]),

@@ -119,6 +119,42 @@ void one_perm(uint64_t seed, int64_t n, int32_t *r, std::vector<uint32_t> &z)
     }
 }
 
+// The INVERSE of one_perm's permutation (inv[r[b]] = b), without building r: the shuffle is the product of the transpositions
+// (i, i + z[i]), i = 0 .. n-2, applied to the identity from the left end; its inverse is the same transpositions applied in the
+// opposite order.  The partners z are all drawn before the first swap, so the chain can run from i = n-2 down to 0.  A batch tag
+// is inv / batch: one sequential pass instead of a second scattered one (out[r[b]] = b / batch missed the L1 on every store).
+URE_HOST_CLONES static void tags_of_positions(const int32_t *inv, int64_t n, int32_t batch, uint16_t *out)
+{
+    // floor(v / batch) through the rounded reciprocal: v < 2^31 and |v * RN(1 / batch) - v / batch| < 2^-21, so the truncated
+    // product is the quotient or one beside it; the remainder says which
+    const double rb = 1.0 / (double)batch;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t v = (uint32_t)inv[i];
+        uint32_t q = (uint32_t)((double)v * rb);
+        const int32_t r = (int32_t)(v - q * (uint32_t)batch);
+        q += (uint32_t)(r >= batch) - (uint32_t)(r < 0);
+        out[i] = (uint16_t)q;
+    }
+}
+
+void one_perm_tags(uint64_t seed, int64_t n, int32_t batch, int32_t *inv, std::vector<uint32_t> &z, uint16_t *out)
+{
+    for (int64_t i = 0; i < n; ++i) inv[i] = (int32_t)i;
+    if (n >= 2) {
+        Mt19937 mt(seed);
+        z.resize((size_t)n);
+        fill_partners(mt.st, &mt.idx, z.data(), n - 1, n);
+        // (two chains interleaved in one loop were tried: no faster -- the chain is not latency bound)
+        for (int64_t i = n - 2; i >= 0; --i) {
+            const int64_t j = i + (int64_t)z[(size_t)i];
+            const int32_t sav = inv[i];
+            inv[i] = inv[j];
+            inv[j] = sav;
+        }
+    }
+    tags_of_positions(inv, n, batch, out);
+}
+
 }  // namespace
 
 extern "C" int ure_host_randperm(const int64_t *seeds, int n_perms, int64_t n, int32_t *out, int n_threads)
@@ -156,16 +192,9 @@ extern "C" int ure_host_randperm_tags(const int64_t *seeds, int n_perms, int64_t
     auto work = [&]() {
         std::vector<uint32_t> z;
         std::vector<int32_t> r((size_t)n);
-        for (int t = next.fetch_add(1); t < n_perms; t = next.fetch_add(1)) {
-            one_perm((uint64_t)seeds[t], n, r.data(), z);
-            // position b of the epoch trains file row r[b]: that row's step is b / batch
-            uint16_t *out = tags + (size_t)t * n;
-            int64_t b = 0;
-            for (uint32_t step = 0; b < n; ++step) {
-                const int64_t end = std::min<int64_t>(n, b + batch);
-                for (; b < end; ++b) out[r[(size_t)b]] = (uint16_t)step;
-            }
-        }
+        // file row f trains at position inv[f] of the epoch: its step is inv[f] / batch
+        for (int t = next.fetch_add(1); t < n_perms; t = next.fetch_add(1))
+            one_perm_tags((uint64_t)seeds[t], n, batch, r.data(), z, tags + (size_t)t * n);
     };
     if (nt == 1) {
         work();

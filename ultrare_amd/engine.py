@@ -153,6 +153,7 @@ def build_shards(triples, n_user, n_item, device=None, keep_positions=False, uni
             if getattr(e, 'code', None) == -2:             # (-3: a shard beyond 2^31 slots -- reported as it is)
                 raise ValueError(f'user or item id outside [0, n_user) x [0, n_item): {e}') from None
             raise
+        mark('w: layouts built (native)')
         n_slots, n_active = built[0], built[1]
         n_units = built[2] if d_units else [-1] * S
         out, ready, pinned = _upload_layouts(stage, host, off, cols, n_slots, n_active, n_units, d_units, n_user, n_item, dev, on_gpu, keep_positions)
@@ -177,6 +178,7 @@ def _upload_layouts(stage, host, off, cols, n_slots, n_active, n_units, d_units,
     pinned = stage.is_pinned() and on_gpu
     for s in range(S):
         blob[d_off[s]:d_off[s] + used[s]].copy_(stage[off[s]:off[s] + used[s]], non_blocking=pinned)
+    mark('w: layouts copies queued')
     # engine-side scratch: batch tags (0xFFFF matches no batch) and the stages of the inverse permutation
     t_words = [(al(3 * int(k)), al(len(c[0]))) for k, c in zip(n_slots, cols)]       # three tag buffers (touch_mode 2 prepares two epochs ahead)
     z_words = [(al(len(c[0])), al(max(((len(c[0]) + 2047) // 2048) * ((len(c[0]) + 2047) // 2048 + 1), 1) if (len(c[0]) + 2047) // 2048 <= 1024 else 1))
@@ -184,6 +186,7 @@ def _upload_layouts(stage, host, off, cols, n_slots, n_active, n_units, d_units,
     tags = torch.full((sum(a + b for a, b in t_words),), -1, dtype=torch.int16, device=dev)
     zeros = torch.zeros(sum(a + b for a, b in z_words), dtype=torch.int32, device=dev)
     out, t_at, z_at = [], 0, 0
+    mark('w: layouts fills queued')
     for s, (uid, iid, rating) in enumerate(cols):
         sh = object.__new__(ShardData)
         n, k = len(uid), int(n_slots[s])
@@ -216,6 +219,7 @@ def _upload_layouts(stage, host, off, cols, n_slots, n_active, n_units, d_units,
     # whoever trains on a layout from another stream (layouts may be built on a worker thread, whose current stream is the
     # device's default stream) waits for this event first: TrainJob does
     ready = None
+    mark('w: layouts views made')
     if on_gpu:
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
@@ -234,6 +238,10 @@ class ShardData:
 
     _count_lock = __import__('threading').Lock()
     built = 0            # layouts built (and uploaded) by this process: lets a measurement show that its timed call paid for them
+
+    def ptr(self, name):
+        """Device address of one of the layout's arrays."""
+        return nv.ptr(getattr(self, name))
 
     def row_slot(self):
         """Device int32 [n_user + n_item]: a row's index in the schedule when it is one of the n_active rows with
@@ -294,6 +302,27 @@ def _closed_form_scalars(lr_host, steps, lam, mu):
     return np.asarray(out, dtype=np.float32)
 
 
+class _States:
+    """TrainJob.state: per shard the views of the job's device memory ({'U', 'V', 'mU', 'mV', 'perm', 'sse', 'snap' ...}), made when first asked for."""
+
+    def __init__(self, n, make):
+        self._n, self._make, self._got = n, make, {}
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, s):
+        s = s + self._n if s < 0 else s
+        if not 0 <= s < self._n:
+            raise IndexError(s)
+        if s not in self._got:
+            self._got[s] = self._make(s)
+        return self._got[s]
+
+    def __iter__(self):
+        return (self[s] for s in range(self._n))
+
+
 class TrainJob:
     """A set of shards trained side by side, one optimizer step of each per launch.
 
@@ -350,15 +379,19 @@ class TrainJob:
         small = [lr_host] + ([closed_form_scalars(lr_host, st_, float(np.float32(lam)), float(np.float32(momentum))) for st_ in steps_of] if self.snapshots else [])
         small = upload_many(small, dev)                  # the learning rates and every shard's closed-form scalars: one copy
         self.lr = small[0]
-        self.state = []
         self._chunks = []        # per shard whose permutations are uploaded in chunks: [(first epoch after the chunk, event), ...]
         descs = (nv.UreShard * len(shards))()
         mark('job: start')
+        cur = torch.cuda.current_stream(dev) if torch.device(dev).type == 'cuda' else None
+        seen = set()
         for sh in shards:
-            if sh.ready is not None:
-                torch.cuda.current_stream(dev).wait_event(sh.ready)
+            if sh.ready is not None and id(sh.ready) not in seen:
+                seen.add(id(sh.ready))
+                cur.wait_event(sh.ready)
         # every float table of every shard from ONE zero-filled allocation (a request of 16 shards made ~130 small allocations
-        # and fills here: 8-12 ms of host time beside 16 busy worker threads), the snapshots from another
+        # and fills here: 8-12 ms of host time beside 16 busy worker threads), the snapshots from another.  The descriptors are
+        # filled from ADDRESSES (base + offset); the views of the tables are made when somebody asks for them (self.state), which a
+        # request does after its launches are queued.
         al = lambda x: (x + 63) // 64 * 64
         d = self.d
         sizes = [(2 * sh.n_user * d, 2 * sh.n_item * d, sh.n_user * d, sh.n_item * d, self.epochs * sh.n_user,
@@ -366,44 +399,52 @@ class TrainJob:
         pool = torch.zeros(sum(al(x) for sz in sizes for x in sz), dtype=torch.float32, device=dev)
         snap_rows = [(sh.n_active if self.snapshots == 'compact' else sh.n_user + sh.n_item) if self.snapshots else 0 for sh in shards]
         snap_pool = torch.empty(sum(al(self.epochs * r * d) for r in snap_rows), dtype=torch.float32, device=dev) if self.snapshots else None
+        self._pool, self._snap_pool, self._small = pool, snap_pool, small
+        base, snap_base = pool.data_ptr(), (snap_pool.data_ptr() if snap_pool is not None else 0)
         at = snap_at = 0
+        mark('job: pools')
+        self._offs, self._snap_offs, self._perms, self._init_src = [], [], [], []
+        copies = []                                   # (src, rows, dst, dst2) of the start tables: one launch below
         for s, (sh, (U0, V0), perm) in enumerate(zip(shards, inits, perms)):
-            for t in (U0, V0):
-                if getattr(t, '_ure_event', None) is not None:          # uploaded on a side stream (rng.shard_draws_async)
-                    torch.cuda.current_stream(dev).wait_event(t._ure_event)
-                    t.record_stream(torch.cuda.current_stream(dev))
-            U0 = torch.as_tensor(U0, dtype=torch.float32)
-            V0 = torch.as_tensor(V0, dtype=torch.float32)
-            assert U0.shape == (sh.n_user, self.k) and V0.shape == (sh.n_item, self.k)
-            views = []
+            srcs = []
+            for t, n_rows in ((U0, sh.n_user), (V0, sh.n_item)):
+                ev = getattr(t, '_ure_event', None)
+                if ev is not None and id(ev) not in seen:               # uploaded on a side stream (rng.shard_draws_async)
+                    seen.add(id(ev))
+                    cur.wait_event(ev)
+                if ev is not None:
+                    t.record_stream(cur)
+                t = torch.as_tensor(t, dtype=torch.float32)
+                assert t.shape == (n_rows, self.k)
+                if t.device != torch.device(dev) or not t.is_contiguous():
+                    t = t.to(dev, non_blocking=True).contiguous()
+                srcs.append(t)
+            self._init_src.append(srcs)                                 # (alive until the copy below has run: released by close())
+            off = []
             for x in sizes[s]:
-                views.append(pool[at:at + x])
+                off.append(at)
                 at += al(x)
-            U, V = views[0].view(2, sh.n_user, d), views[1].view(2, sh.n_item, d)
-            mU, mV = views[2].view(sh.n_user, d), views[3].view(sh.n_item, d)
-            U[0, :, :self.k] = U0.to(dev, non_blocking=True)
-            V[0, :, :self.k] = V0.to(dev, non_blocking=True)
-            U0d, V0d = None, None
+            self._offs.append(off)
+            pU, pV, pmU, pmV, psse, pU0, pV0 = (base + 4 * o for o in off)
             perm = torch.as_tensor(perm)
             if getattr(perm, '_ure_chunks', None) is not None:      # still arriving in chunks of epochs (rng.shard_draws_async)
                 self._chunks.append(list(perm._ure_chunks))
             elif getattr(perm, '_ure_event', None) is not None:     # uploaded on a side stream (rng.epoch_perms_async)
-                torch.cuda.current_stream(dev).wait_event(perm._ure_event)
+                cur.wait_event(perm._ure_event)
             assert perm.shape == (self.epochs, sh.N), f'perm of shard {s} must be [epochs, N]'
             # int16: not permutations but the batch tags the host made of them (rng.epoch_tags; struct ure_shard: file_tags)
             as_tags = perm.dtype == torch.int16
             perm = perm.to(device=dev, dtype=torch.int16 if as_tags else torch.int32).contiguous()
-            sse = views[4].view(self.epochs, sh.n_user)
-            self.state.append({'U': U, 'V': V, 'mU': mU, 'mV': mV, 'perm': perm, 'sse': sse})
+            self._perms.append(perm)
             D = descs[s]
             for name in ('ent_oid', 'ent_r', 'ent_tag', 'ent_src', 'file_tag', 'inv_stage', 'inv_off', 'sched'):
-                setattr(D, name, nv.ptr(getattr(sh, name)))
+                setattr(D, name, sh.ptr(name))
             if self.index:
                 # no work units: the step's items come from the epoch's index.  Rows by weight class (slots per step on average)
                 nnz, st_s = sh._sched_host[:min(sh.n_active, INDEX_HEAVY_MAX), 3], steps_all[s]
                 D.n_multi = int(np.count_nonzero(nnz >= INDEX_HEAVY_SLOTS * st_s))
                 D.n_split = min(D.n_multi, int(np.count_nonzero(nnz >= INDEX_SPLIT_SLOTS * st_s)))
-                units, n_units = sh.sched, 0
+                units, n_units = sh.ptr('sched'), 0
             elif self.touch:
                 # epochs of several windows (more than 64 steps): a row of up to TOUCH_ROW_PASSES scan passes stays ONE work item -- its
                 # lane group skips the passes without a slot of the step (csrc/mf_touch.h: pass masks) -- instead of one unit per pass
@@ -411,40 +452,40 @@ class TrainJob:
                 units, n_units, n_multi = sh.units(self.d, touch=True, min_passes=TOUCH_ROW_PASSES if long_epochs else 1,
                                                    unit_passes=TOUCH_UNIT_PASSES if long_epochs else 1)
                 D.n_multi = n_multi
+                units = nv.ptr(units)
             else:
                 units = sh.units(self.d)
                 n_units = units.shape[0]
-            D.units, D.n_units, D.n_active, D.n_slots = nv.ptr(units), n_units, sh.n_active, sh.n_slots
-            D.U[0], D.U[1] = nv.ptr(U[0]), nv.ptr(U[1])
-            D.V[0], D.V[1] = nv.ptr(V[0]), nv.ptr(V[1])
-            D.mU, D.mV = nv.ptr(mU), nv.ptr(mV)
-            D.perm, D.lr, D.sse = (None if as_tags else nv.ptr(perm)), nv.ptr(self.lr), nv.ptr(sse)
+                units = nv.ptr(units)
+            D.units, D.n_units, D.n_active, D.n_slots = units, n_units, sh.n_active, sh.n_slots
+            D.U[0], D.U[1] = pU, pU + 4 * sh.n_user * d
+            D.V[0], D.V[1] = pV, pV + 4 * sh.n_item * d
+            D.mU, D.mV = pmU, pmV
+            D.perm, D.lr, D.sse = (None if as_tags else nv.ptr(perm)), nv.ptr(self.lr), psse
             D.file_tags = nv.ptr(perm) if as_tags else None
             D.N, D.n_user, D.n_item, D.d = sh.N, sh.n_user, sh.n_item, self.d
             D.batch, D.epochs = self.batch, self.epochs
             D.lam, D.mu = float(lam), float(momentum)
             D.touch_mode = (3 if self.index else 2 if self.ahead else 1) if self.touch else 0
+            self._snap_offs.append(snap_at)
             if self.snapshots:
-                snap_a = small[1 + s]
-                self.state[-1].update(snap_a=snap_a)
-                D.snap_a = nv.ptr(snap_a)
+                D.snap_a = small[1 + s].data_ptr()
                 if self.snapshots == 'compact':
-                    snap = snap_pool[snap_at:snap_at + self.epochs * sh.n_active * d].view(self.epochs, sh.n_active, d)
-                    self.state[-1].update(snap=snap)
-                    D.snap, D.row_slot = nv.ptr(snap), nv.ptr(sh.row_slot())
+                    D.snap, D.row_slot = snap_base + 4 * snap_at, sh.ptr('_row_slot')
                 else:
-                    nU = self.epochs * sh.n_user * d
-                    snapU = snap_pool[snap_at:snap_at + nU].view(self.epochs, sh.n_user, d)
-                    snapV = snap_pool[snap_at + nU:snap_at + nU + self.epochs * sh.n_item * d].view(self.epochs, sh.n_item, d)
-                    self.state[-1].update(snapU=snapU, snapV=snapV)
-                    D.snapU, D.snapV = nv.ptr(snapU), nv.ptr(snapV)
+                    D.snapU, D.snapV = snap_base + 4 * snap_at, snap_base + 4 * (snap_at + self.epochs * sh.n_user * d)
                 snap_at += al(self.epochs * snap_rows[s] * d)
             if self.lazy_rows:
-                U0d, V0d = views[5].view(sh.n_user, d), views[6].view(sh.n_item, d)
-                U0d.copy_(U[0])
-                V0d.copy_(V[0])
-                self.state[-1].update(U0=U0d, V0=V0d)
-                D.U0, D.V0, D.lr_host, D.lazy_rows = nv.ptr(U0d), nv.ptr(V0d), lr_host.ctypes.data, 1
+                D.U0, D.V0, D.lr_host, D.lazy_rows = pU0, pV0, lr_host.ctypes.data, 1
+            copies += [(srcs[0].data_ptr(), sh.n_user, pU, pU0 if self.lazy_rows else 0), (srcs[1].data_ptr(), sh.n_item, pV, pV0 if self.lazy_rows else 0)]
+        # the start tables into buffer 0 (and the closed form's copy), every shard's in one launch
+        n_c = len(copies)
+        src_a, dst_a, dst2_a = (ctypes.c_void_p * n_c)(*[c[0] for c in copies]), (ctypes.c_void_p * n_c)(*[c[2] for c in copies]), \
+            (ctypes.c_void_p * n_c)(*[c[3] or None for c in copies])
+        rows_a = (ctypes.c_int64 * n_c)(*[c[1] for c in copies])
+        nv.check(nv.lib().ure_copy_rows_batch(n_c, src_a, dst_a, dst2_a if self.lazy_rows else None, rows_a, self.k, d, nv.stream_handle()), 'ure_copy_rows_batch')
+        self._init_src = None             # (allocator: their memory is reused only after the streams they were recorded on have passed this point)
+        self.state = _States(len(shards), self._state_of)
         self._descs = descs
         self._job = ctypes.c_void_p()
         mark('job: tables allocated, descriptors filled')
@@ -453,6 +494,25 @@ class TrainJob:
         self.ticks = int(nv.lib().ure_job_ticks(self._job))
         self.shard_steps = [int(nv.lib().ure_job_shard_steps(self._job, s)) for s in range(len(shards))]
         self.done = 0
+
+    def _state_of(self, s):
+        sh, d, pool = self.shards[s], self.d, self._pool
+        o = self._offs[s]
+        st = {'U': pool[o[0]:o[0] + 2 * sh.n_user * d].view(2, sh.n_user, d), 'V': pool[o[1]:o[1] + 2 * sh.n_item * d].view(2, sh.n_item, d),
+              'mU': pool[o[2]:o[2] + sh.n_user * d].view(sh.n_user, d), 'mV': pool[o[3]:o[3] + sh.n_item * d].view(sh.n_item, d),
+              'perm': self._perms[s], 'sse': pool[o[4]:o[4] + self.epochs * sh.n_user].view(self.epochs, sh.n_user)}
+        if self.lazy_rows:
+            st.update(U0=pool[o[5]:o[5] + sh.n_user * d].view(sh.n_user, d), V0=pool[o[6]:o[6] + sh.n_item * d].view(sh.n_item, d))
+        if self.snapshots:
+            at, sp = self._snap_offs[s], self._snap_pool
+            st.update(snap_a=self._small[1 + s])
+            if self.snapshots == 'compact':
+                st.update(snap=sp[at:at + self.epochs * sh.n_active * d].view(self.epochs, sh.n_active, d))
+            else:
+                nU = self.epochs * sh.n_user * d
+                st.update(snapU=sp[at:at + nU].view(self.epochs, sh.n_user, d),
+                          snapV=sp[at + nU:at + nU + self.epochs * sh.n_item * d].view(self.epochs, sh.n_item, d))
+        return st
 
     def steps_per_epoch(self, s):
         return self.shard_steps[s] // self.epochs

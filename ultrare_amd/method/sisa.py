@@ -65,6 +65,7 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
         from ..read import shard_layouts
         layouts = rng.worker_pool().submit(shard_layouts, [as_loader(train_dlist[i]) for i in own_ids], n_user, n_item, engine._device(), k)
     streams = rng.shard_streams(len(ids), n_user, n_item, k, epochs, True) if on_device else None
+    engine.mark('streams')
     if streams is not None:
         # every shard's start state by skip-ahead, then the owned shards' draws (init, seeds, permutations, upload) on a few worker
         # threads (rng.draws_batch_async): the model inits first, then the permutation chunks round robin
@@ -100,6 +101,7 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
             for sp in specs:
                 sp['threads'] = max(2, PERM_THREADS // W)
             futures = dict(zip(order, rng.draws_batch_async(specs, W, gate)))
+            engine.mark('draws submitted')
             shards = dict(zip(own_ids, layouts.result()))
         finally:
             gate.set()

@@ -163,6 +163,8 @@ def shard_layouts(loaders, n_user, n_item, device=None, units_for=None):
                 built = list(_unit_pool().map(lambda sh: sh.units_host(d), need)) if len(need) > 1 else [need[0].units_host(d)]
                 for sh, (u, n_units, n_rows), dev_u in zip(need, built, upload_many([b[0] for b in built], need[0].device)):
                     sh._units[(d, False)] = (dev_u, n_units, n_rows)
+    from .engine import mark
+    mark('w: shard_layouts returns')
     return out
 
 

@@ -429,10 +429,13 @@ class _DrawsTask:
 
     def init(self):
         start_state, n_user, n_item, k, epochs, with_total_test = self.args[:6]
+        from .engine import mark
+        mark('w: init start')
         g = torch.Generator()
         g.set_state(start_state)
         init = mf_init(n_user, n_item, k, generator=g)
         self.seeds = epoch_seeds(epochs, with_total_test, generator=g)
+        mark('w: init drawn')
         if self.device is not None:
             # the init tables go up first, on a side stream of this worker
             dev = self.device
@@ -469,6 +472,7 @@ class _DrawsTask:
             nv.check(L.ure_host_randperm(sd.ctypes.data, len(sd), n_rows, self.host.data_ptr(), threads), 'ure_host_randperm')
             self.perms_value = self.host
             return
+        from .engine import mark
         dev, st, on_dev, host = self.device, self.stream, self.on_dev, self.host
         sd_ptr, host_ptr, row_bytes = sd.ctypes.data, host.data_ptr(), (2 if self.tags_batch else 4) * n_rows
         self.perms_value = on_dev
@@ -491,6 +495,7 @@ class _DrawsTask:
                 ev.record(st)
             slot[0] = ev
             flag.set()
+            mark(f'w: chunk to {c1}')
             c0 = c1
             yield
 
