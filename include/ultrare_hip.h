@@ -164,6 +164,11 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out);
  * are not NULL, dst2[i] (the copy ure_shard.U0 / V0 keep for the closed form).  Columns [k, d) are not written.  (csrc/job_io.hip) */
 int ure_copy_rows_batch(int32_t n, const float *const *src, float *const *dst, float *const *dst2, const int64_t *rows, int32_t k, int32_t d,
                         void *stream);
+
+/* ABI 7.  The per-epoch training loss of a job's shards (scratch.py:72-77 accumulates it batch by batch): ure_shard.sse holds the squared
+ * errors per epoch and USER ([epochs][n_user] float32, each owner adds its batches' share); out[i][e] = their sum over the users of
+ * shard i in double, always in the same order, all shards in one launch.  sse[i], out: device memory.  (csrc/job_io.hip)             */
+int ure_epoch_sse_batch(int32_t n, const float *const *sse, const int64_t *n_user, int32_t epochs, double *out, void *stream);
 int ure_job_destroy(ure_job_t *job);
 /* Number of optimizer steps shard `s` needs in total = epochs * ceil(N/B), and
  * the maximum over the job's shards (the number of ticks to run). */

@@ -49,6 +49,7 @@ _PROTOTYPES = {
     'ure_job_create': (ctypes.c_int, [ctypes.POINTER(UreShard), ctypes.c_int, ctypes.POINTER(_vp)]),
     'ure_job_destroy': (ctypes.c_int, [_vp]),
     'ure_copy_rows_batch': (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    'ure_epoch_sse_batch': (ctypes.c_int, [_i32, _vp, _vp, _i32, _vp, _vp]),
     'ure_job_shard_steps': (_i64, [_vp, ctypes.c_int]),
     'ure_job_ticks': (_i64, [_vp]),
     'ure_job_train': (ctypes.c_int, [_vp, _i64, _i64, _vp]),

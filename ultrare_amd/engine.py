@@ -14,6 +14,7 @@ HBM layout of one shard:
   U[2][n_user][d] V[2][n_item][d] f32 ping-pong weights ; mU, mV momentum
   perm[epochs][N] i32 ; lr[epochs] f32 ; sse[epochs][n_user] f32 (per-user squared error)
 """
+import contextlib
 import ctypes
 import os
 
@@ -52,6 +53,19 @@ def mark(label):
     if HOST_TRACE is not None:
         import time
         HOST_TRACE.append((label, time.perf_counter()))
+
+
+_SIDE_STREAMS = {}
+
+
+def side_streams(dev, n):
+    """n HIP streams beside the current one, kept per device (independent chains of short launches -- the test series of a
+    request's shards -- run on them side by side)."""
+    key = str(torch.device(dev))
+    have = _SIDE_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(dev))
+    return have[:n]
 
 
 def to_device_async(arr, dev):
@@ -117,115 +131,147 @@ def _device():
 
 def build_shards(triples, n_user, n_item, device=None, keep_positions=False, units_for=None):
     """The HBM layouts of the shards of one call: triples = [(uid, iid, rating)] -> [ShardData].
-    ONE native call builds every layout, side by side on host threads, packed into one pinned staging buffer (pooled);
-    each goes up in one asynchronous copy on the current stream into its part of one device allocation, and the
-    engine-side scratch of all shards (batch tags, inverse-permutation stages) comes from two fills.  units_for = a table width k:
-    the work units of that width are built by the same native call and travel in the same copies (ShardData.units finds them).  From pageable numpy
-    arrays, shard after shard, the same 22 MB of a 5-shard ml-1m call took 9-10 ms of a 20 ms Sisa.learn (profiles/r03/NOTES.md)."""
-    from . import rng
-    n_user, n_item = int(n_user), int(n_item)
-    dev = device or _device()
-    on_gpu = torch.device(dev).type == 'cuda'
-    rows = n_user + n_item
-    cols = []
-    for uid, iid, rating in triples:
-        uid, iid, rating = np.asarray(uid), np.asarray(iid), np.asarray(rating)
-        n = len(uid)
-        if n == 0:
-            raise ValueError('a shard needs at least one interaction')
-        if not (len(iid) == n and len(rating) == n):
-            raise ValueError('uid / iid / rating lengths differ')
-        # (ids outside [0, n_user) x [0, n_item) are refused by the native builder, which walks the arrays anyway)
-        cols.append((uid, iid, rating))
-    S = len(cols)
-    al = lambda x: (x + 7) // 8 * 8                              # every array starts on a 32-byte boundary
-    d_units = pad_dim(int(units_for)) if units_for else 0
-    words = [al(nv.layout_region_words(len(c[0]), n_user, n_item) + (nv.units_capacity_words(len(c[0]), n_user, n_item, d_units) if d_units else 0))
-             for c in cols]
-    stage = rng.STAGING.take((sum(words),), torch.int32)
-    host = stage.numpy()
-    off = np.concatenate([[0], np.cumsum(words)]).astype(np.int64)
-    handed_back = False
-    try:
+    ONE native call builds every layout, side by side on host threads, packed into one pinned staging buffer (pooled); all of them go up
+    in ONE asynchronous copy into one device allocation, and the engine-side scratch of all shards (batch tags, inverse-permutation
+    stages) comes from two fills.  units_for = a table width k: the work units of that width are built by the same native call and
+    travel in the same copy (ShardData.units finds them).  From pageable numpy arrays, shard after shard, the same 22 MB of a 5-shard
+    ml-1m call took 9-10 ms of a 20 ms Sisa.learn (profiles/r03/NOTES.md)."""
+    return LayoutPlan(triples, n_user, n_item, device, units_for).build(keep_positions)
+
+
+class LayoutPlan:
+    """build_shards in pieces that a request overlaps: __init__ checks the triples and takes the host staging buffer; allocate() (on
+    the request's own thread and stream) makes every device allocation and fill from UPPER BOUNDS of the slot counts -- nothing in it
+    waits for the layouts --; build() (any thread: a worker of the request, started BEFORE allocate()) runs the native builder, waits
+    for allocate(), queues the one copy and returns the ShardData, which hold ADDRESSES; the tensor views of a layout's arrays are
+    made when somebody asks for them."""
+
+    def __init__(self, triples, n_user, n_item, device=None, units_for=None):
+        from . import rng
+        self.n_user, self.n_item = int(n_user), int(n_item)
+        self.dev = dev = device or _device()
+        self.on_gpu = torch.device(dev).type == 'cuda'
+        cols = []
+        for uid, iid, rating in triples:
+            uid, iid, rating = np.asarray(uid), np.asarray(iid), np.asarray(rating)
+            n = len(uid)
+            if n == 0:
+                raise ValueError('a shard needs at least one interaction')
+            if not (len(iid) == n and len(rating) == n):
+                raise ValueError('uid / iid / rating lengths differ')
+            # (ids outside [0, n_user) x [0, n_item) are refused by the native builder, which walks the arrays anyway)
+            cols.append((uid, iid, rating))
+        self.cols = cols
+        al = lambda x: (x + 7) // 8 * 8                              # every array starts on a 32-byte boundary
+        self.d_units = pad_dim(int(units_for)) if units_for else 0
+        self.words = [al(nv.layout_region_words(len(c[0]), self.n_user, self.n_item) +
+                         (nv.units_capacity_words(len(c[0]), self.n_user, self.n_item, self.d_units) if self.d_units else 0)) for c in cols]
+        self.off = np.concatenate([[0], np.cumsum(self.words)]).astype(np.int64)
+        self.stage = rng.STAGING.take((int(self.off[-1]),), torch.int32)
+        self._owner = __import__('threading').current_thread()
+        self._allocated = __import__('threading').Event()
+        self._alloc_error = None
+
+    def allocate(self):
+        from . import rng
+        cols, dev, al = self.cols, self.dev, (lambda x: (x + 7) // 8 * 8)
         try:
-            built = nv.build_layouts(cols, n_user, n_item, [host[off[s]:off[s + 1]] for s in range(S)], threads=min(S, rng.host_cpus()), units_d=d_units)
-        except nv.NativeError as e:
-            if getattr(e, 'code', None) == -2:             # (-3: a shard beyond 2^31 slots -- reported as it is)
-                raise ValueError(f'user or item id outside [0, n_user) x [0, n_item): {e}') from None
+            self.blob = torch.empty(int(self.off[-1]), dtype=torch.int32, device=dev)
+            # engine-side scratch: batch tags (0xFFFF matches no batch; three buffers: touch_mode 2 prepares two epochs ahead) and
+            # the stages of the inverse permutation.  Sized for the most slots a shard of n interactions can have.
+            self.t_words = [(al(3 * nv.layout_capacity(len(c[0]), self.n_user, self.n_item)), al(len(c[0]))) for c in cols]
+            self.z_words = [(al(len(c[0])), al(max(((len(c[0]) + 2047) // 2048) * ((len(c[0]) + 2047) // 2048 + 1), 1) if (len(c[0]) + 2047) // 2048 <= 1024 else 1))
+                            for c in cols]
+            self.tags = torch.full((sum(a + b for a, b in self.t_words),), -1, dtype=torch.int16, device=dev)
+            self.zeros = torch.zeros(sum(a + b for a, b in self.z_words), dtype=torch.int32, device=dev)
+            self.allocated = None
+            if self.on_gpu:
+                self.allocated = torch.cuda.Event()
+                self.allocated.record(torch.cuda.current_stream(dev))
+        except BaseException as e:
+            self._alloc_error = e
             raise
-        mark('w: layouts built (native)')
-        n_slots, n_active = built[0], built[1]
-        n_units = built[2] if d_units else [-1] * S
-        out, ready, pinned = _upload_layouts(stage, host, off, cols, n_slots, n_active, n_units, d_units, n_user, n_item, dev, on_gpu, keep_positions)
-        rng.STAGING.give(stage, ready if pinned else None)
-        handed_back = True
-    finally:
-        if not handed_back:
-            rng.STAGING.give(stage, None)                  # whatever went wrong, the pooled staging buffer goes back
-    with ShardData._count_lock:
-        ShardData.built += S
-    return out
+        finally:
+            self._allocated.set()
+        return self
 
-
-def _upload_layouts(stage, host, off, cols, n_slots, n_active, n_units, d_units, n_user, n_item, dev, on_gpu, keep_positions):
-    from . import rng
-    S, rows = len(cols), n_user + n_item
-    al = lambda x: (x + 7) // 8 * 8
-    units_at = [al(3 * int(k) + 5 * rows) for k in n_slots]                       # where a shard's units start inside its region (when built)
-    used = [a + (al(4 * int(u)) if u > 0 else 0) for a, u in zip(units_at, n_units)]
-    d_off = np.concatenate([[0], np.cumsum(used)]).astype(np.int64)
-    blob = torch.empty(int(d_off[-1]), dtype=torch.int32, device=dev)
-    pinned = stage.is_pinned() and on_gpu
-    for s in range(S):
-        blob[d_off[s]:d_off[s] + used[s]].copy_(stage[off[s]:off[s] + used[s]], non_blocking=pinned)
-    mark('w: layouts copies queued')
-    # engine-side scratch: batch tags (0xFFFF matches no batch) and the stages of the inverse permutation
-    t_words = [(al(3 * int(k)), al(len(c[0]))) for k, c in zip(n_slots, cols)]       # three tag buffers (touch_mode 2 prepares two epochs ahead)
-    z_words = [(al(len(c[0])), al(max(((len(c[0]) + 2047) // 2048) * ((len(c[0]) + 2047) // 2048 + 1), 1) if (len(c[0]) + 2047) // 2048 <= 1024 else 1))
-               for c in cols]
-    tags = torch.full((sum(a + b for a, b in t_words),), -1, dtype=torch.int16, device=dev)
-    zeros = torch.zeros(sum(a + b for a, b in z_words), dtype=torch.int32, device=dev)
-    out, t_at, z_at = [], 0, 0
-    mark('w: layouts fills queued')
-    for s, (uid, iid, rating) in enumerate(cols):
-        sh = object.__new__(ShardData)
-        n, k = len(uid), int(n_slots[s])
-        sh.N, sh.n_user, sh.n_item, sh.device = n, n_user, n_item, dev
-        sh.n_slots, sh.n_active = k, int(n_active[s])
-        part = blob[d_off[s]:d_off[s] + used[s]]
-        sh._blob = blob
-        sh.ent_oid, sh.ent_r, sh.ent_src = part[:k], part[k:2 * k].view(torch.float32), part[2 * k:3 * k]
-        sh.sched = part[3 * k:3 * k + 4 * rows].view(rows, 4)
-        sh._row_slot = part[3 * k + 4 * rows:3 * k + 5 * rows]
-        sh._sched_host = host[off[s] + 3 * k:off[s] + 3 * k + 4 * rows].reshape(rows, 4).copy()
-        sh.max_row = int(sh._sched_host[0, 3])
-        sh.u_pos = sh.i_pos = None
-        if keep_positions:                                        # host copies of every interaction's two slots (tests, tools)
-            lay = nv.build_layout(np.ascontiguousarray(uid, dtype=np.int32), np.ascontiguousarray(iid, dtype=np.int32),
-                                  np.ascontiguousarray(rating, dtype=np.float32), n_user, n_item, want_pos=True)
-            sh.u_pos, sh.i_pos = lay['u_pos'], lay['i_pos']
-        a, b = t_words[s]
-        sh.ent_tag = tags[t_at:t_at + 3 * k].view(3, k)
-        sh.file_tag = tags[t_at + a:t_at + a + n]
-        t_at += a + b
-        a, b = z_words[s]
-        sh.inv_stage = zeros[z_at:z_at + n]
-        sh.inv_off = zeros[z_at + a:z_at + a + b]
-        z_at += a + b
-        sh._units = {}
-        if n_units[s] > 0:
-            sh._units[(d_units, False)] = (part[units_at[s]:units_at[s] + 4 * int(n_units[s])].view(int(n_units[s]), 4), int(n_units[s]), sh.n_active)
-        out.append(sh)
-    # whoever trains on a layout from another stream (layouts may be built on a worker thread, whose current stream is the
-    # device's default stream) waits for this event first: TrainJob does
-    ready = None
-    mark('w: layouts views made')
-    if on_gpu:
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(dev))
-    for sh in out:
-        sh.ready = ready
-    return out, ready, pinned
+    def build(self, keep_positions=False):
+        from . import rng
+        if not self._allocated.is_set() and __import__('threading').current_thread() is self._owner:
+            self.allocate()                         # (one thread does everything: build_shards)
+        S, cols, off, host = len(self.cols), self.cols, self.off, self.stage.numpy()
+        n_user, n_item, dev, d_units = self.n_user, self.n_item, self.dev, self.d_units
+        rows = n_user + n_item
+        handed_back = False
+        try:
+            try:
+                built = nv.build_layouts(cols, n_user, n_item, [host[off[s]:off[s + 1]] for s in range(S)], threads=min(S, rng.host_cpus()), units_d=d_units)
+            except nv.NativeError as e:
+                if getattr(e, 'code', None) == -2:             # (-3: a shard beyond 2^31 slots -- reported as it is)
+                    raise ValueError(f'user or item id outside [0, n_user) x [0, n_item): {e}') from None
+                raise
+            mark('w: layouts built (native)')
+            if not self._allocated.wait(60.0):
+                raise RuntimeError('LayoutPlan.build() on a worker: nobody called allocate()')
+            if self._alloc_error is not None:
+                raise RuntimeError('the device allocations of the layouts failed') from self._alloc_error
+            n_slots, n_active = built[0], built[1]
+            n_units = built[2] if d_units else [-1] * S
+            al = lambda x: (x + 7) // 8 * 8
+            units_at = [al(3 * int(k) + 5 * rows) for k in n_slots]                       # where a shard's units start inside its region (when built)
+            used = [a + (al(4 * int(u)) if u > 0 else 0) for a, u in zip(units_at, n_units)]
+            end = int(off[S - 1]) + used[S - 1]
+            pinned = self.stage.is_pinned() and self.on_gpu
+            ready = None
+            with (torch.cuda.device(dev) if self.on_gpu else contextlib.nullcontext()):
+                if self.on_gpu:
+                    # (the allocations and fills were queued on the planner's stream, which need not be this thread's)
+                    torch.cuda.current_stream(dev).wait_event(self.allocated)
+                self.blob[:end].copy_(self.stage[:end], non_blocking=pinned)          # ONE copy (the slack between the regions travels along)
+                if self.on_gpu:
+                    # whoever trains on a layout from another stream waits for this event first: TrainJob does
+                    ready = torch.cuda.Event()
+                    ready.record(torch.cuda.current_stream(dev))
+            mark('w: layouts copy queued')
+            out, t_at, z_at = [], 0, 0
+            for s, (uid, iid, rating) in enumerate(cols):
+                sh = object.__new__(ShardData)
+                n, k = len(uid), int(n_slots[s])
+                sh.N, sh.n_user, sh.n_item, sh.device = n, n_user, n_item, dev
+                sh.n_slots, sh.n_active = k, int(n_active[s])
+                o = int(off[s])
+                ta, tb = self.t_words[s]
+                za, zb = self.z_words[s]
+                f32, i32, i16 = torch.float32, torch.int32, torch.int16
+                # name -> (tensor it lives in, first element, elements, dtype, shape)
+                sh._where = {'ent_oid': (self.blob, o, k, i32, None), 'ent_r': (self.blob, o + k, k, f32, None), 'ent_src': (self.blob, o + 2 * k, k, i32, None),
+                             'sched': (self.blob, o + 3 * k, 4 * rows, i32, (rows, 4)), '_row_slot': (self.blob, o + 3 * k + 4 * rows, rows, i32, None),
+                             'ent_tag': (self.tags, t_at, 3 * k, i16, (3, k)), 'file_tag': (self.tags, t_at + ta, n, i16, None),
+                             'inv_stage': (self.zeros, z_at, n, i32, None), 'inv_off': (self.zeros, z_at + za, zb, i32, None)}
+                t_at += ta + tb
+                z_at += za + zb
+                sh._blob = self.blob
+                sh._sched_host = host[o + 3 * k:o + 3 * k + 4 * rows].reshape(rows, 4).copy()
+                sh.max_row = int(sh._sched_host[0, 3])
+                sh.u_pos = sh.i_pos = None
+                if keep_positions:                                        # host copies of every interaction's two slots (tests, tools)
+                    lay = nv.build_layout(np.ascontiguousarray(uid, dtype=np.int32), np.ascontiguousarray(iid, dtype=np.int32),
+                                          np.ascontiguousarray(rating, dtype=np.float32), n_user, n_item, want_pos=True)
+                    sh.u_pos, sh.i_pos = lay['u_pos'], lay['i_pos']
+                sh._units = {}
+                if n_units[s] > 0:
+                    ua = o + units_at[s]
+                    sh._units[(d_units, False)] = (self.blob[ua:ua + 4 * int(n_units[s])].view(int(n_units[s]), 4), int(n_units[s]), sh.n_active)
+                sh.ready = ready
+                out.append(sh)
+            rng.STAGING.give(self.stage, ready if pinned else None)
+            handed_back = True
+        finally:
+            if not handed_back:
+                rng.STAGING.give(self.stage, None)                  # whatever went wrong, the pooled staging buffer goes back
+        with ShardData._count_lock:
+            ShardData.built += S
+        return out
 
 
 class ShardData:
@@ -240,8 +286,23 @@ class ShardData:
     built = 0            # layouts built (and uploaded) by this process: lets a measurement show that its timed call paid for them
 
     def ptr(self, name):
-        """Device address of one of the layout's arrays."""
-        return nv.ptr(getattr(self, name))
+        """Device address of one of the layout's arrays (no tensor is made for it)."""
+        base, first, _, dtype, _ = self._where[name]
+        return base.data_ptr() + first * base.element_size()
+
+    def __getattr__(self, name):
+        # the layout's arrays as tensors (ent_oid, ent_r, ent_src, sched, ent_tag, file_tag, inv_stage, inv_off, _row_slot): views made on first use
+        where = self.__dict__.get('_where')
+        if where is None or name not in where:
+            raise AttributeError(name)
+        base, first, count, dtype, shape = where[name]
+        t = base[first:first + count]
+        if dtype != base.dtype:
+            t = t.view(dtype)
+        if shape is not None:
+            t = t.view(*shape)
+        self.__dict__[name] = t
+        return t
 
     def row_slot(self):
         """Device int32 [n_user + n_item]: a row's index in the schedule when it is one of the n_active rows with
@@ -638,7 +699,7 @@ class TrainJob:
         main.wait_event(h['event'])
         return h['ev'].evaluate_series_own(fixed, h['own'], self.d, out, stream)
 
-    def evaluate_series(self, s, eval_set, fixed, out, stream=None, subset=None):
+    def evaluate_series(self, s, eval_set, fixed, out, stream=None, subset=None, lane=0):
         """scratch.py:83-97 for every epoch of shard s on `eval_set`: member e = the ensemble `fixed` + the shard's model
         after epoch e, from whichever kind of snapshots the job keeps.  out: device float64 [epochs, 3].
         subset = (EvalSet.subset_of plan, out_sub [epochs, 3]): the same numbers for a subset of the set's users as well."""
@@ -646,17 +707,17 @@ class TrainJob:
         if self.snapshots == 'compact':
             sh = self.shards[s]
             return eval_set.evaluate_series_compact(fixed, st['snap'], sh.row_slot(), st['U0'], st['V0'], st['snap_a'], sh.n_user, self.d, out, stream,
-                                                    subset=subset)
-        return eval_set.evaluate_series(fixed, st['snapU'], st['snapV'], self.d, out, stream, subset=subset)
+                                                    subset=subset, lane=lane)
+        return eval_set.evaluate_series(fixed, st['snapU'], st['snapV'], self.d, out, stream, subset=subset, lane=lane)
 
-    def evaluate_series_pair(self, s, test_ev, total_ev, fixed, out_test, out_total, stream=None):
+    def evaluate_series_pair(self, s, test_ev, total_ev, fixed, out_test, out_total, stream=None, lane=0):
         """The two per-epoch series of scratch.py:83-97 -- the shard's own test set and the total test set.  Where the first is a subset of
         the second (the reference builds the total set from the shards' sets: config.py:144-148) ONE series on the total set yields both."""
         plan = test_ev.subset_of(total_ev)
         if plan is None:
-            self.evaluate_series(s, test_ev, fixed, out_test, stream)
-            return self.evaluate_series(s, total_ev, fixed, out_total, stream)
-        return self.evaluate_series(s, total_ev, fixed, out_total, stream, subset=(plan, out_test))
+            self.evaluate_series(s, test_ev, fixed, out_test, stream, lane=lane)
+            return self.evaluate_series(s, total_ev, fixed, out_total, stream, lane=lane)
+        return self.evaluate_series(s, total_ev, fixed, out_total, stream, subset=(plan, out_test), lane=lane)
 
     def materialize(self, stream=None):
         """Bring the lazily advanced rows (lazy_rows) up to date in the current tables."""
@@ -700,15 +761,24 @@ class TrainJob:
 
     def epoch_sse(self, s):
         """Per-epoch sum of squared training errors (host float64 array; synchronises)."""
-        return self.state[s]['sse'].double().sum(dim=1).cpu().numpy()
+        return self.epoch_sse_queue([s]).cpu().numpy()[0]
+
+    def epoch_sse_queue(self, which=None, out=None, stream=None):
+        """epoch_sse of the shards `which` (default: all) as a DEVICE float64 tensor [n, epochs] (`out`, if given): one launch
+        (ure_epoch_sse_batch: a fixed summation order, the same whoever asks), nothing synchronises."""
+        which = list(range(len(self.shards))) if which is None else list(which)
+        n = len(which)
+        out = torch.empty(n, self.epochs, dtype=torch.float64, device=self.device) if out is None else out
+        assert out.shape == (n, self.epochs) and out.dtype == torch.float64 and out.is_contiguous()
+        base = self._pool.data_ptr()
+        ptrs = (ctypes.c_void_p * n)(*[base + 4 * self._offs[s][4] for s in which])
+        rows = (ctypes.c_int64 * n)(*[self.shards[s].n_user for s in which])
+        nv.check(nv.lib().ure_epoch_sse_batch(n, ptrs, rows, self.epochs, out.data_ptr(), nv.stream_handle(stream)), 'ure_epoch_sse_batch')
+        return out
 
     def epoch_sse_all(self):
-        """epoch_sse of every shard, [n_shards, epochs], read in ONE copy (a copy per shard is a synchronisation per shard:
-        0.4 ms of a 5-shard call, 1.3 ms of a 16-shard one)."""
-        out = torch.empty(len(self.state), self.epochs, dtype=torch.float64, device=self.device)
-        for s, st in enumerate(self.state):
-            torch.sum(st['sse'].double(), dim=1, out=out[s])
-        return out.cpu().numpy()
+        """epoch_sse of every shard, [n_shards, epochs] (host; synchronises once)."""
+        return self.epoch_sse_queue().cpu().numpy()
 
     def close(self):
         if self._job:
@@ -809,10 +879,9 @@ class EvalSet:
         self._subsets[key] = (weakref.ref(total), plan)
         return plan
 
-    def _subset_after(self, subset, m, e0, st):
-        """ure_eval_subset on the m members a series call just left in the scratch buffers (subset = (plan of subset_of, out [E, 3]))."""
+    def _subset_after(self, subset, m, e0, st, b):
+        """ure_eval_subset on the m members a series call just left in the scratch buffers b (subset = (plan of subset_of, out [E, 3]))."""
         plan, out_sub = subset
-        b = self._series
         nv.check(nv.lib().ure_eval_subset(nv.ptr(plan['users']), plan['n'], nv.ptr(plan['pairs']), plan['n_pairs'], nv.ptr(b['pred']), nv.ptr(self.rating),
                                           nv.ptr(b['hits']), nv.ptr(b['ndcg']), self.n, self.n_users, m, nv.ptr(out_sub[e0]), st), 'ure_eval_subset')
 
@@ -849,20 +918,21 @@ class EvalSet:
         rmse = float(np.sqrt(sse / self.n))
         return rmse, float(np.mean(ndcg)), float(np.mean(hits / top_k))
 
-    def _series_buffers(self, E):
-        """Scratch of one series call (kept on the set): -> (buffers, members per call)."""
+    def _series_buffers(self, E, lane=0):
+        """Scratch of one series call (kept on the set): -> (buffers, members per call).  lane: series that run side by side on
+        different streams (Sisa: the shards of a request) take a scratch of their own each; a lane belongs to ONE stream."""
         per_call = max(1, min(E, SERIES_SCRATCH_BYTES // (4 * self.n)))
-        if getattr(self, '_series_cap', 0) < per_call:
+        lanes = self.__dict__.setdefault('_series_lanes', {})
+        if lanes.get(lane, (0, None))[0] < per_call:
             dev = self.device
-            self._series = {'base': torch.empty(self.n, dtype=torch.float32, device=dev),
-                            'pred': torch.empty(per_call, self.n, dtype=torch.float32, device=dev),
-                            'sse': torch.empty(per_call, SCORE_PARTIALS, dtype=torch.float64, device=dev),
-                            'hits': torch.empty(per_call, max(self.n_users, 1), dtype=torch.int32, device=dev),
-                            'ndcg': torch.empty(per_call, max(self.n_users, 1), dtype=torch.float64, device=dev)}
-            self._series_cap = per_call
-        return self._series, per_call
+            lanes[lane] = (per_call, {'base': torch.empty(self.n, dtype=torch.float32, device=dev),
+                                      'pred': torch.empty(per_call, self.n, dtype=torch.float32, device=dev),
+                                      'sse': torch.empty(per_call, SCORE_PARTIALS, dtype=torch.float64, device=dev),
+                                      'hits': torch.empty(per_call, max(self.n_users, 1), dtype=torch.int32, device=dev),
+                                      'ndcg': torch.empty(per_call, max(self.n_users, 1), dtype=torch.float64, device=dev)})
+        return lanes[lane][1], per_call
 
-    def evaluate_series(self, fixed, U_series, V_series, d, out, stream=None, subset=None):
+    def evaluate_series(self, fixed, U_series, V_series, d, out, stream=None, subset=None, lane=0):
         """scratch.py:83-97 for every epoch of a shard in four launches (ure_eval_series): member e of
         the series is the ensemble `fixed` + [(U_series[e], V_series[e])]; out[e] (device float64
         [E, 3]) receives its (rmse, ndcg, hr).  Nothing synchronises."""
@@ -872,7 +942,7 @@ class EvalSet:
         if self.n == 0:
             return out.fill_(float('nan'))
         L, st = nv.lib(), nv.stream_handle(stream)
-        b, per_call = self._series_buffers(E)
+        b, per_call = self._series_buffers(E, lane)
         for U, V in fixed:
             assert U.is_contiguous() and V.is_contiguous() and U.shape[1] == d and V.shape[1] == d
         Up = (ctypes.c_void_p * max(len(fixed), 1))(*[U.data_ptr() for U, _ in fixed])
@@ -886,10 +956,10 @@ class EvalSet:
                                        self.n_wide, self.n_half, st),
                      'ure_eval_series')
             if subset is not None:
-                self._subset_after(subset, m, e0, st)
+                self._subset_after(subset, m, e0, st, b)
         return out
 
-    def evaluate_series_compact(self, fixed, snap, row_slot, U0, V0, snap_a, n_user_rows, d, out, stream=None, subset=None):
+    def evaluate_series_compact(self, fixed, snap, row_slot, U0, V0, snap_a, n_user_rows, d, out, stream=None, subset=None, lane=0):
         """evaluate_series on COMPACT snapshots (ure_eval_series_compact): snap [E, n_active, d] holds the rows with
         interactions in the shard, row_slot maps a row id to its place in it (-1: the row is snap_a[e] * (U0 | V0)[row])."""
         E = int(snap.shape[0])
@@ -899,7 +969,7 @@ class EvalSet:
         if self.n == 0:
             return out.fill_(float('nan'))
         L, st = nv.lib(), nv.stream_handle(stream)
-        b, per_call = self._series_buffers(E)
+        b, per_call = self._series_buffers(E, lane)
         for U, V in fixed:
             assert U.is_contiguous() and V.is_contiguous() and U.shape[1] == d and V.shape[1] == d
         Up = (ctypes.c_void_p * max(len(fixed), 1))(*[U.data_ptr() for U, _ in fixed])
@@ -912,7 +982,7 @@ class EvalSet:
                                                nv.ptr(b['sse']), nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating),
                                                self.n_wide, self.n_half, st), 'ure_eval_series_compact')
             if subset is not None:
-                self._subset_after(subset, m, e0, st)
+                self._subset_after(subset, m, e0, st, b)
         return out
 
     def evaluate_series_own(self, fixed, own, d, out, stream=None):

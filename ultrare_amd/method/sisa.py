@@ -62,8 +62,11 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
     layouts = None
     own_ids = [i for pos, i in enumerate(ids) if owner[pos] == rank]
     if on_device:
-        from ..read import shard_layouts
-        layouts = rng.worker_pool().submit(shard_layouts, [as_loader(train_dlist[i]) for i in own_ids], n_user, n_item, engine._device(), k)
+        from ..read import plan_shard_layouts
+        finish = plan_shard_layouts([as_loader(train_dlist[i]) for i in own_ids], n_user, n_item, engine._device(), k)
+        layouts = rng.worker_pool().submit(finish)           # (the native builder starts now ...
+        finish.allocate()                                    #  ... and the device allocations are made beside it)
+        engine.mark('layouts planned')
     streams = rng.shard_streams(len(ids), n_user, n_item, k, epochs, True) if on_device else None
     engine.mark('streams')
     if streams is not None:
@@ -323,6 +326,69 @@ class Sisa(Scratch):
             engine.mark(f'launched (waited {getattr(job, "chunk_wait_s", 0.0) * 1e3:.2f} ms for permutation chunks)')
             for i in mine:
                 rng.release(prepared[i][2])                 # uploaded: host buffers go back to the pool
+
+        # ---- the per-epoch test series, shard after shard in the reference's order (one dict for all shards)
+        out, queued = {}, {}
+        # the results of all series of the call in one device tensor: read with ONE copy below
+        # (and the per-epoch training losses behind them: ONE device tensor, ONE copy to the host for the whole call)
+        n_res = len(mine) * 6 * self.epochs if keep_logs else 0
+        flat = torch.zeros(n_res + len(mine) * self.epochs, dtype=torch.float64, device=engine._device()) if mine else None
+        res_all = flat[:n_res].view(len(mine), 2, self.epochs, 3) if (mine and keep_logs) else None
+        if mine:
+            job.epoch_sse_queue(out=flat[n_res:].view(len(mine), self.epochs))         # (one launch, right behind the last step)
+
+        def queue_series(fixed_of):
+            """Every shard's two test series (scratch.py:83-97) go into the queue; fixed_of(j) = the padded (U, V) of shard j's final model.
+            A series is a chain of short launches that cannot fill the device, and the shards' series do not depend on each other:
+            URE_SERIES_STREAMS = n > 1 deals them out to n streams, joined at the end (built and measured: tools/host_timeline.py --ab, 20
+            interleaved requests per setting, twice: the tail of a 5-shard request 2.54 -> 2.75 and 2.41 -> 2.62 ms with 4 streams -- the
+            events cost more than the overlap of such short chains gives --, so the default is 1: all on the current stream)."""
+            if not keep_logs:
+                return
+            dev = engine._device()
+            n_lanes = max(1, min(len(mine), int(os.environ.get('URE_SERIES_STREAMS', '1')))) if not early else 1
+            main = torch.cuda.current_stream(dev)
+            sides = engine.side_streams(dev, n_lanes - 1)
+            work = []
+            for i in mine:                      # first everything that is queued on THIS stream: the rows brought up to date, padded copies
+                total_ev = as_loader(test_data).eval_set()
+                test_ev = as_loader(test_dlist[i]).eval_set()
+                if unlearning:                              # sisa.py:89: the shards before i in the retraining order are already replaced
+                    replaced = set(ids[:ids.index(i)])
+                    before = [fixed_of(j) if j in replaced else padded_tables(m)[:2] for j, m in enumerate(self.model_list)]
+                else:
+                    before = [fixed_of(j) for j in ids[:ids.index(i)]]
+                test_ev.subset_of(total_ev)                 # (its index lists go up on this stream too, the first time)
+                work.append((i, mine.index(i), test_ev, total_ev, before))
+            if sides:
+                fork = torch.cuda.Event()
+                fork.record(main)
+                for st in sides:
+                    st.wait_event(fork)
+            for i, pos, test_ev, total_ev, before in work:
+                # all epochs of the shard at once: the ensembles differ in their last model only
+                res = res_all[pos]
+                if early.get(i, (None, None))[0] is None:
+                    lane = pos % n_lanes
+                    with torch.cuda.stream(sides[lane - 1] if lane else main):
+                        job.evaluate_series_pair(pos, test_ev, total_ev, before, res[0], res[1], lane=lane)      # (one series where the shard's set is a subset of the total set)
+                else:
+                    for which, ev in enumerate((test_ev, total_ev)):
+                        job.finish_series(early[i][which], before, res[which])
+                queued[i] = pos
+            for st in sides:
+                done = torch.cuda.Event()
+                done.record(st)
+                main.wait_event(done)
+            # (`work` -- the padded copies of earlier models among it -- lives until here: the side streams are joined)
+
+        if mine and not dist:
+            # one process: every final model is in the job's own tables -- the series are queued from THOSE, right behind the last
+            # launch, and the copies the caller keeps are made while the device works through them (made first, the device sat idle for
+            # 0.7 ms of a 5-shard request between its last step and its first series)
+            queue_series(lambda j: job.padded_tables(mine.index(j)))
+            engine.mark('series_queued')
+        if mine:
             for pos, i in enumerate(mine):
                 U, V = job.tables(pos)
                 models[i] = (U.clone().contiguous(), V.clone().contiguous())
@@ -341,48 +407,31 @@ class Sisa(Scratch):
                     U = torch.zeros(self.n_user, self.k, dtype=torch.float32, device=dev)
                     U.index_copy_(0, rows[i], Ur)
                 models[i] = (U, V.clone())
-        out = {i: MF.from_tables(*models[i]) for i in ids}
-
-        # ---- logs, shard after shard in the reference's order (one dict for all shards)
+        out.update({i: MF.from_tables(*models[i]) for i in ids})
         engine.mark('models')
-        logs, queued = {}, {}
-        # the results of all series of the call in one device tensor: read with ONE copy below
-        res_all = torch.zeros(len(mine), 2, self.epochs, 3, dtype=torch.float64, device=engine._device()) if (mine and keep_logs) else None
-        for i in mine:                # every shard's two test series are queued first; results are read once, below
-            if keep_logs:
-                total_ev = as_loader(test_data).eval_set()
-                test_ev = as_loader(test_dlist[i]).eval_set()
-                before = list(self.model_list) if unlearning else []
-                for j in ids:
-                    if j == i:
-                        break
-                    if unlearning:
-                        before[j] = out[j]                  # sisa.py:89: already replaced when shard i trains
-                    else:
-                        before.append(out[j])
-                before = [padded_tables(m)[:2] for m in before]
-                pos = mine.index(i)
-                # all epochs of the shard at once: the ensembles differ in their last model only
-                res = res_all[pos]
-                if early.get(i, (None, None))[0] is None:
-                    job.evaluate_series_pair(pos, test_ev, total_ev, before, res[0], res[1])      # (one series where the shard's set is a subset of the total set)
-                else:
-                    for which, ev in enumerate((test_ev, total_ev)):
-                        job.finish_series(early[i][which], before, res[which])
-                queued[i] = pos
-        engine.mark('series_queued')
+        logs = {}
+        if dist:
+            queue_series(lambda j: padded_tables(out[j])[:2])
+            engine.mark('series_queued')
         # two copies for the whole call (a copy per shard and kind was a synchronisation each; tools/ab_host.py medians of 6:
         # 13.5 / 12.2 -> 12.1 / 12.2 ms learn / unlearn at 5 shards, within the noise at 16)
-        sse_host = job.epoch_sse_all() if mine else None
-        res_host = res_all.cpu().numpy() if res_all is not None else None
+        if mine:
+            from .. import rng
+            stage = rng.SMALL.take((flat.numel(),), torch.float64)
+            stage.copy_(flat, non_blocking=True)
+            if stage.is_pinned():
+                torch.cuda.current_stream(engine._device()).synchronize()
+            host = stage.numpy().copy()
+            rng.SMALL.give(stage)
+            res_host = host[:n_res].reshape(len(mine), 2, self.epochs, 3) if keep_logs else None
+            sse_host = host[n_res:].reshape(len(mine), self.epochs)
         for pos, i in enumerate(mine):
-            entry = {'train_loss': [float(x) for x in np.sqrt(sse_host[pos] / prepared[i][0].N)]}
+            entry = {'train_loss': np.sqrt(sse_host[pos] / prepared[i][0].N).tolist()}
             if keep_logs:
-                res = res_host[pos].transpose(1, 0, 2)
                 for c, key in enumerate(('test_rmse', 'test_ndcg', 'test_hr')):
-                    entry[key] = [float(x) for x in res[:, 0, c]]
+                    entry[key] = res_host[pos, 0, :, c].tolist()
                 for c, key in enumerate(('total_rmse', 'total_ndcg', 'total_hr')):
-                    entry[key] = [float(x) for x in res[:, 1, c]]
+                    entry[key] = res_host[pos, 1, :, c].tolist()
             else:
                 nan = [float('nan')] * self.epochs
                 for key in ('test_rmse', 'test_ndcg', 'test_hr', 'total_rmse', 'total_ndcg', 'total_hr'):

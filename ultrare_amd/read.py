@@ -142,30 +142,49 @@ def shard_layouts(loaders, n_user, n_item, device=None, units_for=None):
     """The HBM layouts of several shards' loaders; the missing ones are built together (engine.build_shards: one native
     call for all of them) and kept on their loaders.  device: required when called from a worker thread, whose current HIP
     device is not the caller's.  units_for: a table width k whose work units are prepared right away as well."""
+    return plan_shard_layouts(loaders, n_user, n_item, device, units_for)()
+
+
+def plan_shard_layouts(loaders, n_user, n_item, device=None, units_for=None):
+    """shard_layouts in pieces (engine.LayoutPlan): the function this returns builds the missing layouts (a worker may call it) and returns
+    every loader's layout; its attribute `allocate` -- to be called on the request's own thread right after the worker was started --
+    makes their device allocations meanwhile."""
     import contextlib
-    from .engine import build_shards, pad_dim
+    from .engine import LayoutPlan, pad_dim
     key = ('train', n_user, n_item)
     todo = [l for l in loaders if key not in l._cache]
-    on = torch.cuda.device(device) if device is not None and torch.device(device).type == 'cuda' else contextlib.nullcontext()
-    with on:
-        if todo:
-            raw = [(l.dataset.users, l.dataset.items, l.dataset.ratings) for l in todo]
-            for l, sh in zip(todo, build_shards(raw, n_user, n_item, device, units_for=units_for)):
-                l._cache[key] = sh
-        out = [l._cache[key] for l in loaders]
-        if units_for is not None:
-            # the work units of this table width for every shard that lacks them: built side by side (native, outside the GIL),
-            # uploaded in one copy
-            from .engine import upload_many
-            d = pad_dim(int(units_for))
-            need = [sh for sh in out if (d, False) not in sh._units]
-            if need:
-                built = list(_unit_pool().map(lambda sh: sh.units_host(d), need)) if len(need) > 1 else [need[0].units_host(d)]
-                for sh, (u, n_units, n_rows), dev_u in zip(need, built, upload_many([b[0] for b in built], need[0].device)):
-                    sh._units[(d, False)] = (dev_u, n_units, n_rows)
-    from .engine import mark
-    mark('w: shard_layouts returns')
-    return out
+    on = lambda: torch.cuda.device(device) if device is not None and torch.device(device).type == 'cuda' else contextlib.nullcontext()
+    plan = None
+    if todo:
+        with on():
+            plan = LayoutPlan([(l.dataset.users, l.dataset.items, l.dataset.ratings) for l in todo], n_user, n_item, device, units_for=units_for)
+
+    def allocate():
+        if plan is not None:
+            with on():
+                plan.allocate()
+
+    def finish():
+        with on():
+            if plan is not None:
+                for l, sh in zip(todo, plan.build()):
+                    l._cache[key] = sh
+            out = [l._cache[key] for l in loaders]
+            if units_for is not None:
+                # the work units of this table width for every shard that lacks them: built side by side (native, outside the GIL),
+                # uploaded in one copy
+                from .engine import upload_many
+                d = pad_dim(int(units_for))
+                need = [sh for sh in out if (d, False) not in sh._units]
+                if need:
+                    built = list(_unit_pool().map(lambda sh: sh.units_host(d), need)) if len(need) > 1 else [need[0].units_host(d)]
+                    for sh, (u, n_units, n_rows), dev_u in zip(need, built, upload_many([b[0] for b in built], need[0].device)):
+                        sh._units[(d, False)] = (dev_u, n_units, n_rows)
+        from .engine import mark
+        mark('w: shard_layouts returns')
+        return out
+    finish.allocate = allocate              # the caller runs this after handing `finish` to a worker (or not at all: finish then does it)
+    return finish
 
 
 _UNIT_POOL = None

@@ -109,10 +109,12 @@ def fill_draws(n):
 STATS = {'normals': 0, 'skipped_draws': 0}      # host work of this process: N(0, 1) values computed / generator outputs skipped
 
 
-def advance_state(state, n_draws):
-    """A copy of a torch CPU generator state moved past n_draws 32-bit outputs (ure_host_mt_advance)."""
+def advance_state(state, n_draws, count=True):
+    """A copy of a torch CPU generator state moved past n_draws 32-bit outputs (ure_host_mt_advance).  count=False: a second walk
+    over draws that are accounted for elsewhere (STATS counts every output of the stream once)."""
     from . import _native as nv
-    STATS['skipped_draws'] += int(n_draws)
+    if count:
+        STATS['skipped_draws'] += int(n_draws)
     out = state.clone()
     nv.check(nv.lib().ure_host_mt_advance(out.data_ptr(), out.numel(), int(n_draws)), 'ure_host_mt_advance')
     return out
@@ -131,7 +133,11 @@ def model_draws(n_user, n_item, k, epochs, with_total_test):
 
 def mf_init(n_user, n_item, k, generator=None):
     """The four N(0,1) fills of `MF(n_user, n_item, k)` (utils.py:31-40).  The first two (the nn.Embedding
-    constructors') are overwritten by init_weight: the stream is moved past them without computing them."""
+    constructors') are overwritten by init_weight: the stream is moved past them without computing them.
+    (The kept fills stay torch's own `normal_`: this build's kernel for the 16-blocks is ATen's vector polynomial path, which a
+    libm restatement does not reproduce -- tried, 40 % of the values differ in the last bits --, and cutting a fill into pieces that
+    torch fills side by side from skipped-ahead generators -- bit-identical -- lost more to the interpreter lock than it won:
+    profiles/r04/NOTES.md 6.)"""
     g = generator
     draws = model_draws(n_user, n_item, k, 0, False)
     if draws is None:
@@ -400,6 +406,8 @@ class _DrawsTask:
         self.host = self.on_dev = self.ready = self.seeds = self.stream = None
         self.init_value = self.perms_value = None
         self.init_done, self.error = threading.Event(), None
+        # (buffers and events are made here, before any worker of the call runs: made after the workers were started -- so that the
+        # inits begin 0.3 ms earlier -- this thread's Python competed with theirs for the interpreter lock and took 0.8 ms instead of 0.4)
         big = n_rows >= (2 ** 32 - 1) // 20
         # tags_batch = B > 0: the permutations leave the host as BATCH TAGS (uint16 [epochs, n_rows]: the step of the epoch in which
         # every interaction trains; struct ure_shard: file_tags; engine.TrainJob tells them from permutations by their dtype) -- half
@@ -427,6 +435,28 @@ class _DrawsTask:
             for _, flag, _ in self.on_dev._ure_chunks:
                 flag.set()
 
+    def _upload_stream(self):
+        """The side stream of the calling worker thread."""
+        key = (self.device, threading.get_ident())
+        st = _UPLOAD_STREAMS.get(key)
+        if st is None:
+            st = _UPLOAD_STREAMS[key] = torch.cuda.Stream(self.device)
+        return st
+
+    def seeds_first(self):
+        """The per-epoch seeds WITHOUT the model init: they follow the four fills in the stream, whose lengths are known, so a generator
+        moved past them (ure_host_mt_advance) draws them at once -- and the permutations, the bulk of a request's host work, are expanded
+        beside the inits instead of behind them.  False: the tables are too small to skip (the seeds come with init())."""
+        import os
+        start_state, n_user, n_item, k, epochs, with_total_test = self.args[:6]
+        draws = model_draws(n_user, n_item, k, 0, False)
+        if draws is None or os.environ.get('URE_SEEDS_FIRST', '1') == '0':
+            return False
+        g = torch.Generator()
+        g.set_state(advance_state(start_state, draws[0] + draws[1], count=False))
+        self.seeds = epoch_seeds(epochs, with_total_test, generator=g)
+        return True
+
     def init(self):
         start_state, n_user, n_item, k, epochs, with_total_test = self.args[:6]
         from .engine import mark
@@ -434,16 +464,15 @@ class _DrawsTask:
         g = torch.Generator()
         g.set_state(start_state)
         init = mf_init(n_user, n_item, k, generator=g)
-        self.seeds = epoch_seeds(epochs, with_total_test, generator=g)
+        seeds = epoch_seeds(epochs, with_total_test, generator=g)
+        if self.seeds is None:
+            self.seeds = seeds
         mark('w: init drawn')
         if self.device is not None:
             # the init tables go up first, on a side stream of this worker
             dev = self.device
             with torch.cuda.device(dev):
-                st = _UPLOAD_STREAMS.get((dev, threading.get_ident()))
-                if st is None:
-                    st = _UPLOAD_STREAMS[(dev, threading.get_ident())] = torch.cuda.Stream(dev)
-                self.stream = st
+                st = self._upload_stream()
                 with torch.cuda.stream(st):
                     up = tuple(t.to(dev) for t in init)
                     ev0 = torch.cuda.Event()
@@ -473,7 +502,9 @@ class _DrawsTask:
             self.perms_value = self.host
             return
         from .engine import mark
-        dev, st, on_dev, host = self.device, self.stream, self.on_dev, self.host
+        dev, on_dev, host = self.device, self.on_dev, self.host
+        with torch.cuda.device(dev):
+            st = self._upload_stream()
         sd_ptr, host_ptr, row_bytes = sd.ctypes.data, host.data_ptr(), (2 if self.tags_batch else 4) * n_rows
         self.perms_value = on_dev
         first = True
@@ -528,9 +559,9 @@ class ShardDraws:
 
 
 def draws_batch_async(specs, n_workers=0, gate=None):
-    """shard_draws_async for the shards of one call on FEW worker threads: worker w takes the shards w, w + W, ... -- first
-    all their model inits, then (once `gate` is set) their permutation chunks round robin, so that the first chunk of every
-    shard arrives before anybody's second.  One thread per shard -- round 2 -- meant 16 Python threads taking turns on the GIL
+    """shard_draws_async for the shards of one call: every model init on a worker of its own, and beside them FEW chunk workers --
+    worker w takes the shards w, w + W, ...: their seeds first (_DrawsTask.seeds_first: no init needed), then (once `gate` is set)
+    their permutation chunks round robin, so that the first chunk of every shard arrives before anybody's second.  One thread per shard -- round 2 -- meant 16 Python threads taking turns on the GIL
     with the calling thread for a 16-shard call (10 ms between two of its marks).  specs: list of dicts of shard_draws_async's
     arguments.  -> [ShardDraws]."""
     pool = worker_pool()
@@ -540,11 +571,21 @@ def draws_batch_async(specs, n_workers=0, gate=None):
              for sp in specs]
     W = max(1, min(len(tasks), int(n_workers) if n_workers else max(2, host_cpus() // 2)))
 
+    def init(t):
+        try:
+            t.init()
+        except BaseException as e:
+            t.fail(e)
+            raise
+
     def work(mine):
         todo = list(mine)
         try:
             for t in mine:
-                t.init()
+                if not t.seeds_first():
+                    t.init_done.wait()                  # (tables too small to skip: the seeds come with the init)
+                    if t.error is not None:
+                        raise t.error
             if gate is not None:
                 gate.wait()
             gens = [(t, t.chunks()) for t in mine]
@@ -560,7 +601,9 @@ def draws_batch_async(specs, n_workers=0, gate=None):
                 t.fail(e)
             raise
 
-    futures = [pool.submit(work, tasks[w::W]) for w in range(W)]
+    for t in tasks:
+        pool.submit(init, t)                            # the model inits, a worker each ...
+    futures = [pool.submit(work, tasks[w::W]) for w in range(W)]      # ... and beside them the permutation chunks
     return [ShardDraws(futures[i % W], t) for i, t in enumerate(tasks)]
 
 
