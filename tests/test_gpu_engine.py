@@ -524,3 +524,40 @@ def test_one_series_on_the_total_set_yields_the_shard_sets_numbers_too():
     assert engine.EvalSet(uid[parts[0]], iid[parts[0]], changed).subset_of(total) is None
     other_user = engine.EvalSet(np.full(3, n_user + 5, np.int32), np.zeros(3, np.int32), np.ones(3, np.float32))
     assert other_user.subset_of(total) is None
+
+
+def test_start_tables_of_all_shards_in_one_launch_and_losses_in_one_launch():
+    """ure_copy_rows_batch (utils.py:31-40's tables [rows, k] -> the job's padded [rows, d], columns [k, d) untouched, the closed form's
+    copy beside it) and ure_epoch_sse_batch (scratch.py:72-77's per-epoch loss: the sum over the users in double, one fixed order)
+    through the C ABI, on more tables than one launch takes (48)."""
+    import ctypes
+    from ultrare_amd import _native as nv
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    k, d, n = 5, 8, 53
+    rows = [int(x) for x in torch.randint(1, 400, (n,), generator=g)]
+    rows[7] = 0
+    src = [torch.randn(r, k, generator=g).to(dev) for r in rows]
+    dst = [torch.full((r, d), 7.0, device=dev) for r in rows]
+    dst2 = [torch.full((r, d), 9.0, device=dev) if i % 3 else None for i, r in enumerate(rows)]
+    arr = lambda ts: (ctypes.c_void_p * n)(*[(t.data_ptr() if t is not None and t.numel() else (1 if t is not None else None)) for t in ts])
+    # (a table of 0 rows has no storage: any non-NULL address stands for it)
+    rows_a = (ctypes.c_int64 * n)(*rows)
+    nv.check(nv.lib().ure_copy_rows_batch(n, arr(src), arr(dst), arr(dst2), rows_a, k, d, nv.stream_handle()), 'ure_copy_rows_batch')
+    for s, a, b in zip(src, dst, dst2):
+        assert torch.equal(a[:, :k], s) and bool((a[:, k:] == 7.0).all())
+        if b is not None:
+            assert torch.equal(b[:, :k], s) and bool((b[:, k:] == 9.0).all())
+    assert nv.lib().ure_copy_rows_batch(1, arr(src[:1] + [None] * (n - 1)), None, None, rows_a, k, d, None) != 0        # dst missing: refused
+    E = 7
+    users = [int(x) for x in torch.randint(1, 3000, (n,), generator=g)]
+    sse = [(torch.rand(E, u, generator=g) * 3).to(dev) for u in users]
+    out = torch.zeros(n, E, dtype=torch.float64, device=dev)
+    nv.check(nv.lib().ure_epoch_sse_batch(n, (ctypes.c_void_p * n)(*[t.data_ptr() for t in sse]), (ctypes.c_int64 * n)(*users), E, out.data_ptr(),
+                                          nv.stream_handle()), 'ure_epoch_sse_batch')
+    want = torch.stack([t.double().sum(dim=1) for t in sse])
+    assert torch.allclose(out, want, rtol=1e-13, atol=0)
+    again = torch.zeros_like(out)
+    nv.check(nv.lib().ure_epoch_sse_batch(n, (ctypes.c_void_p * n)(*[t.data_ptr() for t in sse]), (ctypes.c_int64 * n)(*users), E, again.data_ptr(),
+                                          nv.stream_handle()), 'ure_epoch_sse_batch')
+    assert torch.equal(out, again)

@@ -205,6 +205,7 @@ class LayoutPlan:
         handed_back = False
         try:
             try:
+                mark('w: layouts native start')
                 built = nv.build_layouts(cols, n_user, n_item, [host[off[s]:off[s + 1]] for s in range(S)], threads=min(S, rng.host_cpus()), units_d=d_units)
             except nv.NativeError as e:
                 if getattr(e, 'code', None) == -2:             # (-3: a shard beyond 2^31 slots -- reported as it is)

@@ -61,24 +61,30 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
     # table width (a layout a loader already holds is returned as it is)
     layouts = None
     own_ids = [i for pos, i in enumerate(ids) if owner[pos] == rank]
-    if on_device:
+
+    def start_layouts():
         from ..read import plan_shard_layouts
         finish = plan_shard_layouts([as_loader(train_dlist[i]) for i in own_ids], n_user, n_item, engine._device(), k)
-        layouts = rng.worker_pool().submit(finish)           # (the native builder starts now ...
+        fut = rng.worker_pool().submit(finish)               # (the native builder starts now ...
         finish.allocate()                                    #  ... and the device allocations are made beside it)
         engine.mark('layouts planned')
+        return fut
     streams = rng.shard_streams(len(ids), n_user, n_item, k, epochs, True) if on_device else None
     engine.mark('streams')
+    if on_device and streams is None:
+        layouts = start_layouts()
     if streams is not None:
-        # every shard's start state by skip-ahead, then the owned shards' draws (init, seeds, permutations, upload) on a few worker
-        # threads (rng.draws_batch_async): the model inits first, then the permutation chunks round robin
+        # every shard's start state by skip-ahead; then, in the order of what the job waits for longest: the owned shards' model inits
+        # (a worker each, started at once: rng.start_inits), the layouts (one native call on a worker, the device allocations beside
+        # it), and last the permutations' buffers and chunk workers (rng.draws_batch_async: seeds by skip-ahead, chunks round robin)
         import threading
         starts, end = streams
         torch.set_rng_state(end)
         mine = [pos for pos in range(len(ids)) if owner[pos] == rank]
         # `gate` can hold the permutation expansion back until the layouts are built (URE_GATE=1).  Measured with the layouts as
         # ONE native call on a worker (tools/ab_host.py, medians of 5 alternating runs): 5 shards 13.8 / 13.1 ms without the gate,
-        # 15.1 / 14.0 with it; 16 shards 24.6 / 22.5 against 24.1 / 20.9 (noise).  Open by default.
+        # 15.1 / 14.0 with it; 16 shards 24.6 / 22.5 against 24.1 / 20.9 (noise); with the chunks beside the inits (round 4,
+        # tools/host_timeline.py --ab, 20 interleaved requests each): 9.4 ms without, 9.9 with.  Open by default.
         gate = threading.Event()
         if os.environ.get('URE_GATE', '0') != '1':
             gate.set()
@@ -98,12 +104,16 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
                                       tags_batch=loader.batch_size if os.environ.get('URE_HOST_TAGS', '1') != '0' else 0,
                                       chunk_epochs=chunk_epochs))
                     order.append(i)
+            early = os.environ.get('URE_INITS_FIRST', '1') != '0'
+            tasks = rng.start_inits(specs) if early else None
+            engine.mark('inits started')
+            layouts = start_layouts()
             # few workers, several shards each (rng.draws_batch_async): the expansion threads of a worker's native calls share
             # the rank's CPUs
             W = max(1, min(len(specs), int(os.environ.get('URE_DRAW_WORKERS', '0')) or max(2, rng.host_cpus() // 2)))
             for sp in specs:
                 sp['threads'] = max(2, PERM_THREADS // W)
-            futures = dict(zip(order, rng.draws_batch_async(specs, W, gate)))
+            futures = dict(zip(order, rng.draws_batch_async(specs, W, gate, tasks=tasks)))
             engine.mark('draws submitted')
             shards = dict(zip(own_ids, layouts.result()))
         finally:

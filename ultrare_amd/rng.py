@@ -398,7 +398,8 @@ class _DrawsTask:
     per step of the generator.  Buffers and events are created on the calling thread (the pool and the allocator see the
     caller's current stream)."""
 
-    def __init__(self, start_state, n_user, n_item, k, epochs, with_total_test, n_rows, shuffle, threads, device, want_perms, chunk_epochs, tags_batch=0):
+    def __init__(self, start_state, n_user, n_item, k, epochs, with_total_test, n_rows, shuffle, threads, device, want_perms, chunk_epochs, tags_batch=0,
+                 buffers=True):
         from . import _native as nv
         nv.lib()
         self.args = (start_state, n_user, n_item, k, epochs, with_total_test, n_rows, shuffle, int(threads or 0), want_perms)
@@ -406,8 +407,15 @@ class _DrawsTask:
         self.host = self.on_dev = self.ready = self.seeds = self.stream = None
         self.init_value = self.perms_value = None
         self.init_done, self.error = threading.Event(), None
-        # (buffers and events are made here, before any worker of the call runs: made after the workers were started -- so that the
-        # inits begin 0.3 ms earlier -- this thread's Python competed with theirs for the interpreter lock and took 0.8 ms instead of 0.4)
+        self._buffer_args = (chunk_epochs, tags_batch)
+        if buffers:
+            self.make_buffers()
+
+    def make_buffers(self):
+        """The permutations' host and device buffers and events, on the CALLING thread (the pool and the allocator see the caller's
+        current stream).  init() does not need them (start_inits), chunks() does."""
+        chunk_epochs, tags_batch = self._buffer_args
+        _, _, _, _, epochs, _, n_rows, shuffle, _, want_perms = self.args
         big = n_rows >= (2 ** 32 - 1) // 20
         # tags_batch = B > 0: the permutations leave the host as BATCH TAGS (uint16 [epochs, n_rows]: the step of the epoch in which
         # every interaction trains; struct ure_shard: file_tags; engine.TrainJob tells them from permutations by their dtype) -- half
@@ -426,6 +434,9 @@ class _DrawsTask:
                 # an event) under the GIL, and a request of 16 small shards had 112 of them competing with the calling thread
                 chunk_epochs = max(int(chunk_epochs), -(-(4 << 20) // ((2 if self.tags_batch else 4) * n_rows)))
                 self.on_dev._ure_chunks = [(min(epochs, c0 + chunk_epochs), threading.Event(), [None]) for c0 in range(0, epochs, chunk_epochs)]
+                if self.error is not None:                  # the init failed before the buffers were there: never leave a consumer waiting
+                    for _, flag, _ in self.on_dev._ure_chunks:
+                        flag.set()
 
     def fail(self, exc):
         """Never leave a consumer waiting: init() / the chunk flags are released, the exception is kept for result()."""
@@ -558,25 +569,46 @@ class ShardDraws:
         return self.init(), self.perms()
 
 
-def draws_batch_async(specs, n_workers=0, gate=None):
+def _task_of(sp, buffers=True):
+    return _DrawsTask(sp['start_state'], sp['n_user'], sp['n_item'], sp['k'], sp['epochs'], sp['with_total_test'], sp.get('n_rows', 0),
+                      sp.get('shuffle', False), sp.get('threads', 0), sp.get('device'), sp.get('want_perms', True), sp.get('chunk_epochs', 8),
+                      sp.get('tags_batch', 0), buffers)
+
+
+def _guarded_init(t):
+    try:
+        t.init()
+    except BaseException as e:
+        t.fail(e)
+        raise
+
+
+def start_inits(specs):
+    """The model inits of a call's shards, each on a worker of its own, started at once: all they need is the shard's start state.
+    -> the tasks, to be handed to draws_batch_async(tasks=...) once the caller has done what is more urgent than the permutations'
+    buffers (a request: getting its layouts under way)."""
+    tasks = [_task_of(sp, buffers=False) for sp in specs]
+    pool = worker_pool()
+    for t in tasks:
+        pool.submit(_guarded_init, t)
+    return tasks
+
+
+def draws_batch_async(specs, n_workers=0, gate=None, tasks=None):
     """shard_draws_async for the shards of one call: every model init on a worker of its own, and beside them FEW chunk workers --
     worker w takes the shards w, w + W, ...: their seeds first (_DrawsTask.seeds_first: no init needed), then (once `gate` is set)
     their permutation chunks round robin, so that the first chunk of every shard arrives before anybody's second.  One thread per shard -- round 2 -- meant 16 Python threads taking turns on the GIL
     with the calling thread for a 16-shard call (10 ms between two of its marks).  specs: list of dicts of shard_draws_async's
     arguments.  -> [ShardDraws]."""
     pool = worker_pool()
-    tasks = [_DrawsTask(sp['start_state'], sp['n_user'], sp['n_item'], sp['k'], sp['epochs'], sp['with_total_test'], sp.get('n_rows', 0),
-                        sp.get('shuffle', False), sp.get('threads', 0), sp.get('device'), sp.get('want_perms', True), sp.get('chunk_epochs', 8),
-                        sp.get('tags_batch', 0))
-             for sp in specs]
+    started = tasks is not None                      # (start_inits: the inits are running already)
+    if started:
+        for t, sp in zip(tasks, specs):
+            t.args = t.args[:8] + (int(sp.get('threads', 0) or 0),) + t.args[9:]
+            t.make_buffers()
+    else:
+        tasks = [_task_of(sp) for sp in specs]
     W = max(1, min(len(tasks), int(n_workers) if n_workers else max(2, host_cpus() // 2)))
-
-    def init(t):
-        try:
-            t.init()
-        except BaseException as e:
-            t.fail(e)
-            raise
 
     def work(mine):
         todo = list(mine)
@@ -601,8 +633,9 @@ def draws_batch_async(specs, n_workers=0, gate=None):
                 t.fail(e)
             raise
 
-    for t in tasks:
-        pool.submit(init, t)                            # the model inits, a worker each ...
+    if not started:
+        for t in tasks:
+            pool.submit(_guarded_init, t)               # the model inits, a worker each ...
     futures = [pool.submit(work, tasks[w::W]) for w in range(W)]      # ... and beside them the permutation chunks
     return [ShardDraws(futures[i % W], t) for i, t in enumerate(tasks)]
 
