@@ -53,6 +53,9 @@ constexpr int kIdxLight = 0, kIdxHeavy = 1, kIdxSplit = 2;
 #ifndef URE_INDEX_WAVES
 #define URE_INDEX_WAVES 4
 #endif
+// (Rows of 64 bytes, d = 16: configs[3]'s shape, epoch time with (rows gathered together, waves per SIMD) = (4, 4) 4.50-4.53 ms, (8, 4) 5.56,
+// (4, 8) 4.50, (1, 8) 4.51, (2, 4) 4.47, (2, 6) 4.48, (2, 7) 4.48, (3, 8) 4.49, (2, 8) 4.34-4.40 -- the one setting that wins does so at 64 VGPRs
+// with 4 of them spilled; not taken.  tools/r4_short_ab.sh, three boxes.)
 
 // the epoch that starts at `tick` for this shard, or -1
 __device__ __forceinline__ int idx_epoch_start(const ure_shard_t &S, const shard_aux &A, int64_t tick)
@@ -334,6 +337,122 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_kernel(const ure_shard_t *
             stg_u4(A.sslot + (size_t)(base + rank), make_uint4((unsigned)oid, __float_as_uint(r), (unsigned)row, tag | ((unsigned)cls << 16)));
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- epoch start 5, epochs of at most 63 steps (a job of short epochs of narrow rows: engine.INDEX_SHORT_EPOCH_MAX_D).  With few steps
+// a chunk's slots of one step are MANY -- 1,024 slots / 27 steps = 38 -- and they are neighbours in the sorted array: the wavefront
+// sorts 1,024 slots at a time in LDS (count per step, prefix, place) and writes them out in sorted order, so a step's share leaves as
+// one run of ~600 bytes instead of 38 scattered 16-byte stores (partial-line stores run at ~34 G/s: 1.3 ms per epoch for the 45 M
+// sorted slots of configs[3]'s shape, whatever the row width).  Every slot lands exactly where idx_scatter_kernel puts it.
+constexpr int kIdxStage = 1024;                 // slots a wavefront sorts in LDS at a time
+
+__global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    __shared__ uint4 stage[kWavesPerBlock][kIdxStage];
+    __shared__ unsigned goff[kWavesPerBlock][64], lcnt[kWavesPerBlock][64], lstart[kWavesPerBlock][64], lfill[kWavesPerBlock][64];
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    const int epoch = idx_epoch_start(S, A, tick);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = (int)blockIdx.x * kWavesPerBlock + wave;
+    if (epoch < 0 || c >= A.idx_chunks) return;
+    const int steps = A.steps;                                      // <= 63: a step is its own lane below
+    uint4 *st = stage[wave];
+    unsigned *g_off = goff[wave], *l_cnt = lcnt[wave], *l_start = lstart[wave], *l_fill = lfill[wave];
+    g_off[lane] = lane < steps ? ldg(A.hist + (size_t)c * (steps + 1) + lane) : 0u;
+    l_cnt[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    const uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, epoch);
+    const int64_t lo = (int64_t)c * kIdxChunk, hi = min(lo + kIdxChunk, S.n_slots);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int n_all = S.n_user + S.n_item;
+    struct Batch { unsigned tag; int oid, idx, row; float r; };
+    auto fetch = [&](int64_t p) {
+        Batch b{0xFFFFu, 0, 0, 0, 0.f};
+        if (p < hi) {
+            b.tag = ldg(ent_tag + p);
+            b.oid = ldg(S.ent_oid + p);
+            b.r = ldg(S.ent_r + p);
+            const ure_i2 g = *(const ure_i2 URE_AS1 *)(A.grp_row + 2 * (p >> 3));
+            const int gi = g.x, gr = g.y;
+            b.idx = gi; b.row = gr;
+        }
+        return b;
+    };
+    auto word_of = [&](const Batch &b) {
+        if (b.tag >= (unsigned)steps) return 0ull;
+        const int other = b.row >= S.n_user ? b.oid : S.n_user + b.oid;
+        return ldg(A.W + (size_t)(b.tag / kIdxWin) * n_all + other);
+    };
+    // the staged slots leave in sorted order: slot i of the stage belongs to the step whose range [l_start, l_start + l_cnt) holds i
+    auto flush = [&]() {
+        const unsigned total = l_start[63] + l_cnt[63];
+        for (unsigned i = lane; i < total; i += kWave) {
+            const uint4 rec = st[i];
+            const unsigned tag = rec.w & 0xFFFFu;
+            stg_u4(A.sslot + (size_t)(g_off[tag] + (i - l_start[tag])), rec);
+        }
+        __builtin_amdgcn_wave_barrier();
+        g_off[lane] += l_cnt[lane];
+        l_cnt[lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
+    };
+    // Eight batches at a time: their loads of the row-major arrays go out together, then the eight gathers of the opposite rows' mask
+    // words, then the batches are placed one after the other -- the two memory levels are paid once per 512 slots, not per 64.
+    constexpr int kRound = 8;
+    for (int64_t s0 = lo; s0 < hi; s0 += kIdxStage) {
+        // the counts of these 1,024 slots per step (their tags once more: 2 KB, in the caches), then the exclusive prefix over the steps
+        for (int64_t p = s0 + lane * 8; p < min(s0 + kIdxStage, hi); p += kWave * 8) {
+            const uint4 t4 = ldg_u4(ent_tag + p);
+            const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned t = (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+                if (t < (unsigned)steps) atomicAdd(&l_cnt[t], 1u);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned mine_n = l_cnt[lane];
+        unsigned incl = mine_n;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const unsigned v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        l_start[lane] = incl - mine_n;
+        l_fill[lane] = incl - mine_n;
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t r0 = s0; r0 < min(s0 + kIdxStage, hi); r0 += kRound * kWave) {
+            Batch bt[kRound];
+            unsigned long long wd[kRound];
+#pragma unroll
+            for (int k = 0; k < kRound; ++k) bt[k] = fetch(r0 + k * kWave + lane);
+#pragma unroll
+            for (int k = 0; k < kRound; ++k) wd[k] = word_of(bt[k]);
+#pragma unroll
+            for (int k = 0; k < kRound; ++k) {
+                const unsigned tag = bt[k].tag;
+                const bool valid = tag < (unsigned)steps;
+                const int oid = bt[k].oid | (valid ? idx_buffer_at(wd[k], (int)(tag % kIdxWin)) << 31 : 0);
+                const int cls = bt[k].idx < S.n_split ? kIdxSplit : bt[k].idx < S.n_multi ? kIdxHeavy : kIdxLight;
+                unsigned long long peers = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {                               // (tags below 64)
+                    const bool bit = (tag >> b) & 1u;
+                    const unsigned long long m = __ballot(bit);
+                    peers &= bit ? m : ~m;
+                }
+                if (valid) {
+                    const unsigned base = l_fill[tag];                      // (all peers read before their first lane writes: LDS runs a wave's accesses in order)
+                    const int rank = __popcll(peers & below);
+                    if (rank == 0) l_fill[tag] = base + (unsigned)__popcll(peers);
+                    st[base + rank] = make_uint4((unsigned)oid, __float_as_uint(bt[k].r), (unsigned)bt[k].row, tag | ((unsigned)cls << 16));
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        flush();
     }
 }
 
