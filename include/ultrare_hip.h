@@ -218,6 +218,15 @@ int ure_host_randperm_tags(const int64_t *seeds, int n_perms, int64_t n, int32_t
  * init fills the reference discards (utils.py:31-40: the nn.Embedding constructors' fills) and, in a
  * multi-rank run, the draws of the shards other ranks own.  In place.                       */
 int ure_host_mt_advance(uint8_t *state, int64_t n_bytes, int64_t n_draws);
+/* ABI 7.  MF.init_weight's kept fills (utils.py:31-40) from a torch CPU generator state: the state is moved past `skip_draws` outputs
+ * (the nn.Embedding constructors' discarded fills), then U0 [nu] and V0 [nv] (each 0 or >= 16 elements) are filled as
+ * `tensor.normal_()` fills a contiguous float32 tensor on an AVX2-capable host: the uniforms in generator order, then Box-Muller
+ * 16 at a time through the installed PyTorch's own avx_mathfun kernels (csrc/host_normal_avx2.cpp), the 16-blocks on n_threads
+ * threads; the state ends where torch's would.  -4: those kernels are not in this build / not supported by this CPU.  The Python
+ * side checks the function against torch once per process and keeps torch's fill when a bit differs.  HOST memory.           */
+int ure_host_mf_init(uint8_t *state, int64_t n_bytes, int64_t skip_draws, float *U0, int64_t nu, float *V0, int64_t nv, int n_threads);
+/* The Box-Muller half alone: data [16 n_blocks] uniforms -> normals in place (ATen's normal_fill_16_AVX2).  0, or -4 as above. */
+int ure_host_normal_blocks(float *data, int64_t n_blocks, float mean, float std_);
 
 /* ---------------------------------------------------------------------------
  * Host-side ingest (HOST memory throughout; linear time, `n_threads` = 0 means all cores)

@@ -22,6 +22,23 @@ FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-mun
          '-ffp-contract=off', '-Wall', '-Wno-unused-result', '-pthread', '-mllvm', '-amdgpu-kernarg-preload-count=8']
 
 
+# host_normal_avx2.cpp is built apart: -mavx2 -mfma -ffp-contract=fast (its arithmetic must contract as PyTorch's own build of the same
+# header does: bit-identical normals) against the include directory of the installed PyTorch
+AVX2_SOURCE = 'host_normal_avx2.cpp'
+AVX2_FLAGS = ['-O3', '-std=c++17', '-fPIC', '-mavx2', '-mfma', '-ffp-contract=fast', '-c']
+
+
+def torch_include():
+    """The installed PyTorch's include directory when it ships ATen/native/cpu/avx_mathfun.h, else None."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+        inc = os.path.join(os.path.dirname(spec.origin), 'include')
+        return inc if os.path.exists(os.path.join(inc, 'ATen', 'native', 'cpu', 'avx_mathfun.h')) else None
+    except Exception:
+        return None
+
+
 def source_hash(extra=()):
     """sha256 (16 hex digits) over every file of csrc/, the public header and the compiler flags: the
     identity of the code a library, a profile or a counter file belongs to."""
@@ -32,7 +49,7 @@ def source_hash(extra=()):
         h.update(os.path.basename(path).encode() + b'\0')
         with open(path, 'rb') as f:
             h.update(f.read())
-    h.update(' '.join(list(FLAGS) + list(extra)).encode())
+    h.update(' '.join(list(FLAGS) + list(extra) + AVX2_FLAGS + [str(torch_include() is not None)]).encode())
     return h.hexdigest()[:16]
 
 
@@ -83,11 +100,20 @@ def build(force=False, verbose=False, timeline=None, defines=(), out=None):
         raise RuntimeError('hipcc not found: libultrare_hip.so cannot be built')
     out = timeline or out or LIB
     extra = (['-DURE_TIMELINE'] if timeline else []) + ['-D' + d for d in defines]
+    inc = torch_include()
+    obj = out + '.avx2.o'
+    cmd0 = [hipcc, '-x', 'c++'] + AVX2_FLAGS + (['-DURE_HAVE_AVX_MATHFUN', '-I', inc] if inc else []) + ['-o', obj, os.path.join(CSRC, AVX2_SOURCE)]
     cmd = [hipcc] + FLAGS + extra + [f'-DURE_SOURCE_HASH="URE_SRC_HASH={source_hash(extra)}"'] + ['-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-o', out] + \
-          [os.path.join(CSRC, s) for s in SOURCES]
+          [os.path.join(CSRC, s) for s in SOURCES] + ['-Wl,' + obj]          # (as a linker argument: hipcc takes every plain input for HIP source)
     if verbose:
+        print(' '.join(cmd0), flush=True)
         print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd0)
+        subprocess.check_call(cmd)
+    finally:
+        if os.path.exists(obj):
+            os.remove(obj)
     return out
 
 

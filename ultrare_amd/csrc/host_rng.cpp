@@ -275,3 +275,107 @@ extern "C" int ure_host_mt_advance(uint8_t *state, int64_t n_bytes, int64_t n_dr
     __builtin_memcpy(state + 16, &next, 8);
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// MF.init_weight's two kept fills (utils.py:31-40) natively.  ATen's `tensor.normal_()` for a contiguous float32 tensor of n >= 16
+// elements (aten/src/ATen/native/cpu/DistributionTemplates.h: normal_fill_AVX2) draws n uniforms (24 bits of one 32-bit output each)
+// into the tensor with the scalar engine -- 3 of its 4.3 ns per element --, then turns them into normals 16 at a time, and when 16 does
+// not divide n draws 16 more uniforms for the LAST 16 elements.  Here the uniforms come off the generator in bulk (regeneration and
+// tempering vectorise: ~0.3 ns each), and the 16-blocks -- independent of each other -- go through the installed PyTorch's own
+// polynomial kernels (host_normal_avx2.cpp) on n_threads threads.  ultrare_amd/rng.py compares the result with torch once per
+// process and keeps torch's own fill when a single bit differs.
+// ---------------------------------------------------------------------------------------------
+extern "C" int ure_host_normal_blocks(float *data, int64_t n_blocks, float mean, float std_);       // host_normal_avx2.cpp
+
+namespace {
+
+URE_HOST_CLONES void temper_to_uniform(const uint32_t *src, float *dst, int64_t count)
+{
+    for (int64_t t = 0; t < count; ++t) {
+        uint32_t x = src[t];
+        x ^= x >> 11;
+        x ^= (x << 7) & 0x9d2c5680u;
+        x ^= (x << 15) & 0xefc60000u;
+        x ^= x >> 18;
+        dst[t] = (float)(x & 0xffffffu) * 5.9604644775390625e-8f;          // at::uniform_real_distribution<float>(0, 1): exact
+    }
+}
+
+// `count` uniforms off a generator in ATen's engine order: `if (--left == 0) next_state(); y = state[next++]`
+void mt_uniforms(uint32_t *st, int32_t &left, uint64_t &next, float *dst, int64_t count)
+{
+    constexpr int N = 624;
+    while (count > 0) {
+        if (left > 1) {
+            const int64_t c = std::min<int64_t>(count, (int64_t)left - 1);
+            temper_to_uniform(st + next, dst, c);
+            left -= (int32_t)c;
+            next += (uint64_t)c;
+            dst += c;
+            count -= c;
+            continue;
+        }
+        mt_regenerate(st, 1);
+        const int64_t c = std::min<int64_t>(count, N);
+        temper_to_uniform(st, dst, c);
+        left = (int32_t)(N - (c - 1));
+        next = (uint64_t)c;
+        dst += c;
+        count -= c;
+    }
+}
+
+int normal_fill(uint32_t *st, int32_t &left, uint64_t &next, float *out, int64_t n, int n_threads)
+{
+    mt_uniforms(st, left, next, out, n);
+    const int64_t blocks = n / 16;
+    const int nt = (int)std::min<int64_t>(std::max(1, n_threads), std::max<int64_t>(1, blocks / 512));
+    std::atomic<int> rc{0};
+    auto work = [&](int t) {
+        const int64_t b0 = blocks * t / nt, b1 = blocks * (t + 1) / nt;
+        if (const int r = ure_host_normal_blocks(out + 16 * b0, b1 - b0, 0.0f, 1.0f)) rc.store(r);
+    };
+    if (nt > 1) {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+    } else {
+        work(0);
+    }
+    if (rc.load()) return rc.load();
+    if (n % 16) {
+        mt_uniforms(st, left, next, out + n - 16, 16);
+        return ure_host_normal_blocks(out + n - 16, 1, 0.0f, 1.0f);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int ure_host_mf_init(uint8_t *state, int64_t n_bytes, int64_t skip_draws, float *U0, int64_t nu, float *V0, int64_t nv, int n_threads)
+{
+    constexpr int N = 624;
+    if (!state || n_bytes < (int64_t)(24 + 8 * N) || skip_draws < 0 || nu < 0 || nv < 0 || (nu && !U0) || (nv && !V0))
+        return ure::fail(-1, "ure_host_mf_init: bad arguments");
+    if ((nu && nu < 16) || (nv && nv < 16)) return ure::fail(-1, "ure_host_mf_init: a fill of fewer than 16 elements takes ATen's scalar path, not restated");
+    if (skip_draws)
+        if (const int r = ure_host_mt_advance(state, n_bytes, skip_draws)) return r;
+    int32_t left;
+    uint64_t next;
+    __builtin_memcpy(&left, state + 8, 4);
+    __builtin_memcpy(&next, state + 16, 8);
+    uint64_t *wide = reinterpret_cast<uint64_t *>(state + 24);
+    if (left < 1 || left > N || next > (uint64_t)N) return ure::fail(-1, "ure_host_mf_init: not a torch CPU generator state (left=%d next=%llu)", left, (unsigned long long)next);
+    uint32_t st[N];
+    for (int k = 0; k < N; ++k) st[k] = (uint32_t)wide[k];
+    int rc = 0;
+    if (nu) rc = normal_fill(st, left, next, U0, nu, n_threads);
+    if (!rc && nv) rc = normal_fill(st, left, next, V0, nv, n_threads);
+    if (rc) return ure::fail(rc, "ure_host_mf_init: the AVX2 kernels of the installed PyTorch are not available in this build or on this CPU");
+    for (int k = 0; k < N; ++k) wide[k] = st[k];
+    __builtin_memcpy(state + 8, &left, 4);
+    __builtin_memcpy(state + 16, &next, 8);
+    return 0;
+}
+

@@ -131,15 +131,49 @@ def model_draws(n_user, n_item, k, epochs, with_total_test):
     return fills, fills, 2 * epochs * (4 if with_total_test else 3)
 
 
-def mf_init(n_user, n_item, k, generator=None):
+_NATIVE_FILL = [None]
+
+
+def native_fill_ok():
+    """Whether ure_host_mf_init reproduces THIS torch build's `tensor.normal_()` bit for bit (csrc/host_rng.cpp, host_normal_avx2.cpp:
+    ATen's AVX2 fill through the installed PyTorch's own avx_mathfun kernels), established once per process on three pairs of fills
+    from a state in the middle of a generator block -- lengths with and without the redrawn tail, several blocks --: tables and end
+    state compared.  URE_NATIVE_FILL=0 keeps torch's fill."""
+    if _NATIVE_FILL[0] is None:
+        import os
+        ok = os.environ.get('URE_NATIVE_FILL', '1') != '0'
+        if ok:
+            from . import _native as nv
+            g = torch.Generator()
+            g.manual_seed(20240607)
+            torch.empty(5, dtype=torch.int64).random_(generator=g)
+            for nu, nv_ in ((1616, 41), (16, 2000), (4099, 4112)):
+                st = g.get_state().clone()
+                want = [torch.empty(n).normal_(0, 1, generator=g) for n in (nu, nv_)]
+                got = [torch.empty(n) for n in (nu, nv_)]
+                rc = nv.lib().ure_host_mf_init(st.data_ptr(), st.numel(), 0, got[0].data_ptr(), nu, got[1].data_ptr(), nv_, 2)
+                ok = ok and rc == 0 and all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(want, got)) and torch.equal(st, g.get_state())
+        _NATIVE_FILL[0] = bool(ok)
+    return _NATIVE_FILL[0]
+
+
+def mf_init(n_user, n_item, k, generator=None, threads=1):
     """The four N(0,1) fills of `MF(n_user, n_item, k)` (utils.py:31-40).  The first two (the nn.Embedding
-    constructors') are overwritten by init_weight: the stream is moved past them without computing them.
-    (The kept fills stay torch's own `normal_`: this build's kernel for the 16-blocks is ATen's vector polynomial path, which a
-    libm restatement does not reproduce -- tried, 40 % of the values differ in the last bits --, and cutting a fill into pieces that
-    torch fills side by side from skipped-ahead generators -- bit-identical -- lost more to the interpreter lock than it won:
-    profiles/r04/NOTES.md 6.)"""
+    constructors') are overwritten by init_weight: the stream is moved past them without computing them.  The two kept ones come
+    from ONE native call (ure_host_mf_init: the uniforms in bulk, the 16-blocks through the installed PyTorch's own kernels on
+    `threads` threads) where that reproduces torch's fill bit for bit (native_fill_ok), else from torch itself."""
     g = generator
     draws = model_draws(n_user, n_item, k, 0, False)
+    if draws is not None and native_fill_ok():
+        from . import _native as nv
+        state = (torch.get_rng_state() if g is None else g.get_state()).clone()
+        U0, V0 = torch.empty(n_user, k), torch.empty(n_item, k)
+        nv.check(nv.lib().ure_host_mf_init(state.data_ptr(), state.numel(), int(draws[0]), U0.data_ptr(), n_user * k, V0.data_ptr(), n_item * k,
+                                           max(1, int(threads))), 'ure_host_mf_init')
+        (torch.set_rng_state if g is None else g.set_state)(state)
+        STATS['skipped_draws'] += int(draws[0])
+        STATS['normals'] += (n_user + n_item) * k
+        return U0, V0
     if draws is None:
         torch.empty(n_user, k).normal_(0, 1, generator=g)
         torch.empty(n_item, k).normal_(0, 1, generator=g)
@@ -279,7 +313,11 @@ def release(perms):
                     chunks[-1][2][0].synchronize()
             else:
                 perms._ure_event.synchronize()
-            POOL.give(host)
+            shared = getattr(perms, '_ure_shared', None)
+            if shared is not None:
+                shared.drop()                   # (a view of a block the shards of a call share)
+            else:
+                POOL.give(host)
             perms._ure_host = None
         else:
             POOL.give(perms)
@@ -411,32 +449,49 @@ class _DrawsTask:
         if buffers:
             self.make_buffers()
 
-    def make_buffers(self):
-        """The permutations' host and device buffers and events, on the CALLING thread (the pool and the allocator see the caller's
-        current stream).  init() does not need them (start_inits), chunks() does."""
-        chunk_epochs, tags_batch = self._buffer_args
+    def _buffer_plan(self):
+        """-> (word type, epochs, rows) of the buffers chunks() fills and uploads, or None (no permutations, or not on a device)."""
+        _, tags_batch = self._buffer_args
         _, _, _, _, epochs, _, n_rows, shuffle, _, want_perms = self.args
         big = n_rows >= (2 ** 32 - 1) // 20
         # tags_batch = B > 0: the permutations leave the host as BATCH TAGS (uint16 [epochs, n_rows]: the step of the epoch in which
         # every interaction trains; struct ure_shard: file_tags; engine.TrainJob tells them from permutations by their dtype) -- half
         # the bytes on PCIe, and no partition phases on the device.  Only on the chunked device path.
         self.tags_batch = int(tags_batch) if (self.device is not None and 0 < -(-n_rows // max(int(tags_batch), 1)) <= 65535) else 0
-        word = torch.int16 if self.tags_batch else torch.int32
-        if want_perms and shuffle and n_rows > 0 and epochs > 0 and not big:
-            self.host = POOL.take((epochs, n_rows), word)
-            if self.device is not None:
-                dev = self.device
-                self.on_dev = torch.empty((epochs, n_rows), dtype=word, device=dev)
-                self.ready = torch.cuda.Event()
-                self.ready.record(torch.cuda.current_stream(dev))
-                self.on_dev._ure_host = self.host
-                # chunks of at least chunk_epochs epochs and ~4 MB: every chunk costs its worker ~0.1 ms of Python (slices, a copy,
-                # an event) under the GIL, and a request of 16 small shards had 112 of them competing with the calling thread
-                chunk_epochs = max(int(chunk_epochs), -(-(4 << 20) // ((2 if self.tags_batch else 4) * n_rows)))
-                self.on_dev._ure_chunks = [(min(epochs, c0 + chunk_epochs), threading.Event(), [None]) for c0 in range(0, epochs, chunk_epochs)]
-                if self.error is not None:                  # the init failed before the buffers were there: never leave a consumer waiting
-                    for _, flag, _ in self.on_dev._ure_chunks:
-                        flag.set()
+        if not (want_perms and shuffle and n_rows > 0 and epochs > 0 and not big):
+            return None
+        return (torch.int16 if self.tags_batch else torch.int32), epochs, n_rows
+
+    def _adopt(self, host, on_dev, ready, shared=None):
+        """Take the buffers (views of a block all shards of a call share, or this shard's own)."""
+        chunk_epochs, _ = self._buffer_args
+        _, _, _, _, epochs, _, n_rows = self.args[:7]
+        self.host, self.on_dev, self.ready = host, on_dev, ready
+        if on_dev is None:
+            return
+        on_dev._ure_host, on_dev._ure_shared = host, shared
+        # chunks of at least chunk_epochs epochs and ~4 MB: every chunk costs its worker ~0.1 ms of Python (slices, a copy,
+        # an event) under the GIL, and a request of 16 small shards had 112 of them competing with the calling thread
+        chunk_epochs = max(int(chunk_epochs), -(-(4 << 20) // ((2 if self.tags_batch else 4) * n_rows)))
+        on_dev._ure_chunks = [(min(epochs, c0 + chunk_epochs), threading.Event(), [None]) for c0 in range(0, epochs, chunk_epochs)]
+        if self.error is not None:                  # the init failed before the buffers were there: never leave a consumer waiting
+            for _, flag, _ in on_dev._ure_chunks:
+                flag.set()
+
+    def make_buffers(self):
+        """The permutations' host and device buffers and events, on the CALLING thread (the pool and the allocator see the caller's
+        current stream).  init() does not need them (start_inits), chunks() does."""
+        plan = self._buffer_plan()
+        if plan is None:
+            return
+        word, epochs, n_rows = plan
+        host = POOL.take((epochs, n_rows), word)
+        on_dev = ready = None
+        if self.device is not None:
+            on_dev = torch.empty((epochs, n_rows), dtype=word, device=self.device)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+        self._adopt(host, on_dev, ready)
 
     def fail(self, exc):
         """Never leave a consumer waiting: init() / the chunk flags are released, the exception is kept for result()."""
@@ -569,6 +624,48 @@ class ShardDraws:
         return self.init(), self.perms()
 
 
+class _SharedBlock:
+    """One pooled host block that the shards of a call share: it goes back to the pool when the last of them lets go."""
+
+    def __init__(self, block, users):
+        self.block, self.left, self.lock = block, users, threading.Lock()
+
+    def drop(self):
+        with self.lock:
+            self.left -= 1
+            last = self.left == 0
+        if last:
+            POOL.give(self.block)
+
+
+def make_buffers_together(tasks):
+    """make_buffers for the shards of one call from ONE host block, ONE device allocation and one event (a buffer, an allocation and an
+    event per shard were 16 x 0.1-0.2 ms of the calling thread at 16 shards, beside 16 busy init workers).  Shards that cannot share
+    (no device, another word type) get their own."""
+    plans = [(t, t._buffer_plan()) for t in tasks]
+    share = [(t, p) for t, p in plans if p is not None and t.device is not None]
+    if len(share) < 2 or len({(p[0], str(t.device)) for t, p in share}) != 1:
+        share = []
+    if share:
+        word, dev = share[0][1][0], share[0][0].device
+        al = lambda x: (x + 63) // 64 * 64
+        offs, at = [], 0
+        for _, (_, epochs, n_rows) in share:
+            offs.append(at)
+            at += al(epochs * n_rows)
+        host_all = POOL.take((at,), word)
+        dev_all = torch.empty(at, dtype=word, device=dev)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        block = _SharedBlock(host_all, len(share))
+        for (t, (_, epochs, n_rows)), o in zip(share, offs):
+            t._adopt(host_all[o:o + epochs * n_rows].view(epochs, n_rows), dev_all[o:o + epochs * n_rows].view(epochs, n_rows), ready, block)
+    shared = {id(t) for t, _ in share}
+    for t, p in plans:
+        if id(t) not in shared:
+            t.make_buffers()
+
+
 def _task_of(sp, buffers=True):
     return _DrawsTask(sp['start_state'], sp['n_user'], sp['n_item'], sp['k'], sp['epochs'], sp['with_total_test'], sp.get('n_rows', 0),
                       sp.get('shuffle', False), sp.get('threads', 0), sp.get('device'), sp.get('want_perms', True), sp.get('chunk_epochs', 8),
@@ -605,9 +702,9 @@ def draws_batch_async(specs, n_workers=0, gate=None, tasks=None):
     if started:
         for t, sp in zip(tasks, specs):
             t.args = t.args[:8] + (int(sp.get('threads', 0) or 0),) + t.args[9:]
-            t.make_buffers()
     else:
-        tasks = [_task_of(sp) for sp in specs]
+        tasks = [_task_of(sp, buffers=False) for sp in specs]
+    make_buffers_together(tasks)
     W = max(1, min(len(tasks), int(n_workers) if n_workers else max(2, host_cpus() // 2)))
 
     def work(mine):
