@@ -606,6 +606,56 @@ def test_mt_advance_matches_torch_generator_state():
         rng.advance_state(torch.zeros(16, dtype=torch.uint8), 5)
 
 
+def test_native_model_init_is_torchs_own_fill_bit_for_bit():
+    """ure_host_mf_init (utils.py:31-40's kept fills: uniforms off the generator in bulk, the 16-blocks through the installed
+    PyTorch's own AVX2 kernels) against `tensor.normal_()`: tables AND generator state, for lengths with and without the redrawn
+    tail, from states at the start and in the middle of a generator block, on 1 and 3 threads; the Box-Muller half alone; and the
+    refusals.  Where this build cannot reproduce torch (no AVX2, another PyTorch) rng.native_fill_ok() is False and rng.mf_init keeps
+    torch's fill -- checked too."""
+    from ultrare_amd import _native as nv, rng
+    L = nv.lib()
+    rng._NATIVE_FILL[0] = None
+    ok = rng.native_fill_ok()
+    g, h = torch.Generator(), torch.Generator()
+    for seed, pre in ((1, 0), (7, 333), (42, 624 * 3 + 1)):
+        g.manual_seed(seed)
+        if pre:
+            torch.empty(pre, dtype=torch.int32).random_(generator=g)
+        for (n_user, n_item, k) in ((6040, 3416, 32), (1508, 2071, 16), (37, 5, 5), (1, 16, 1), (313, 17, 3)):
+            if min(n_user, n_item) * k < 16:
+                continue
+            h.set_state(g.get_state())
+            for threads in (1, 3):
+                g.set_state(h.get_state())
+                U0, V0 = rng.mf_init(n_user, n_item, k, generator=g, threads=threads)
+                rng._NATIVE_FILL[0] = False                      # torch's own four fills
+                try:
+                    gt = torch.Generator()
+                    gt.set_state(h.get_state())
+                    for rows in (n_user, n_item):
+                        torch.empty(rows, k).normal_(0, 1, generator=gt)
+                    Ut, Vt = torch.empty(n_user, k).normal_(0, 1, generator=gt), torch.empty(n_item, k).normal_(0, 1, generator=gt)
+                finally:
+                    rng._NATIVE_FILL[0] = ok
+                assert torch.equal(U0.view(torch.int32), Ut.view(torch.int32)) and torch.equal(V0.view(torch.int32), Vt.view(torch.int32)), (seed, n_user, k, threads)
+                assert torch.equal(g.get_state(), gt.get_state())
+    if not ok:
+        pytest.skip('this build does not reproduce torch\'s AVX2 fill: rng.mf_init keeps torch\'s own (checked above)')
+    # the Box-Muller half alone, in place, equals normal_ on the same uniforms
+    g.manual_seed(5)
+    st = g.get_state()
+    want = torch.empty(16 * 200).normal_(0, 1, generator=g)
+    g.set_state(st)
+    u = torch.empty(16 * 200).uniform_(0, 1, generator=g)
+    assert L.ure_host_normal_blocks(u.data_ptr(), 200, 0.0, 1.0) == 0 and torch.equal(u.view(torch.int32), want.view(torch.int32))
+    # refusals: fewer than 16 elements (ATen's scalar path is not restated), not a generator state
+    st = g.get_state().clone()
+    buf = torch.empty(64)
+    assert L.ure_host_mf_init(st.data_ptr(), st.numel(), 0, buf.data_ptr(), 15, buf.data_ptr(), 16, 1) != 0
+    assert L.ure_host_mf_init(torch.zeros(5056, dtype=torch.uint8).data_ptr(), 5056, 0, buf.data_ptr(), 16, buf.data_ptr(), 16, 1) != 0
+    assert torch.equal(st, g.get_state())
+
+
 def test_shard_streams_reproduce_the_sequential_draws():
     """rng.shard_streams / mf_init(generator=) / epoch_seeds(generator=): every shard's draws taken from its own
     generator, positioned by skip-ahead, equal the draws a single generator makes shard after shard with the

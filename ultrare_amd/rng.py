@@ -157,7 +157,13 @@ def native_fill_ok():
     return _NATIVE_FILL[0]
 
 
-def mf_init(n_user, n_item, k, generator=None, threads=1):
+def fill_threads(n_normals, sharers=1):
+    """Host threads for the 16-blocks of a model init of n_normals values when `sharers` inits run side by side: one for small tables
+    (an ml-1m shard: 0.3 M values, 0.5 ms), up to eight for big ones (the 25 M shape at d = 128: 28 M values)."""
+    return 1 if n_normals < (2 << 20) else max(1, min(8, host_cpus() // max(1, int(sharers))))
+
+
+def mf_init(n_user, n_item, k, generator=None, threads=None):
     """The four N(0,1) fills of `MF(n_user, n_item, k)` (utils.py:31-40).  The first two (the nn.Embedding
     constructors') are overwritten by init_weight: the stream is moved past them without computing them.  The two kept ones come
     from ONE native call (ure_host_mf_init: the uniforms in bulk, the 16-blocks through the installed PyTorch's own kernels on
@@ -168,8 +174,9 @@ def mf_init(n_user, n_item, k, generator=None, threads=1):
         from . import _native as nv
         state = (torch.get_rng_state() if g is None else g.get_state()).clone()
         U0, V0 = torch.empty(n_user, k), torch.empty(n_item, k)
+        threads = fill_threads((n_user + n_item) * k) if threads is None else max(1, int(threads))
         nv.check(nv.lib().ure_host_mf_init(state.data_ptr(), state.numel(), int(draws[0]), U0.data_ptr(), n_user * k, V0.data_ptr(), n_item * k,
-                                           max(1, int(threads))), 'ure_host_mf_init')
+                                           threads), 'ure_host_mf_init')
         (torch.set_rng_state if g is None else g.set_state)(state)
         STATS['skipped_draws'] += int(draws[0])
         STATS['normals'] += (n_user + n_item) * k
@@ -445,6 +452,7 @@ class _DrawsTask:
         self.host = self.on_dev = self.ready = self.seeds = self.stream = None
         self.init_value = self.perms_value = None
         self.init_done, self.error = threading.Event(), None
+        self.sharers = 1                            # inits of the same call running beside this one (start_inits)
         self._buffer_args = (chunk_epochs, tags_batch)
         if buffers:
             self.make_buffers()
@@ -529,7 +537,7 @@ class _DrawsTask:
         mark('w: init start')
         g = torch.Generator()
         g.set_state(start_state)
-        init = mf_init(n_user, n_item, k, generator=g)
+        init = mf_init(n_user, n_item, k, generator=g, threads=fill_threads((n_user + n_item) * k, self.sharers))
         seeds = epoch_seeds(epochs, with_total_test, generator=g)
         if self.seeds is None:
             self.seeds = seeds
@@ -687,6 +695,7 @@ def start_inits(specs):
     tasks = [_task_of(sp, buffers=False) for sp in specs]
     pool = worker_pool()
     for t in tasks:
+        t.sharers = len(tasks)
         pool.submit(_guarded_init, t)
     return tasks
 
@@ -732,6 +741,7 @@ def draws_batch_async(specs, n_workers=0, gate=None, tasks=None):
 
     if not started:
         for t in tasks:
+            t.sharers = len(tasks)
             pool.submit(_guarded_init, t)               # the model inits, a worker each ...
     futures = [pool.submit(work, tasks[w::W]) for w in range(W)]      # ... and beside them the permutation chunks
     return [ShardDraws(futures[i % W], t) for i, t in enumerate(tasks)]
