@@ -107,6 +107,13 @@ def fill_draws(n):
 
 
 STATS = {'normals': 0, 'skipped_draws': 0}      # host work of this process: N(0, 1) values computed / generator outputs skipped
+_STATS_LOCK = threading.Lock()                  # (the model inits of a request run on a worker each)
+
+
+def _count(**kw):
+    with _STATS_LOCK:
+        for k, v in kw.items():
+            STATS[k] = STATS.get(k, 0) + int(v)
 
 
 def advance_state(state, n_draws, count=True):
@@ -114,7 +121,7 @@ def advance_state(state, n_draws, count=True):
     over draws that are accounted for elsewhere (STATS counts every output of the stream once)."""
     from . import _native as nv
     if count:
-        STATS['skipped_draws'] += int(n_draws)
+        _count(skipped_draws=n_draws)
     out = state.clone()
     nv.check(nv.lib().ure_host_mt_advance(out.data_ptr(), out.numel(), int(n_draws)), 'ure_host_mt_advance')
     return out
@@ -178,8 +185,7 @@ def mf_init(n_user, n_item, k, generator=None, threads=None):
         nv.check(nv.lib().ure_host_mf_init(state.data_ptr(), state.numel(), int(draws[0]), U0.data_ptr(), n_user * k, V0.data_ptr(), n_item * k,
                                            threads), 'ure_host_mf_init')
         (torch.set_rng_state if g is None else g.set_state)(state)
-        STATS['skipped_draws'] += int(draws[0])
-        STATS['normals'] += (n_user + n_item) * k
+        _count(skipped_draws=draws[0], normals=(n_user + n_item) * k)
         return U0, V0
     if draws is None:
         torch.empty(n_user, k).normal_(0, 1, generator=g)
@@ -190,7 +196,7 @@ def mf_init(n_user, n_item, k, generator=None, threads=None):
         g.set_state(advance_state(g.get_state(), draws[0]))
     U0 = torch.empty(n_user, k).normal_(0, 1, generator=g)
     V0 = torch.empty(n_item, k).normal_(0, 1, generator=g)
-    STATS['normals'] += (n_user + n_item) * k * (1 if draws is not None else 2)
+    _count(normals=(n_user + n_item) * k * (1 if draws is not None else 2))
     return U0, V0
 
 
@@ -243,7 +249,7 @@ def shard_streams(n_shards, n_user, n_item, k, epochs, with_total_test):
         key = (hashlib.blake2b(s.numpy().tobytes(), digest_size=16).digest(), int(n_shards), int(sum(draws)))
         hit = _STREAM_MEMO.get(key)
         if hit is not None:
-            STATS['memo_hits'] = STATS.get('memo_hits', 0) + 1
+            _count(memo_hits=1)
             return [t.clone() for t in hit[0]], hit[1].clone()
     starts = []
     for _ in range(n_shards):
