@@ -213,6 +213,21 @@ int ure_host_randperm(const int64_t *seeds, int n_perms, int64_t n, int32_t *out
 /* The same permutations as batch tags (struct ure_shard: file_tags): tags[t][perm_t[b]] = b / batch, uint16 (needs
  * ceil(n / batch) <= 65535 steps per epoch).  HOST memory.                                                       */
 int ure_host_randperm_tags(const int64_t *seeds, int n_perms, int64_t n, int32_t batch, uint16_t *tags, int n_threads);
+/* ABI 7.  The same tags made ON THE DEVICE (csrc/perm_tags.hip): MT19937's outputs by its three parallel phases per block, the shuffle
+ * with deterministic reservations (the sequential loop's permutation, whatever the timing), tags[f] = inverse[f] / batch.  One entry
+ * per permutation -- the shards and epochs of a request in one launch --: its seed (as ure_host_randperm_tags takes it), where its n
+ * tags go (device memory), n <= 2^18 rows, the batch size (ceil(n / batch) <= 65535).  perms: DEVICE memory; scratch: device memory of
+ * ure_device_randperm_tags_scratch(largest n, groups) 32-bit words; `groups` workgroups of 1,024 lanes make one permutation each at
+ * a time.  A word per group behind the groups' scratch is 0xdead if a group gave up (it cannot).                                */
+typedef struct ure_perm {
+    int64_t   seed;
+    uint16_t *tags;
+    int32_t   n;
+    int32_t   batch;
+} ure_perm_t;
+int64_t ure_device_randperm_tags_scratch(int64_t n_max, int32_t groups);
+int ure_device_randperm_tags(const ure_perm_t *perms, int32_t n_perms, int64_t n_max, uint32_t *scratch, int64_t scratch_words, int32_t groups,
+                             void *stream);
 /* Moves a torch CPU generator state (the bytes of torch.get_rng_state(): u64 seed, i32 left, i32 seeded,
  * u64 next, u64 state[624], ...) past `n_draws` 32-bit MT19937 outputs without producing them: the model
  * init fills the reference discards (utils.py:31-40: the nn.Embedding constructors' fills) and, in a

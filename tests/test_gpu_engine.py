@@ -561,3 +561,43 @@ def test_start_tables_of_all_shards_in_one_launch_and_losses_in_one_launch():
     nv.check(nv.lib().ure_epoch_sse_batch(n, (ctypes.c_void_p * n)(*[t.data_ptr() for t in sse]), (ctypes.c_int64 * n)(*users), E, again.data_ptr(),
                                           nv.stream_handle()), 'ure_epoch_sse_batch')
     assert torch.equal(out, again)
+
+
+@pytest.mark.parametrize('groups', [1, 7])
+def test_batch_tags_made_on_the_device_equal_the_hosts(groups):
+    """ure_device_randperm_tags (read.py:127-133: the RandomSampler's permutation of an epoch, as batch tags; MT19937 by its parallel
+    phases, the shuffle with deterministic reservations) against ure_host_randperm_tags -- itself pinned to torch.randperm in
+    tests/test_cpu_host.py -- bit for bit: shards of different sizes in ONE table (1 row, 2 rows, around the 624-output block of the
+    generator, 65,536 + 1, the largest the path takes), seeds of 62 bits, several batch sizes; no workgroup gave up."""
+    import ctypes
+    from ultrare_amd import _native as nv, rng
+    L = nv.lib()
+    dev = torch.device('cuda:0')
+    rs = np.random.RandomState(7)
+    cases = [(1, 1), (2, 1), (3, 2), (623, 100), (624, 7), (625, 624), (626, 1), (5000, 30000), (65537, 4097), (56321, 30000), (1 << 18, 30000)]
+    table, want, outs = [], [], []
+    for n, batch in cases:
+        reps = 1 if n > 100000 else 3
+        seeds = rs.randint(0, 2 ** 62, size=reps).astype(np.int64)
+        host = torch.empty(reps, n, dtype=torch.int16)
+        nv.check(L.ure_host_randperm_tags(seeds.ctypes.data, reps, n, batch, host.data_ptr(), 4), 'ure_host_randperm_tags')
+        out = torch.full((reps, n), -1, dtype=torch.int16, device=dev)
+        for r in range(reps):
+            table.append((int(seeds[r]), out.data_ptr() + 2 * n * r, n, batch))
+        want.append(host)
+        outs.append(out)
+    tab = np.array(table, dtype=rng.PERM_DTYPE)
+    assert tab.itemsize == 24
+    tab_d = torch.from_numpy(tab.view(np.uint8)).to(dev)
+    n_max = max(n for n, _ in cases)
+    words = int(L.ure_device_randperm_tags_scratch(n_max, groups))
+    scratch = torch.empty(words, dtype=torch.int32, device=dev)
+    nv.check(L.ure_device_randperm_tags(tab_d.data_ptr(), len(tab), n_max, scratch.data_ptr(), words, groups, nv.stream_handle()), 'ure_device_randperm_tags')
+    torch.cuda.synchronize()
+    for (n, batch), host, out in zip(cases, want, outs):
+        assert torch.equal(out.cpu(), host), (n, batch)
+    flags = scratch[2 * ((n_max + 63) // 64 * 64) * min(groups, len(tab)):][:groups].cpu()
+    assert int(flags.abs().sum()) == 0
+    # refusals: more than 2^18 rows, scratch too small
+    assert L.ure_device_randperm_tags(tab_d.data_ptr(), 1, (1 << 18) + 1, scratch.data_ptr(), words, 1, None) != 0
+    assert L.ure_device_randperm_tags(tab_d.data_ptr(), len(tab), n_max, scratch.data_ptr(), 16, groups, None) != 0

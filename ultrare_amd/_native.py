@@ -60,6 +60,8 @@ _PROTOTYPES = {
                                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64)]),
     'ure_host_randperm': (ctypes.c_int, [_vp, ctypes.c_int, _i64, _vp, ctypes.c_int]),
     'ure_host_randperm_tags': (ctypes.c_int, [_vp, ctypes.c_int, _i64, _i32, _vp, ctypes.c_int]),
+    'ure_device_randperm_tags_scratch': (_i64, [_i64, _i32]),
+    'ure_device_randperm_tags': (ctypes.c_int, [_vp, _i32, _i64, _vp, _i64, _i32, _vp]),
     'ure_host_mt_advance': (ctypes.c_int, [_vp, _i64, _i64]),
     'ure_host_mf_init': (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, ctypes.c_int]),
     'ure_host_normal_blocks': (ctypes.c_int, [_vp, _i64, ctypes.c_float, ctypes.c_float]),

@@ -680,6 +680,89 @@ def make_buffers_together(tasks):
             t.make_buffers()
 
 
+PERM_DTYPE = np.dtype([('seed', '<i8'), ('tags', '<u8'), ('n', '<i4'), ('batch', '<i4')])        # struct ure_perm
+DEVICE_TAGS_MAX_ROWS = 1 << 18
+DEVICE_TAGS_GROUPS = 128
+_PERM_STREAMS = {}
+
+
+def device_tags_wanted():
+    import os
+    return os.environ.get('URE_DEVICE_TAGS', '0') == '1'
+
+
+def device_tags(tasks):
+    """The batch tags of a call's shards made on the DEVICE (ure_device_randperm_tags: csrc/perm_tags.hip) instead of by host threads:
+    the seeds come by skip-ahead (_DrawsTask.seeds_first), every (shard, epoch) is one entry of ONE descriptor table, and the epochs go
+    out in a few launches on a side stream -- chunk c of all shards together --, each with the event TrainJob.run waits for before
+    the launches that read it.  No host buffer, no upload, no expansion threads.  -> False when a shard cannot take this path (too
+    many rows, no tags, tables too small to skip ahead): the caller falls back to the host path for the whole call."""
+    from . import _native as nv
+    from .engine import upload_many
+    plans = [t._buffer_plan() for t in tasks]
+    if not tasks or any(p is None or p[0] != torch.int16 or p[2] > DEVICE_TAGS_MAX_ROWS or t.device is None for t, p in zip(tasks, plans)):
+        return False
+    if len({str(t.device) for t in tasks}) != 1 or not all(t.seeds_first() for t in tasks):
+        return False
+    dev = tasks[0].device
+    epochs = plans[0][1]
+    if any(p[1] != epochs for p in plans):
+        return False
+    al = lambda x: (x + 63) // 64 * 64
+    offs, at = [], 0
+    for _, e, n_rows in plans:
+        offs.append(at)
+        at += al(e * n_rows)
+    main = torch.cuda.current_stream(dev)
+    dev_all = torch.empty(at, dtype=torch.int16, device=dev)
+    # chunks of epochs, the same for every shard: about DEVICE_TAGS_GROUPS permutations per launch (a workgroup each)
+    per = max(2, min(epochs, DEVICE_TAGS_GROUPS // max(1, len(tasks))))
+    bounds = list(range(0, epochs, per)) + [epochs]
+    table = np.zeros(len(tasks) * epochs, dtype=PERM_DTYPE)
+    at_row, launches = 0, []
+    for c0, c1 in zip(bounds[:-1], bounds[1:]):
+        lo = at_row
+        for t, (_, _, n_rows), o in zip(tasks, plans, offs):
+            rows = table[at_row:at_row + (c1 - c0)]
+            rows['seed'] = np.asarray(t.seeds[c0:c1], dtype=np.uint64).astype(np.int64)
+            rows['tags'] = dev_all.data_ptr() + 2 * (o + np.arange(c0, c1, dtype=np.int64) * n_rows)
+            rows['n'], rows['batch'] = n_rows, t.tags_batch
+            at_row += c1 - c0
+        launches.append((c1, lo, at_row))
+    n_max = max(p[2] for p in plans)
+    groups = min(DEVICE_TAGS_GROUPS, max(hi - lo for _, lo, hi in launches))
+    L = nv.lib()
+    words = int(L.ure_device_randperm_tags_scratch(n_max, groups))
+    scratch = torch.empty(words, dtype=torch.int32, device=dev)
+    table_dev = upload_many([table.view(np.uint8)], dev)[0]
+    side = _PERM_STREAMS.get(str(dev))
+    if side is None:
+        side = _PERM_STREAMS[str(dev)] = torch.cuda.Stream(dev)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    side.wait_event(ready)
+    events = []
+    for c1, lo, hi in launches:
+        nv.check(L.ure_device_randperm_tags(table_dev.data_ptr() + lo * PERM_DTYPE.itemsize, hi - lo, n_max, scratch.data_ptr(), words, groups,
+                                            side.cuda_stream), 'ure_device_randperm_tags')
+        ev = torch.cuda.Event()
+        ev.record(side)
+        events.append((c1, ev))
+    for t, (_, e, n_rows), o in zip(tasks, plans, offs):
+        on_dev = dev_all[o:o + e * n_rows].view(e, n_rows)
+        t.host, t.on_dev, t.ready = None, on_dev, ready
+        on_dev._ure_host, on_dev._ure_shared = None, None
+        on_dev._ure_keep = (scratch, table_dev, dev_all)          # (alive as long as the tags are: the side stream works on them)
+        chunks = []
+        for c1, ev in events:
+            flag = threading.Event()
+            flag.set()
+            chunks.append((c1, flag, [ev]))
+        on_dev._ure_chunks = chunks
+        t.perms_value = on_dev
+    return True
+
+
 def _task_of(sp, buffers=True):
     return _DrawsTask(sp['start_state'], sp['n_user'], sp['n_item'], sp['k'], sp['epochs'], sp['with_total_test'], sp.get('n_rows', 0),
                       sp.get('shuffle', False), sp.get('threads', 0), sp.get('device'), sp.get('want_perms', True), sp.get('chunk_epochs', 8),
@@ -719,7 +802,9 @@ def draws_batch_async(specs, n_workers=0, gate=None, tasks=None):
             t.args = t.args[:8] + (int(sp.get('threads', 0) or 0),) + t.args[9:]
     else:
         tasks = [_task_of(sp, buffers=False) for sp in specs]
-    make_buffers_together(tasks)
+    on_device = device_tags_wanted() and device_tags(tasks)
+    if not on_device:
+        make_buffers_together(tasks)
     W = max(1, min(len(tasks), int(n_workers) if n_workers else max(2, host_cpus() // 2)))
 
     def work(mine):
@@ -749,6 +834,11 @@ def draws_batch_async(specs, n_workers=0, gate=None, tasks=None):
         for t in tasks:
             t.sharers = len(tasks)
             pool.submit(_guarded_init, t)               # the model inits, a worker each ...
+    if on_device:                                       # (the tags are being made on the device: nothing left for chunk workers)
+        from concurrent.futures import Future
+        done = Future()
+        done.set_result(None)
+        return [ShardDraws(done, t) for t in tasks]
     futures = [pool.submit(work, tasks[w::W]) for w in range(W)]      # ... and beside them the permutation chunks
     return [ShardDraws(futures[i % W], t) for i, t in enumerate(tasks)]
 
