@@ -233,6 +233,9 @@ int ure_device_randperm_tags(const ure_perm_t *perms, int32_t n_perms, int64_t n
  * init fills the reference discards (utils.py:31-40: the nn.Embedding constructors' fills) and, in a
  * multi-rank run, the draws of the shards other ranks own.  In place.                       */
 int ure_host_mt_advance(uint8_t *state, int64_t n_bytes, int64_t n_draws);
+/* ABI 7.  n int64 values as `tensor.random_()` draws them (the per-epoch seeds of scratch.py:78-97: two 32-bit outputs each, the first
+ * the high word, bit 63 cleared) from a COPY of a torch CPU generator state moved past skip_draws outputs.  HOST memory.          */
+int ure_host_draw_int64(const uint8_t *state, int64_t n_bytes, int64_t skip_draws, int64_t n, int64_t *out);
 /* ABI 7.  MF.init_weight's kept fills (utils.py:31-40) from a torch CPU generator state: the state is moved past `skip_draws` outputs
  * (the nn.Embedding constructors' discarded fills), then U0 [nu] and V0 [nv] (each 0 or >= 16 elements) are filled as
  * `tensor.normal_()` fills a contiguous float32 tensor on an AVX2-capable host: the uniforms in generator order, then Box-Muller

@@ -271,6 +271,7 @@ def test_late_permutation_chunks_do_not_change_results(monkeypatch):
     from ultrare_amd.method.sisa import Sisa
     S, E = 3, 20
     idx, trd, ted, tot = _sisa_inputs(S)
+    monkeypatch.setenv('URE_DEVICE_TAGS', '0')          # (the host's chunk workers: with the tags made on the device there is nothing to be late)
     out = []
     for delay in (0.0, 0.03):
         monkeypatch.setattr(rng, '_TEST_CHUNK_DELAY_S', delay)
@@ -283,6 +284,25 @@ def test_late_permutation_chunks_do_not_change_results(monkeypatch):
     assert torch.equal(out[0][1], out[1][1])
     assert out[0][2]['train_loss'] == out[1][2]['train_loss'] and out[0][2]['total_ndcg'] == out[1][2]['total_ndcg']
     assert out[0][3] == out[1][3]
+
+
+def test_tags_made_on_the_device_train_like_the_hosts(monkeypatch):
+    """Sisa(parallel) with the epochs' batch tags made on the device (ure_device_randperm_tags, the default) and with the host's
+    expansion threads (URE_DEVICE_TAGS=0): the same models, the same logs, bit for bit."""
+    from ultrare_amd.method.sisa import Sisa
+    S, E = 4, 6
+    idx, trd, ted, tot = _sisa_inputs(S)
+    out = []
+    for mode in ('1', '0'):
+        monkeypatch.setenv('URE_DEVICE_TAGS', mode)
+        sisa = Sisa(Param(E, parallel=True), 'mf', S, idx)
+        torch.manual_seed(42)
+        ml = sisa.learn(trd, ted, tot, 0, '')
+        out.append(([m.item_mat.weight.detach().clone() for m in ml], ml[0].user_mat.weight.detach().clone(), dict(sisa.log), dict(sisa.log0)))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(out[0][1], out[1][1])
+    assert out[0][2] == out[1][2] and out[0][3] == out[1][3]
 
 
 def test_cli_default_trains_shards_side_by_side_and_prints_the_same_lines(tmp_path, capsys):

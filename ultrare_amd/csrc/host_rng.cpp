@@ -353,6 +353,43 @@ int normal_fill(uint32_t *st, int32_t &left, uint64_t &next, float *out, int64_t
 
 }  // namespace
 
+// The per-epoch seeds of scratch.py:78-97 without a generator object: `n` int64 values as `tensor.random_()` draws them (two 32-bit
+// outputs each, the first the high word, bit 63 cleared) from a COPY of the state moved past `skip_draws` outputs.
+extern "C" int ure_host_draw_int64(const uint8_t *state, int64_t n_bytes, int64_t skip_draws, int64_t n, int64_t *out)
+{
+    constexpr int N = 624;
+    if (!state || n_bytes < (int64_t)(24 + 8 * N) || skip_draws < 0 || n < 0 || (n && !out)) return ure::fail(-1, "ure_host_draw_int64: bad arguments");
+    std::vector<uint8_t> copy(state, state + n_bytes);
+    if (skip_draws)
+        if (const int r = ure_host_mt_advance(copy.data(), n_bytes, skip_draws)) return r;
+    int32_t left;
+    uint64_t next;
+    __builtin_memcpy(&left, copy.data() + 8, 4);
+    __builtin_memcpy(&next, copy.data() + 16, 8);
+    const uint64_t *wide = reinterpret_cast<const uint64_t *>(copy.data() + 24);
+    if (left < 1 || left > N || next > (uint64_t)N) return ure::fail(-1, "ure_host_draw_int64: not a torch CPU generator state (left=%d next=%llu)", left, (unsigned long long)next);
+    uint32_t st[N];
+    for (int k = 0; k < N; ++k) st[k] = (uint32_t)wide[k];
+    auto draw = [&]() {
+        if (--left == 0) {
+            mt_regenerate(st, 1);
+            left = N;
+            next = 0;
+        }
+        uint32_t x = st[next++];
+        x ^= x >> 11;
+        x ^= (x << 7) & 0x9d2c5680u;
+        x ^= (x << 15) & 0xefc60000u;
+        x ^= x >> 18;
+        return x;
+    };
+    for (int64_t k = 0; k < n; ++k) {
+        const uint64_t hi = draw(), lo = draw();
+        out[k] = (int64_t)(((hi << 32) | lo) & 0x7fffffffffffffffull);
+    }
+    return 0;
+}
+
 extern "C" int ure_host_mf_init(uint8_t *state, int64_t n_bytes, int64_t skip_draws, float *U0, int64_t nu, float *V0, int64_t nv, int n_threads)
 {
     constexpr int N = 624;

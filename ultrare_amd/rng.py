@@ -532,9 +532,13 @@ class _DrawsTask:
         draws = model_draws(n_user, n_item, k, 0, False)
         if draws is None or os.environ.get('URE_SEEDS_FIRST', '1') == '0':
             return False
-        g = torch.Generator()
-        g.set_state(advance_state(start_state, draws[0] + draws[1], count=False))
-        self.seeds = epoch_seeds(epochs, with_total_test, generator=g)
+        # (one native call: the state is copied, moved past the four fills and asked for the epochs' int64 draws -- as `random_()` makes them)
+        from . import _native as nv
+        per = 4 if with_total_test else 3
+        vals = np.empty(max(epochs, 0) * per, dtype=np.int64)
+        nv.check(nv.lib().ure_host_draw_int64(start_state.data_ptr(), start_state.numel(), int(draws[0] + draws[1]), len(vals), vals.ctypes.data),
+                 'ure_host_draw_int64')
+        self.seeds = vals[1::per].tolist()
         return True
 
     def init(self):
@@ -687,8 +691,9 @@ _PERM_STREAMS = {}
 
 
 def device_tags_wanted():
+    """URE_DEVICE_TAGS=0 keeps the host's expansion threads (the path of shards of more than 2^18 rows in any case)."""
     import os
-    return os.environ.get('URE_DEVICE_TAGS', '0') == '1'
+    return os.environ.get('URE_DEVICE_TAGS', '1') != '0'
 
 
 def device_tags(tasks):
@@ -718,17 +723,19 @@ def device_tags(tasks):
     # chunks of epochs, the same for every shard: about DEVICE_TAGS_GROUPS permutations per launch (a workgroup each)
     per = max(2, min(epochs, DEVICE_TAGS_GROUPS // max(1, len(tasks))))
     bounds = list(range(0, epochs, per)) + [epochs]
-    table = np.zeros(len(tasks) * epochs, dtype=PERM_DTYPE)
-    at_row, launches = 0, []
+    # the table in launch order -- (chunk, shard, epoch) --, built shard by epoch and reordered once
+    S = len(tasks)
+    n_of = np.array([p[2] for p in plans], dtype=np.int64)
+    full = np.zeros((S, epochs), dtype=PERM_DTYPE)
+    full['seed'] = np.array([t.seeds for t in tasks], dtype=np.uint64).astype(np.int64)
+    full['tags'] = dev_all.data_ptr() + 2 * (np.array(offs, dtype=np.int64)[:, None] + np.arange(epochs, dtype=np.int64)[None, :] * n_of[:, None])
+    full['n'] = n_of[:, None]
+    full['batch'] = np.array([t.tags_batch for t in tasks], dtype=np.int64)[:, None]
+    table = np.concatenate([full[:, c0:c1].reshape(-1) for c0, c1 in zip(bounds[:-1], bounds[1:])])
+    launches, at_row = [], 0
     for c0, c1 in zip(bounds[:-1], bounds[1:]):
-        lo = at_row
-        for t, (_, _, n_rows), o in zip(tasks, plans, offs):
-            rows = table[at_row:at_row + (c1 - c0)]
-            rows['seed'] = np.asarray(t.seeds[c0:c1], dtype=np.uint64).astype(np.int64)
-            rows['tags'] = dev_all.data_ptr() + 2 * (o + np.arange(c0, c1, dtype=np.int64) * n_rows)
-            rows['n'], rows['batch'] = n_rows, t.tags_batch
-            at_row += c1 - c0
-        launches.append((c1, lo, at_row))
+        launches.append((c1, at_row, at_row + S * (c1 - c0)))
+        at_row += S * (c1 - c0)
     n_max = max(p[2] for p in plans)
     groups = min(DEVICE_TAGS_GROUPS, max(hi - lo for _, lo, hi in launches))
     L = nv.lib()
@@ -748,17 +755,15 @@ def device_tags(tasks):
         ev = torch.cuda.Event()
         ev.record(side)
         events.append((c1, ev))
+    flag = threading.Event()
+    flag.set()
+    chunks = [(c1, flag, [ev]) for c1, ev in events]              # (the same for every shard: a launch holds chunk c of all of them)
     for t, (_, e, n_rows), o in zip(tasks, plans, offs):
         on_dev = dev_all[o:o + e * n_rows].view(e, n_rows)
         t.host, t.on_dev, t.ready = None, on_dev, ready
         on_dev._ure_host, on_dev._ure_shared = None, None
         on_dev._ure_keep = (scratch, table_dev, dev_all)          # (alive as long as the tags are: the side stream works on them)
-        chunks = []
-        for c1, ev in events:
-            flag = threading.Event()
-            flag.set()
-            chunks.append((c1, flag, [ev]))
-        on_dev._ure_chunks = chunks
+        on_dev._ure_chunks = list(chunks)
         t.perms_value = on_dev
     return True
 
