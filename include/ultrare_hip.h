@@ -216,7 +216,7 @@ int ure_host_randperm_tags(const int64_t *seeds, int n_perms, int64_t n, int32_t
 /* ABI 7.  The same tags made ON THE DEVICE (csrc/perm_tags.hip): MT19937's outputs by its three parallel phases per block, the shuffle
  * with deterministic reservations (the sequential loop's permutation, whatever the timing), tags[f] = inverse[f] / batch.  One entry
  * per permutation -- the shards and epochs of a request in one launch --: its seed (as ure_host_randperm_tags takes it), where its n
- * tags go (device memory), n <= 2^18 rows, the batch size (ceil(n / batch) <= 65535).  perms: DEVICE memory; scratch: device memory of
+ * tags go (device memory), n <= 2^20 rows, the batch size (ceil(n / batch) <= 65535).  perms: DEVICE memory; scratch: device memory of
  * ure_device_randperm_tags_scratch(largest n, groups) 32-bit words; `groups` workgroups of 1,024 lanes make one permutation each at
  * a time.  A word per group behind the groups' scratch is 0xdead if a group gave up (it cannot).                                */
 typedef struct ure_perm {

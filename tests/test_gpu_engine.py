@@ -574,7 +574,7 @@ def test_batch_tags_made_on_the_device_equal_the_hosts(groups):
     L = nv.lib()
     dev = torch.device('cuda:0')
     rs = np.random.RandomState(7)
-    cases = [(1, 1), (2, 1), (3, 2), (623, 100), (624, 7), (625, 624), (626, 1), (5000, 30000), (65537, 4097), (56321, 30000), (1 << 18, 30000)]
+    cases = [(1, 1), (2, 1), (3, 2), (623, 100), (624, 7), (625, 624), (626, 1), (5000, 30000), (65537, 4097), (56321, 30000), ((1 << 18) + 5, 30000), (1 << 20, 30000)]
     table, want, outs = [], [], []
     for n, batch in cases:
         reps = 1 if n > 100000 else 3
@@ -598,6 +598,6 @@ def test_batch_tags_made_on_the_device_equal_the_hosts(groups):
         assert torch.equal(out.cpu(), host), (n, batch)
     flags = scratch[2 * ((n_max + 63) // 64 * 64) * min(groups, len(tab)):][:groups].cpu()
     assert int(flags.abs().sum()) == 0
-    # refusals: more than 2^18 rows, scratch too small
-    assert L.ure_device_randperm_tags(tab_d.data_ptr(), 1, (1 << 18) + 1, scratch.data_ptr(), words, 1, None) != 0
+    # refusals: more than 2^20 rows, scratch too small
+    assert L.ure_device_randperm_tags(tab_d.data_ptr(), 1, (1 << 20) + 1, scratch.data_ptr(), words, 1, None) != 0
     assert L.ure_device_randperm_tags(tab_d.data_ptr(), len(tab), n_max, scratch.data_ptr(), 16, groups, None) != 0

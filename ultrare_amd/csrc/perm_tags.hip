@@ -25,7 +25,7 @@ namespace {
 constexpr int kPermBlock = 1024;
 constexpr int kPermInFlight = 4;                 // pending swaps per lane: 4,096 per permutation
 constexpr int kMtN = 624, kMtM = 397;
-constexpr unsigned kPrioBits = 18;               // a swap's index: n <= 2^18 rows (larger shards keep the host path)
+constexpr unsigned kPrioBits = 20;               // a swap's index: n <= 2^20 rows (larger shards keep the host path); 4,096 rounds between wipes
 constexpr unsigned kRounds = 1u << (32 - kPrioBits);
 constexpr int kResWords = 16384;                // reservation words in LDS (64 KB)
 
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kPermBlock) void perm_tags_kernel(const ure_perm_t 
         // ---- the identity, and the swap counter
         for (int f = tid; f < n; f += kPermBlock) inv[f] = (unsigned)f;
         if (tid == 0) next_p = 0u;
-        __threadfence_block();
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the partners and the identity are written before anybody reads them
         __syncthreads();
         // ---- the swaps i = n - 2 - p, p = 0 .. n - 2 (p: the swap's index in running order = its priority)
         unsigned pr[kPermInFlight];                              // 0xffffffff: the slot is empty
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kPermBlock) void perm_tags_kernel(const ure_perm_t 
                 mine += pr[k] != 0xffffffffu;
             }
             if (!__syncthreads_or((int)mine)) break;              // nobody holds a swap and none is left to admit
-            if (round == 0u) {                                   // the round counter wrapped: wipe the reservations (never in practice: 16,383 rounds)
+            if (round == 0u) {                                   // the round counter wrapped: wipe the reservations (a shuffle of 2^20 rows takes ~400 rounds; the counter runs on from shuffle to shuffle)
                 for (int f = tid; f < kResWords; f += kPermBlock) res[f] = 0xffffffffu;
                 round = kRounds - 1;
                 __syncthreads();
@@ -176,7 +176,7 @@ extern "C" int ure_device_randperm_tags(const ure_perm_t *perms, int32_t n_perms
     URE_ARG(n_perms >= 0 && n_max >= 0 && groups > 0);
     if (n_perms == 0 || n_max == 0) return 0;
     URE_ARG(perms && scratch);
-    if (n_max > (int64_t)(1 << ure::kPrioBits)) return ure::fail(-1, "ure_device_randperm_tags: %lld rows: more than 2^18 (such shards keep the host path)", (long long)n_max);
+    if (n_max > (int64_t)(1 << ure::kPrioBits)) return ure::fail(-1, "ure_device_randperm_tags: %lld rows: more than 2^20 (such shards keep the host path)", (long long)n_max);
     const int g = std::min<int>(groups, n_perms);
     if (scratch_words < ure_device_randperm_tags_scratch(n_max, g)) return ure::fail(-1, "ure_device_randperm_tags: scratch too small");
     const int64_t per_group = 2 * ((n_max + 63) / 64 * 64);

@@ -685,13 +685,13 @@ def make_buffers_together(tasks):
 
 
 PERM_DTYPE = np.dtype([('seed', '<i8'), ('tags', '<u8'), ('n', '<i4'), ('batch', '<i4')])        # struct ure_perm
-DEVICE_TAGS_MAX_ROWS = 1 << 18
+DEVICE_TAGS_MAX_ROWS = 1 << 20
 DEVICE_TAGS_GROUPS = 128
 _PERM_STREAMS = {}
 
 
 def device_tags_wanted():
-    """URE_DEVICE_TAGS=0 keeps the host's expansion threads (the path of shards of more than 2^18 rows in any case)."""
+    """URE_DEVICE_TAGS=0 keeps the host's expansion threads (the path of shards of more than 2^20 rows in any case)."""
     import os
     return os.environ.get('URE_DEVICE_TAGS', '1') != '0'
 
