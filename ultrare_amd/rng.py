@@ -686,7 +686,7 @@ def make_buffers_together(tasks):
 
 PERM_DTYPE = np.dtype([('seed', '<i8'), ('tags', '<u8'), ('n', '<i4'), ('batch', '<i4')])        # struct ure_perm
 DEVICE_TAGS_MAX_ROWS = 1 << 20
-DEVICE_TAGS_GROUPS = 128
+DEVICE_TAGS_GROUPS = 256            # workgroups (= permutations at a time) per launch: 32 / 64 / 128 / 256 -> 13.4 / 11.2 / 9.8 / 9.7 ms per 5-shard request, 18.4 / 14.8 / 12.8 / 12.3 at 16 shards
 _PERM_STREAMS = {}
 
 
@@ -721,7 +721,9 @@ def device_tags(tasks):
     main = torch.cuda.current_stream(dev)
     dev_all = torch.empty(at, dtype=torch.int16, device=dev)
     # chunks of epochs, the same for every shard: about DEVICE_TAGS_GROUPS permutations per launch (a workgroup each)
-    per = max(2, min(epochs, DEVICE_TAGS_GROUPS // max(1, len(tasks))))
+    import os
+    max_groups = int(os.environ.get('URE_DEVICE_TAGS_GROUPS', '0')) or DEVICE_TAGS_GROUPS
+    per = max(2, min(epochs, max_groups // max(1, len(tasks))))
     bounds = list(range(0, epochs, per)) + [epochs]
     # the table in launch order -- (chunk, shard, epoch) --, built shard by epoch and reordered once
     S = len(tasks)
@@ -737,7 +739,7 @@ def device_tags(tasks):
         launches.append((c1, at_row, at_row + S * (c1 - c0)))
         at_row += S * (c1 - c0)
     n_max = max(p[2] for p in plans)
-    groups = min(DEVICE_TAGS_GROUPS, max(hi - lo for _, lo, hi in launches))
+    groups = min(max_groups, max(hi - lo for _, lo, hi in launches))
     L = nv.lib()
     words = int(L.ure_device_randperm_tags_scratch(n_max, groups))
     scratch = torch.empty(words, dtype=torch.int32, device=dev)
