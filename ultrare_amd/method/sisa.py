@@ -62,17 +62,18 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
     layouts = None
     own_ids = [i for pos, i in enumerate(ids) if owner[pos] == rank]
 
-    def start_layouts():
+    def start_layouts(allocate=True):
         from ..read import plan_shard_layouts
         finish = plan_shard_layouts([as_loader(train_dlist[i]) for i in own_ids], n_user, n_item, engine._device(), k)
         fut = rng.worker_pool().submit(finish)               # (the native builder starts now ...
-        finish.allocate()                                    #  ... and the device allocations are made beside it)
+        if allocate:
+            finish.allocate()                                #  ... and the device allocations are made beside it)
         engine.mark('layouts planned')
-        return fut
+        return fut, finish.allocate
     streams = rng.shard_streams(len(ids), n_user, n_item, k, epochs, True) if on_device else None
     engine.mark('streams')
     if on_device and streams is None:
-        layouts = start_layouts()
+        layouts = start_layouts()[0]
     if streams is not None:
         # every shard's start state by skip-ahead; then, in the order of what the job waits for longest: the owned shards' model inits
         # (a worker each, started at once: rng.start_inits), the layouts (one native call on a worker, the device allocations beside
@@ -107,13 +108,19 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
             early = os.environ.get('URE_INITS_FIRST', '1') != '0'
             tasks = rng.start_inits(specs) if early else None
             engine.mark('inits started')
-            layouts = start_layouts()
+            # the layouts' native builder goes first (a worker); then the epochs' batch tags are put on their way (rng.draws_batch_async: made on
+            # the device from the seeds, or by host workers); the layouts' device allocations -- which the builder's worker needs only when it
+            # is done -- come last
+            layouts, allocate_layouts = start_layouts(allocate=False)
             # few workers, several shards each (rng.draws_batch_async): the expansion threads of a worker's native calls share
             # the rank's CPUs
             W = max(1, min(len(specs), int(os.environ.get('URE_DRAW_WORKERS', '0')) or max(2, rng.host_cpus() // 2)))
             for sp in specs:
                 sp['threads'] = max(2, PERM_THREADS // W)
-            futures = dict(zip(order, rng.draws_batch_async(specs, W, gate, tasks=tasks)))
+            try:
+                futures = dict(zip(order, rng.draws_batch_async(specs, W, gate, tasks=tasks)))
+            finally:
+                allocate_layouts()                           # (whatever happened: the builder's worker waits for it)
             engine.mark('draws submitted')
             shards = dict(zip(own_ids, layouts.result()))
         finally:
