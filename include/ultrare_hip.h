@@ -243,6 +243,10 @@ int ure_host_draw_int64(const uint8_t *state, int64_t n_bytes, int64_t skip_draw
  * threads; the state ends where torch's would.  -4: those kernels are not in this build / not supported by this CPU.  The Python
  * side checks the function against torch once per process and keeps torch's fill when a bit differs.  HOST memory.           */
 int ure_host_mf_init(uint8_t *state, int64_t n_bytes, int64_t skip_draws, float *U0, int64_t nu, float *V0, int64_t nv, int n_threads);
+/* The same for all shards of a request in one call: shard s from states[s] (in / out), skip_draws[s], into U0[s] [nu], V0[s] [nv]; the
+ * shards side by side on n_threads threads.                                                                                   */
+int ure_host_mf_init_batch(int32_t n_shards, uint8_t *const *states, int64_t n_bytes, const int64_t *skip_draws, float *const *U0, int64_t nu,
+                           float *const *V0, int64_t nv, int n_threads);
 /* The Box-Muller half alone: data [16 n_blocks] uniforms -> normals in place (ATen's normal_fill_16_AVX2).  0, or -4 as above. */
 int ure_host_normal_blocks(float *data, int64_t n_blocks, float mean, float std_);
 

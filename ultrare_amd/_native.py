@@ -65,6 +65,7 @@ _PROTOTYPES = {
     'ure_host_mt_advance': (ctypes.c_int, [_vp, _i64, _i64]),
     'ure_host_draw_int64': (ctypes.c_int, [_vp, _i64, _i64, _i64, _vp]),
     'ure_host_mf_init': (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, ctypes.c_int]),
+    'ure_host_mf_init_batch': (ctypes.c_int, [_i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, ctypes.c_int]),
     'ure_host_normal_blocks': (ctypes.c_int, [_vp, _i64, ctypes.c_float, ctypes.c_float]),
     'ure_host_read_csv': (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                          ctypes.POINTER(_i64), ctypes.c_int]),

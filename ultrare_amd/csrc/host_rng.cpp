@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -413,6 +414,36 @@ extern "C" int ure_host_mf_init(uint8_t *state, int64_t n_bytes, int64_t skip_dr
     for (int k = 0; k < N; ++k) wide[k] = st[k];
     __builtin_memcpy(state + 8, &left, 4);
     __builtin_memcpy(state + 16, &next, 8);
+    return 0;
+}
+
+// The model inits of all shards of a request in ONE call: shard s from its own generator state (in / out), on n_threads threads side by
+// side (a request of 16 shards started 16 Python workers for this; each spent as long under the interpreter lock as in here).
+extern "C" int ure_host_mf_init_batch(int32_t n_shards, uint8_t *const *states, int64_t n_bytes, const int64_t *skip_draws, float *const *U0, int64_t nu,
+                                      float *const *V0, int64_t nv, int n_threads)
+{
+    if (n_shards < 0 || (n_shards > 0 && (!states || !skip_draws || !U0 || !V0))) return ure::fail(-1, "ure_host_mf_init_batch: bad arguments");
+    if (n_shards == 0) return 0;
+    int nt = n_threads > 0 ? n_threads : ure::host_threads();
+    nt = std::max(1, std::min(nt, (int)n_shards));
+    const int inner = std::max(1, (n_threads > 0 ? n_threads : ure::host_threads()) / (int)n_shards);      // threads to spare go into each fill
+    std::atomic<int> next{0}, rc{0};
+    std::vector<std::string> why((size_t)n_shards);
+    auto work = [&]() {
+        for (int s = next.fetch_add(1); s < n_shards; s = next.fetch_add(1)) {
+            const int r = ure_host_mf_init(states[s], n_bytes, skip_draws[s], U0[s], nu, V0[s], nv, inner);
+            if (r) { why[(size_t)s] = ure_last_error(); rc.store(r); }
+        }
+    };
+    if (nt == 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t) pool.emplace_back(work);
+        for (auto &th : pool) th.join();
+    }
+    if (rc.load())
+        for (int s = 0; s < n_shards; ++s)
+            if (!why[(size_t)s].empty()) return ure::fail(rc.load(), "ure_host_mf_init_batch: shard %d: %s", s, why[(size_t)s].c_str());
     return 0;
 }
 

@@ -10,6 +10,7 @@ be taken up front and the permutations expanded later (or on other threads).
   torch DataLoader        _base_seed per iterator                      -> draw_seed
   torch RandomSampler     seed -> Generator -> randperm(N)             -> epoch_perm
 """
+import ctypes
 import threading
 
 import numpy as np
@@ -790,10 +791,73 @@ def start_inits(specs):
     buffers (a request: getting its layouts under way)."""
     tasks = [_task_of(sp, buffers=False) for sp in specs]
     pool = worker_pool()
+    if len(tasks) > 1 and _batch_init_possible(tasks):
+        pool.submit(_batch_init, tasks)                 # ONE worker, one native call for all shards' fills, one upload
+        return tasks
     for t in tasks:
         t.sharers = len(tasks)
         pool.submit(_guarded_init, t)
     return tasks
+
+
+def _batch_init_possible(tasks):
+    a = tasks[0].args
+    return (native_fill_ok() and all(t.args[1:4] == a[1:4] and t.args[4:6] == a[4:6] and t.device == tasks[0].device for t in tasks)
+            and model_draws(a[1], a[2], a[3], 0, False) is not None
+            and len(tasks) * (a[1] + a[2]) * a[3] * 4 <= (256 << 20))          # (one pinned block for all of them: small tables only)
+
+
+def _batch_init(tasks):
+    """The model inits of all shards of a call (same table sizes) by ONE native call (ure_host_mf_init_batch: the shards side by side on
+    host threads) into one pinned block, uploaded in one copy; every task gets its views.  (A worker per shard -- 16 Python threads at
+    configs[4] -- kept each other and the calling thread waiting for the interpreter lock: the layouts' worker started 2 ms late.)"""
+    from . import _native as nv
+    from .engine import mark
+    try:
+        mark('w: init start')
+        _, n_user, n_item, k, epochs, with_total_test = tasks[0].args[:6]
+        S, nu, nv_ = len(tasks), n_user * k, n_item * k
+        draws = model_draws(n_user, n_item, k, 0, False)
+        block = POOL.take((S, nu + nv_), torch.float32)
+        states = [t.args[0].clone() for t in tasks]
+        st_a = (ctypes.c_void_p * S)(*[x.data_ptr() for x in states])
+        base, row = block.data_ptr(), 4 * (nu + nv_)
+        u_a = (ctypes.c_void_p * S)(*[base + s * row for s in range(S)])
+        v_a = (ctypes.c_void_p * S)(*[base + s * row + 4 * nu for s in range(S)])
+        skip = (ctypes.c_int64 * S)(*([int(draws[0])] * S))
+        nv.check(nv.lib().ure_host_mf_init_batch(S, st_a, states[0].numel(), skip, u_a, nu, v_a, nv_, host_cpus()), 'ure_host_mf_init_batch')
+        _count(skipped_draws=S * draws[0], normals=S * (n_user + n_item) * k)
+        per = 4 if with_total_test else 3
+        for t, st in zip(tasks, states):
+            if t.seeds is None:                          # (the epochs' seeds follow the fills in the stream)
+                g = torch.Generator()
+                g.set_state(st)
+                t.seeds = epoch_seeds(epochs, with_total_test, generator=g)
+        mark('w: init drawn')
+        dev = tasks[0].device
+        if dev is not None:
+            with torch.cuda.device(dev):
+                up = tasks[0]._upload_stream()
+                with torch.cuda.stream(up):
+                    on_dev = block.to(dev, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(up)
+            POOL.give(block, ev)
+            for s, t in enumerate(tasks):
+                U0, V0 = on_dev[s, :nu].view(n_user, k), on_dev[s, nu:].view(n_item, k)
+                U0._ure_event = V0._ure_event = ev
+                t.init_value = (U0, V0)
+        else:
+            host = block.clone()
+            POOL.give(block)
+            for s, t in enumerate(tasks):
+                t.init_value = (host[s, :nu].view(n_user, k), host[s, nu:].view(n_item, k))
+        for t in tasks:
+            t.init_done.set()
+    except BaseException as e:
+        for t in tasks:
+            t.fail(e)
+        raise
 
 
 def draws_batch_async(specs, n_workers=0, gate=None, tasks=None):
