@@ -218,7 +218,8 @@ int ure_host_randperm_tags(const int64_t *seeds, int n_perms, int64_t n, int32_t
  * per permutation -- the shards and epochs of a request in one launch --: its seed (as ure_host_randperm_tags takes it), where its n
  * tags go (device memory), n <= 2^20 rows, the batch size (ceil(n / batch) <= 65535).  perms: DEVICE memory; scratch: device memory of
  * ure_device_randperm_tags_scratch(largest n, groups) 32-bit words; `groups` workgroups of 1,024 lanes make one permutation each at
- * a time.  A word per group behind the groups' scratch is 0xdead if a group gave up (it cannot).                                */
+ * a time.  Word 2 * align64(n_max) * groups + g of the scratch is set to 0xdead if workgroup g gave up (it cannot; the caller clears
+ * the words when it makes the scratch).                                                                                          */
 typedef struct ure_perm {
     int64_t   seed;
     uint16_t *tags;

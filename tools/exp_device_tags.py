@@ -19,7 +19,7 @@ from ultrare_amd import rng
 out = {'n': n, 'perms': P, 'batch': B, 'host_ms_16_threads': round(t_host * 1e3, 2)}
 for groups in [int(g) for g in opt('--groups', '16,32,64').split(',')]:
     words = int(L.ure_device_randperm_tags_scratch(n, groups))
-    scratch = torch.empty(words, dtype=torch.int32, device=dev)
+    scratch = torch.zeros(words, dtype=torch.int32, device=dev)
     tags = torch.zeros(P, n, dtype=torch.int16, device=dev)
     table = np.zeros(P, dtype=rng.PERM_DTYPE)
     table['seed'], table['n'], table['batch'] = seeds, n, B
@@ -32,8 +32,7 @@ for groups in [int(g) for g in opt('--groups', '16,32,64').split(',')]:
         nv.check(L.ure_device_randperm_tags(table_d.data_ptr(), P, n, scratch.data_ptr(), words, groups, nv.stream_handle()), 'device')
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
-    g_used = min(groups, P)
-    flags = scratch[2 * ((n + 63) // 64 * 64) * g_used:][:g_used].cpu().tolist()
+    flags = scratch[2 * ((n + 63) // 64 * 64) * groups:][:groups].cpu().tolist()
     same = bool(torch.equal(tags.cpu(), host))
     out[f'groups_{groups}'] = {'ms': round(min(ts) * 1e3, 3), 'equal_to_host': same, 'gave_up_flags': [f for f in flags if f]}
     if not same:

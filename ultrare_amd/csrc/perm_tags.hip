@@ -47,7 +47,8 @@ __device__ __forceinline__ unsigned mt_temper(unsigned x)
 __device__ __forceinline__ unsigned ld_coherent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coherent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(kPermBlock) void perm_tags_kernel(const ure_perm_t *__restrict__ perms, int n_perms, unsigned *__restrict__ scratch, int64_t words_per_group)
+__global__ __launch_bounds__(kPermBlock) void perm_tags_kernel(const ure_perm_t *__restrict__ perms, int n_perms, unsigned *__restrict__ scratch, int64_t words_per_group,
+                                                               unsigned *__restrict__ gave_up)
 {
     __shared__ unsigned st[2][kMtN];
     __shared__ unsigned next_p;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(kPermBlock) void perm_tags_kernel(const ure_perm_t 
         unsigned spins = 0;
         for (;;) {
             if (++spins > 4u * total + 1024u) {                   // (cannot happen: the oldest pending swap is carried out in every round)
-                if (tid == 0) scratch[(size_t)gridDim.x * words_per_group + blockIdx.x] = 0xdeadu;
+                if (tid == 0) gave_up[blockIdx.x] = 0xdeadu;
                 break;
             }
             // admit new swaps into the empty slots, in order (the pending set stays closed under "older than a pending one")
@@ -178,10 +179,12 @@ extern "C" int ure_device_randperm_tags(const ure_perm_t *perms, int32_t n_perms
     URE_ARG(perms && scratch);
     if (n_max > (int64_t)(1 << ure::kPrioBits)) return ure::fail(-1, "ure_device_randperm_tags: %lld rows: more than 2^20 (such shards keep the host path)", (long long)n_max);
     const int g = std::min<int>(groups, n_perms);
-    if (scratch_words < ure_device_randperm_tags_scratch(n_max, g)) return ure::fail(-1, "ure_device_randperm_tags: scratch too small");
+    if (scratch_words < ure_device_randperm_tags_scratch(n_max, groups)) return ure::fail(-1, "ure_device_randperm_tags: scratch too small");
     const int64_t per_group = 2 * ((n_max + 63) / 64 * 64);
-    URE_HIP(hipMemsetAsync(scratch + (size_t)g * per_group, 0, sizeof(uint32_t) * (size_t)g, static_cast<hipStream_t>(stream)));
-    hipLaunchKernelGGL(ure::perm_tags_kernel, dim3((unsigned)g), dim3(ure::kPermBlock), 0, static_cast<hipStream_t>(stream), perms, (int)n_perms, scratch, per_group);
+    // (the flags sit behind the scratch of `groups` workgroups, whatever this launch uses of them; they are never cleared here: a caller
+    // that reads them clears them when it makes the scratch)
+    hipLaunchKernelGGL(ure::perm_tags_kernel, dim3((unsigned)g), dim3(ure::kPermBlock), 0, static_cast<hipStream_t>(stream), perms, (int)n_perms, scratch, per_group,
+                       scratch + (size_t)groups * per_group);
     URE_HIP(hipGetLastError());
     return 0;
 }

@@ -440,6 +440,7 @@ class Sisa(Scratch):
                 torch.cuda.current_stream(engine._device()).synchronize()
             host = stage.numpy().copy()
             rng.SMALL.give(stage)
+            rng.device_tags_check([prepared[i][2] for i in mine])       # (the device is idle here: one tiny read)
             res_host = host[:n_res].reshape(len(mine), 2, self.epochs, 3) if keep_logs else None
             sse_host = host[n_res:].reshape(len(mine), self.epochs)
         for pos, i in enumerate(mine):

@@ -744,6 +744,9 @@ def device_tags(tasks):
     L = nv.lib()
     words = int(L.ure_device_randperm_tags_scratch(n_max, groups))
     scratch = torch.empty(words, dtype=torch.int32, device=dev)
+    n_al = (n_max + 63) // 64 * 64
+    flags = scratch[2 * n_al * groups:2 * n_al * groups + groups]      # a word per workgroup: 0xdead if it ever gave up (device_tags_check)
+    flags.zero_()
     table_dev = upload_many([table.view(np.uint8)], dev)[0]
     side = _PERM_STREAMS.get(str(dev))
     if side is None:
@@ -766,9 +769,24 @@ def device_tags(tasks):
         t.host, t.on_dev, t.ready = None, on_dev, ready
         on_dev._ure_host, on_dev._ure_shared = None, None
         on_dev._ure_keep = (scratch, table_dev, dev_all)          # (alive as long as the tags are: the side stream works on them)
+        on_dev._ure_flags = flags
         on_dev._ure_chunks = list(chunks)
         t.perms_value = on_dev
     return True
+
+
+def device_tags_check(perms):
+    """After the request's device work is done (the caller has synchronised): did a workgroup of perm_tags_kernel give up?  It cannot -- the
+    oldest pending swap is carried out in every round -- but tags that were not made must not train silently.  perms: the tag tensors of
+    the call's shards (one shared flag array; read once)."""
+    seen = set()
+    for p in perms:
+        f = getattr(p, '_ure_flags', None)
+        if f is not None and f.data_ptr() not in seen:
+            seen.add(f.data_ptr())
+            if bool(f.ne(0).any()):
+                from ._native import NativeError
+                raise NativeError('ure_device_randperm_tags: a workgroup gave up on a shuffle (URE_DEVICE_TAGS=0 takes the host path)')
 
 
 def _task_of(sp, buffers=True):
