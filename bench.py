@@ -393,10 +393,12 @@ def unlearn_leg(a, data, shards, d):
            'unlearn_interactions': r['unlearn_interactions'],
            'layouts_built_in_timed_call': r['layouts_built'],
            'includes': 'a NEW request on a warm allocator: its own deletion set and freshly made in-memory loaders, so the timed call '
-                       'builds the HBM layouts of the shards it trains and uploads them (layouts_built_in_timed_call), draws the host RNG '
-                       'streams, runs 50 epochs of all retrained shards side by side with the per-epoch shard / total evaluations, merges '
+                       'builds the HBM layouts of the shards it trains and uploads them (layouts_built_in_timed_call), draws the model inits '
+                       "and the epochs' seeds from the host RNG streams, makes every epoch's batches (torch.randperm's permutations: on the device, "
+                       'csrc/perm_tags.hip), runs 50 epochs of all retrained shards side by side with the per-epoch shard / total evaluations, merges '
                        'the rows, runs the final test and destroys the job (its teardown is joined before the clock stops); the test sets '
                        'stay resident (a deletion does not change them)',
+           'batch_tags': 'device' if __import__('ultrare_amd.rng', fromlist=['rng']).device_tags_wanted() else 'host',
            'final_test': {'learn': r['log0'], 'unlearn': r['unlearn_log0']}, 'nan_shards': r['nan_shards']}
     return out, e2e
 

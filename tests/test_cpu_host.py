@@ -656,6 +656,47 @@ def test_native_model_init_is_torchs_own_fill_bit_for_bit():
     assert torch.equal(st, g.get_state())
 
 
+def test_batch_init_and_seed_draws_equal_torchs():
+    """ure_host_mf_init_batch (all shards of a request in one call, each from its own generator state) and ure_host_draw_int64 (the per-epoch
+    seeds of scratch.py:78-97 off a copy of a state moved past the fills) against torch: tables, end states, seeds."""
+    import ctypes
+    from ultrare_amd import _native as nv, rng
+    if not rng.native_fill_ok():
+        pytest.skip('this build does not reproduce torch\'s AVX2 fill')
+    L = nv.lib()
+    n_user, n_item, k, S, E = 301, 77, 7, 5, 9
+    nu, ni = n_user * k, n_item * k
+    g = torch.Generator()
+    g.manual_seed(11)
+    torch.empty(100).normal_(generator=g)
+    states, want = [], []
+    for s in range(S):
+        states.append(g.get_state().clone())
+        for rows in (n_user, n_item):                                    # the constructors' fills (skipped by the native call)
+            torch.empty(rows, k).normal_(0, 1, generator=g)
+        U, V = torch.empty(n_user, k).normal_(0, 1, generator=g), torch.empty(n_item, k).normal_(0, 1, generator=g)
+        seeds = torch.empty(E * 4, dtype=torch.int64).random_(generator=g)
+        want.append((U, V, seeds, g.get_state().clone()))
+    skip = rng.fill_draws(nu) + rng.fill_draws(ni)
+    block = torch.empty(S, nu + ni)
+    mine = [st.clone() for st in states]
+    st_a = (ctypes.c_void_p * S)(*[x.data_ptr() for x in mine])
+    u_a = (ctypes.c_void_p * S)(*[block[s].data_ptr() for s in range(S)])
+    v_a = (ctypes.c_void_p * S)(*[block[s].data_ptr() + 4 * nu for s in range(S)])
+    nv.check(L.ure_host_mf_init_batch(S, st_a, mine[0].numel(), (ctypes.c_int64 * S)(*([skip] * S)), u_a, nu, v_a, ni, 3), 'ure_host_mf_init_batch')
+    for s in range(S):
+        U, V, seeds, end = want[s]
+        assert torch.equal(block[s, :nu].view(n_user, k), U) and torch.equal(block[s, nu:].view(n_item, k), V)
+        got = np.empty(E * 4, dtype=np.int64)
+        nv.check(L.ure_host_draw_int64(states[s].data_ptr(), states[s].numel(), 2 * skip, E * 4, got.ctypes.data), 'ure_host_draw_int64')
+        assert np.array_equal(got, seeds.numpy()) and (got >= 0).all()
+        # the batch call leaves every state behind its two kept fills: the seeds follow
+        g2 = torch.Generator()
+        g2.set_state(mine[s])
+        assert torch.equal(torch.empty(E * 4, dtype=torch.int64).random_(generator=g2), seeds) and torch.equal(g2.get_state(), end)
+    assert L.ure_host_draw_int64(torch.zeros(5056, dtype=torch.uint8).data_ptr(), 5056, 0, 1, got.ctypes.data) != 0
+
+
 def test_shard_streams_reproduce_the_sequential_draws():
     """rng.shard_streams / mf_init(generator=) / epoch_seeds(generator=): every shard's draws taken from its own
     generator, positioned by skip-ahead, equal the draws a single generator makes shard after shard with the
