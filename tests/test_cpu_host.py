@@ -715,6 +715,12 @@ def test_shard_streams_reproduce_the_sequential_draws():
     torch.manual_seed(7)
     starts, after = rng.shard_streams(S, n_user, n_item, k, E, True)
     assert torch.equal(after, end)
+    for memo in ('0', '1', '1'):                              # the seeds read off the walk itself (and out of the memo, the third time)
+        os.environ['URE_STREAM_MEMO'] = memo
+        torch.manual_seed(7)
+        s2, a2, seeds = rng.shard_streams(S, n_user, n_item, k, E, True, want_seeds=True)
+        assert torch.equal(a2, end) and all(torch.equal(x, y) for x, y in zip(s2, starts)) and seeds == [w[2] for w in want]
+    os.environ.pop('URE_STREAM_MEMO', None)
     for i in reversed(range(S)):                              # any order: the streams are independent
         g = torch.Generator()
         g.set_state(starts[i])

@@ -70,7 +70,7 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
             finish.allocate()                                #  ... and the device allocations are made beside it)
         engine.mark('layouts planned')
         return fut, finish.allocate
-    streams = rng.shard_streams(len(ids), n_user, n_item, k, epochs, True) if on_device else None
+    streams = rng.shard_streams(len(ids), n_user, n_item, k, epochs, True, want_seeds=True) if on_device else None
     engine.mark('streams')
     if on_device and streams is None:
         layouts = start_layouts()[0]
@@ -79,7 +79,7 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
         # (a worker each, started at once: rng.start_inits), the layouts (one native call on a worker, the device allocations beside
         # it), and last the permutations' buffers and chunk workers (rng.draws_batch_async: seeds by skip-ahead, chunks round robin)
         import threading
-        starts, end = streams
+        starts, end, seeds = streams
         torch.set_rng_state(end)
         mine = [pos for pos in range(len(ids)) if owner[pos] == rank]
         # `gate` can hold the permutation expansion back until the layouts are built (URE_GATE=1).  Measured with the layouts as
@@ -99,7 +99,7 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
             chunk_epochs = int(os.environ.get('URE_CHUNK_EPOCHS', '0')) or max(8, -(-epochs * n_owned // 64))
             for pos, i in enumerate(ids):
                 loader = as_loader(train_dlist[i])
-                base = dict(start_state=starts[pos], n_user=n_user, n_item=n_item, k=k, epochs=epochs, with_total_test=True)
+                base = dict(start_state=starts[pos], n_user=n_user, n_item=n_item, k=k, epochs=epochs, with_total_test=True, seeds=seeds[pos])
                 if owner[pos] == rank:
                     specs.append(dict(base, n_rows=len(loader.dataset), shuffle=loader.shuffle, device=engine._device(),
                                       tags_batch=loader.batch_size if os.environ.get('URE_HOST_TAGS', '1') != '0' else 0,

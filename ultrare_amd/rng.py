@@ -231,10 +231,12 @@ def epoch_seeds(epochs, with_total_test, generator=None):
 _STREAM_MEMO = {}
 
 
-def shard_streams(n_shards, n_user, n_item, k, epochs, with_total_test):
+def shard_streams(n_shards, n_user, n_item, k, epochs, with_total_test, want_seeds=False):
     """The generator states at which each of n_shards consecutive Scratch.train calls starts, computed by
     skip-ahead (the draws are data independent), and the state after the last one.  With them every shard's
-    draws can be taken on its own thread from its own torch.Generator.  None when skipping is not possible."""
+    draws can be taken on its own thread from its own torch.Generator.  None when skipping is not possible.
+    want_seeds: -> (starts, end, seeds) with seeds[s] = the shard's per-epoch sampler seeds (epoch_seeds), read off the stream where
+    the walk passes them -- they follow the shard's four fills -- instead of by a second walk per shard later."""
     draws = model_draws(n_user, n_item, k, epochs, with_total_test)
     if draws is None:
         return None
@@ -251,16 +253,23 @@ def shard_streams(n_shards, n_user, n_item, k, epochs, with_total_test):
         hit = _STREAM_MEMO.get(key)
         if hit is not None:
             _count(memo_hits=1)
-            return [t.clone() for t in hit[0]], hit[1].clone()
-    starts = []
+            out = [t.clone() for t in hit[0]], hit[1].clone()
+            return out + ([list(x) for x in hit[2]],) if want_seeds else out
+    from . import _native as nv
+    per = 4 if with_total_test else 3
+    starts, seeds = [], []
     for _ in range(n_shards):
         starts.append(s)
-        s = advance_state(s, sum(draws))
+        s = advance_state(s, draws[0] + draws[1])                      # past the four fills ...
+        vals = np.empty(max(epochs, 0) * per, dtype=np.int64)          # ... the epochs' int64 draws as `random_()` makes them ...
+        nv.check(nv.lib().ure_host_draw_int64(s.data_ptr(), s.numel(), 0, len(vals), vals.ctypes.data), 'ure_host_draw_int64')
+        seeds.append(vals[1::per].tolist())
+        s = advance_state(s, draws[2])                                  # ... and past them
     if key is not None:
         if len(_STREAM_MEMO) >= 64:
             _STREAM_MEMO.clear()
-        _STREAM_MEMO[key] = ([t.clone() for t in starts], s.clone())
-    return starts, s
+        _STREAM_MEMO[key] = ([t.clone() for t in starts], s.clone(), [list(x) for x in seeds])
+    return (starts, s, seeds) if want_seeds else (starts, s)
 
 
 def epoch_perm(seed, n):
@@ -456,10 +465,11 @@ class _DrawsTask:
         nv.lib()
         self.args = (start_state, n_user, n_item, k, epochs, with_total_test, n_rows, shuffle, int(threads or 0), want_perms)
         self.device = torch.device(device) if device is not None and torch.device(device).type == 'cuda' else None
-        self.host = self.on_dev = self.ready = self.seeds = self.stream = None
+        self.host = self.on_dev = self.ready = self.stream = None
         self.init_value = self.perms_value = None
         self.init_done, self.error = threading.Event(), None
         self.sharers = 1                            # inits of the same call running beside this one (start_inits)
+        self.seeds = None                           # (a caller that knows them -- shard_streams(want_seeds=True) -- sets them: _task_of)
         self._buffer_args = (chunk_epochs, tags_batch)
         if buffers:
             self.make_buffers()
@@ -529,6 +539,8 @@ class _DrawsTask:
         moved past them (ure_host_mt_advance) draws them at once -- and the permutations, the bulk of a request's host work, are expanded
         beside the inits instead of behind them.  False: the tables are too small to skip (the seeds come with init())."""
         import os
+        if self.seeds is not None:
+            return True
         start_state, n_user, n_item, k, epochs, with_total_test = self.args[:6]
         draws = model_draws(n_user, n_item, k, 0, False)
         if draws is None or os.environ.get('URE_SEEDS_FIRST', '1') == '0':
@@ -790,9 +802,12 @@ def device_tags_check(perms):
 
 
 def _task_of(sp, buffers=True):
-    return _DrawsTask(sp['start_state'], sp['n_user'], sp['n_item'], sp['k'], sp['epochs'], sp['with_total_test'], sp.get('n_rows', 0),
+    t = _DrawsTask(sp['start_state'], sp['n_user'], sp['n_item'], sp['k'], sp['epochs'], sp['with_total_test'], sp.get('n_rows', 0),
                       sp.get('shuffle', False), sp.get('threads', 0), sp.get('device'), sp.get('want_perms', True), sp.get('chunk_epochs', 8),
                       sp.get('tags_batch', 0), buffers)
+    if sp.get('seeds') is not None:
+        t.seeds = list(sp['seeds'])
+    return t
 
 
 def _guarded_init(t):
