@@ -575,9 +575,11 @@ def test_batch_tags_made_on_the_device_equal_the_hosts(groups):
     dev = torch.device('cuda:0')
     rs = np.random.RandomState(7)
     cases = [(1, 1), (2, 1), (3, 2), (623, 100), (624, 7), (625, 624), (626, 1), (5000, 30000), (65537, 4097), (56321, 30000), ((1 << 18) + 5, 30000), (1 << 20, 30000)]
+    if groups == 1:
+        cases.append((70001, 999))          # 130 more shuffles on the one workgroup: its round counter (4,096 rounds between wipes of the reservations) wraps
     table, want, outs = [], [], []
     for n, batch in cases:
-        reps = 1 if n > 100000 else 3
+        reps = 130 if n == 70001 else 1 if n > 100000 else 3
         seeds = rs.randint(0, 2 ** 62, size=reps).astype(np.int64)
         host = torch.empty(reps, n, dtype=torch.int16)
         nv.check(L.ure_host_randperm_tags(seeds.ctypes.data, reps, n, batch, host.data_ptr(), 4), 'ure_host_randperm_tags')

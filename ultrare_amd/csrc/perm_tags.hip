@@ -44,9 +44,6 @@ __device__ __forceinline__ unsigned mt_temper(unsigned x)
     return x;
 }
 
-__device__ __forceinline__ unsigned ld_coherent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_coherent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 __global__ __launch_bounds__(kPermBlock) void perm_tags_kernel(const ure_perm_t *__restrict__ perms, int n_perms, unsigned *__restrict__ scratch, int64_t words_per_group,
                                                                unsigned *__restrict__ gave_up)
 {
