@@ -368,7 +368,10 @@ class _States:
     """TrainJob.state: per shard the views of the job's device memory ({'U', 'V', 'mU', 'mV', 'perm', 'sse', 'snap' ...}), made when first asked for."""
 
     def __init__(self, n, make):
-        self._n, self._make, self._got = n, make, {}
+        import weakref
+        # (a weak reference to the job's method: job -> state -> job would be a cycle, and a job's 0.7 GB of device memory -- 660 MB per
+        # request measured -- would wait for the cyclic collector instead of going back when the last reference to the job does)
+        self._n, self._make, self._got = n, weakref.WeakMethod(make), {}
 
     def __len__(self):
         return self._n
@@ -378,7 +381,10 @@ class _States:
         if not 0 <= s < self._n:
             raise IndexError(s)
         if s not in self._got:
-            self._got[s] = self._make(s)
+            make = self._make()
+            if make is None:
+                raise ReferenceError('the job of these views is gone')
+            self._got[s] = make(s)
         return self._got[s]
 
     def __iter__(self):
@@ -785,6 +791,11 @@ class TrainJob:
         if self._job:
             nv.lib().ure_job_destroy(self._job)
             self._job = ctypes.c_void_p()
+            # the device memory goes back now (ure_job_destroy has waited for the device): tables, snapshots, batch tags and what made them
+            self._pool = self._snap_pool = self._small = None
+            self._perms = []
+            if isinstance(getattr(self, 'state', None), _States):
+                self.state._got.clear()
 
     def __del__(self):
         try:
