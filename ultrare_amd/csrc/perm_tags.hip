@@ -88,8 +88,8 @@ __global__ __launch_bounds__(kPermBlock) void perm_tags_kernel(const ure_perm_t 
             }
             cur ^= 1;
         }
-        // ---- the identity, and the swap counter
-        for (int f = tid; f < n; f += kPermBlock) inv[f] = (unsigned)f;
+        // ---- the swap counter
+        if (tid == 0) inv[n - 1] = (unsigned)(n - 1);           // (the one position that is never a swap's own)
         if (tid == 0) next_p = 0u;
         __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the partners and the identity are written before anybody reads them
         __syncthreads();
@@ -140,11 +140,15 @@ __global__ __launch_bounds__(kPermBlock) void perm_tags_kernel(const ure_perm_t 
                     const unsigned v = tag | pr[k];
                     const unsigned got_i = res[pi[k] & (kResWords - 1)], got_j = res[pj[k] & (kResWords - 1)];
                     if (got_i == v && got_j == v) {
+                        // Position i is touched for the first time by swap i itself (every older swap lies to the right of it): it still holds i, and
+                        // nobody has to have written that.  So: one load, two stores, and no pass that writes the identity first.
+                        // (plain accesses: the lanes of a workgroup share their compute unit's L1, which its own stores keep current)
                         if (pj[k] != pi[k]) {
-                            // (plain accesses: the lanes of a workgroup share their compute unit's L1, which its own stores keep current)
-                            const unsigned a = inv[pi[k]], b = inv[pj[k]];
+                            const unsigned b = inv[pj[k]];
                             inv[pi[k]] = b;
-                            inv[pj[k]] = a;
+                            inv[pj[k]] = (unsigned)pi[k];
+                        } else {
+                            inv[pi[k]] = (unsigned)pi[k];
                         }
                         pr[k] = 0xffffffffu;
                     }
