@@ -99,26 +99,27 @@ __global__ __launch_bounds__(kPermBlock) void perm_tags_kernel(const ure_perm_t 
 #pragma unroll
         for (int k = 0; k < kPermInFlight; ++k) pr[k] = 0xffffffffu;
         const unsigned total = (unsigned)(n - 1);
+        // a slot takes the next swap in running order (the pending set stays closed under "older than a pending one")
+        auto admit = [&](int k) {
+            const unsigned p = atomicAdd(&next_p, 1u);
+            if (p < total) {
+                pr[k] = p;
+                pi[k] = n - 2 - (int)p;
+                pj[k] = pi[k] + (int)z[pi[k]];
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < kPermInFlight; ++k) admit(k);
         unsigned spins = 0;
         for (;;) {
             if (++spins > 4u * total + 1024u) {                   // (cannot happen: the oldest pending swap is carried out in every round)
                 if (tid == 0) gave_up[blockIdx.x] = 0xdeadu;
                 break;
             }
-            // admit new swaps into the empty slots, in order (the pending set stays closed under "older than a pending one")
             unsigned mine = 0;
 #pragma unroll
-            for (int k = 0; k < kPermInFlight; ++k) {
-                if (pr[k] == 0xffffffffu) {
-                    const unsigned p = atomicAdd(&next_p, 1u);
-                    if (p < total) {
-                        pr[k] = p;
-                        pi[k] = n - 2 - (int)p;
-                        pj[k] = pi[k] + (int)z[pi[k]];
-                    }
-                }
-                mine += pr[k] != 0xffffffffu;
-            }
+            for (int k = 0; k < kPermInFlight; ++k) mine += pr[k] != 0xffffffffu;
+            // (this barrier also ends the round before: its swaps are done -- the vmcnt wait below -- before anybody reserves again)
             if (!__syncthreads_or((int)mine)) break;              // nobody holds a swap and none is left to admit
             if (round == 0u) {                                   // the round counter wrapped: wipe the reservations (a shuffle of 2^20 rows takes ~400 rounds; the counter runs on from shuffle to shuffle)
                 for (int f = tid; f < kResWords; f += kPermBlock) res[f] = 0xffffffffu;
@@ -151,10 +152,10 @@ __global__ __launch_bounds__(kPermBlock) void perm_tags_kernel(const ure_perm_t 
                             inv[pi[k]] = (unsigned)pi[k];
                         }
                         pr[k] = 0xffffffffu;
+                        admit(k);                                // the slot's next swap: its partner is loaded beside this round's memory traffic
                     }
                 }
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            __syncthreads();                                     // the swaps of this round are done before the next round reserves
+            __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this round's stores are done (a workgroup fence would not wait for them)
         }
         // ---- the tags: file row f trains at position inv[f] of the epoch
         uint16_t *out = perms[perm].tags;
