@@ -136,10 +136,23 @@ def cold_request(shards=5, k=32, epochs=50, data=None):
         t['layouts_built'] = engine.ShardData.built - built0
         return ml, s, t
 
+    def median_of(ts):
+        # (the request whose total is the median of the repetitions, with every total listed: one timing on these shared hosts came out
+        # at 64 ms where the others gave 26-29)
+        order = sorted(range(len(ts)), key=lambda i: ts[i]['total_s'])
+        t = dict(ts[order[len(ts) // 2]])
+        t['total_s_all'] = [x['total_s'] for x in ts]
+        return t
+
     try:
         request([], None)                                   # warm-up: library load, allocator, pinned pool
-        ml, s, t_learn = request([], None)
-        ml2, s2, t_un = request(del_user, [copy.deepcopy(m) for m in ml])
+        learns, unlearns = [], []
+        for _ in range(3):
+            ml, s, t = request([], None)
+            learns.append(t)
+            ml2, s2, t = request(del_user, [copy.deepcopy(m) for m in ml])
+            unlearns.append(t)
+        t_learn, t_un = median_of(learns), median_of(unlearns)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return {'shards': shards, 'k': k, 'epochs': epochs, 'learn': t_learn, 'unlearn': t_un, 'retrained': len(s2.retrained),
