@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define URE_ABI_VERSION 7
+#define URE_ABI_VERSION 8
 #define URE_MAX_MODELS_PER_CALL 32
 #define URE_SCORE_PARTIALS 2048       /* length of ure_score's sse buffer */
 
@@ -234,6 +234,15 @@ int ure_device_randperm_tags(const ure_perm_t *perms, int32_t n_perms, int64_t n
  * init fills the reference discards (utils.py:31-40: the nn.Embedding constructors' fills) and, in a
  * multi-rank run, the draws of the shards other ranks own.  In place.                       */
 int ure_host_mt_advance(uint8_t *state, int64_t n_bytes, int64_t n_draws);
+/* ABI 8.  MT19937 jump-ahead (csrc/mt_jump.cpp), what ure_host_mt_advance uses beyond 4,096 blocks: st [624] = the words of a
+ * generator block (torch.get_rng_state()'s state[] narrowed to 32 bits) -> the block `blocks` regenerations later, in place, by
+ * x^(624 blocks - 1) modulo the generator's characteristic polynomial applied to the raw word sequence (~0.1 ms for any distance;
+ * the polynomial of a distance is memoised).  ure_host_mt_jump_support: the degrees of that polynomial's nonzero terms, ascending
+ * (< 19,937 of them; capacity 0 only counts) -- what the device-side jump of ure_device_mf_init convolves with.
+ * ure_host_mt_charpoly: the 135 exponents of the characteristic polynomial itself, ascending (tests recompute them). */
+int ure_host_mt_jump_blocks(uint32_t *st, int64_t blocks);
+int ure_host_mt_jump_support(int64_t blocks, uint16_t *support, int32_t capacity, int32_t *n_support);
+int ure_host_mt_charpoly(uint16_t *exponents, int32_t capacity);
 /* ABI 7.  n int64 values as `tensor.random_()` draws them (the per-epoch seeds of scratch.py:78-97: two 32-bit outputs each, the first
  * the high word, bit 63 cleared) from a COPY of a torch CPU generator state moved past skip_draws outputs.  HOST memory.          */
 int ure_host_draw_int64(const uint8_t *state, int64_t n_bytes, int64_t skip_draws, int64_t n, int64_t *out);

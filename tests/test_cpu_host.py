@@ -606,6 +606,120 @@ def test_mt_advance_matches_torch_generator_state():
         rng.advance_state(torch.zeros(16, dtype=torch.uint8), 5)
 
 
+def test_mt_charpoly_table_is_the_generators_own():
+    """csrc/mt_jump.cpp's table of MT19937's characteristic polynomial, recomputed here from the generator's output: Berlekamp-Massey on
+    one bit of 2 x 19,937 + 200 consecutive outputs (Python's `random` is MT19937; the polynomial is irreducible, so every output bit has
+    it as its minimal polynomial)."""
+    import random
+    from ultrare_amd import _native as nv
+    rnd = random.Random(12345)
+    n_bits = 2 * 19937 + 200
+    C, B, L, m, W = 1, 1, 0, 1, 0
+    for n in range(n_bits):
+        W = (W << 1) | (rnd.getrandbits(32) & 1)
+        if bin(C & W).count('1') & 1:
+            T = C
+            C ^= B << m
+            if 2 * L <= n:
+                L, B, m = n + 1 - L, T, 1
+            else:
+                m += 1
+        else:
+            m += 1
+    assert L == 19937
+    want = sorted(L - i for i in range(L + 1) if (C >> i) & 1)            # s_n = sum c_i s_(n-i)  ->  phi(x) = sum c_i x^(L-i)
+    got = np.zeros(135, dtype=np.uint16)
+    assert nv.lib().ure_host_mt_charpoly(got.ctypes.data, 135) == 135
+    assert got.tolist() == want and len(want) == 135 and want[-2] == 19314
+
+
+def test_mt_jump_equals_the_walk_byte_for_byte():
+    """ure_host_mt_advance beyond 4,096 blocks jumps (x^J modulo the characteristic polynomial on the raw word sequence); in pieces below
+    that threshold it walks.  Same generator state either way, from the start and the middle of a block, at distances on and off block
+    boundaries, up to BASELINE.json configs[3]'s per-shard distance and beyond -- and torch's own state after really making the draws."""
+    import ctypes
+    from ultrare_amd import _native as nv, rng
+    L = nv.lib()
+
+    def walk(s, n, step=2_000_000):
+        s = s.clone()
+        while n > 0:
+            c = min(n, step)
+            nv.check(L.ure_host_mt_advance(s.data_ptr(), s.numel(), c), 'ure_host_mt_advance')
+            n -= c
+        return s
+    torch.manual_seed(42)
+    fresh = torch.get_rng_state()                        # left = 1: the first draw regenerates
+    torch.empty(1000).normal_()
+    mid = torch.get_rng_state()
+    blk = 624
+    for s0 in (fresh, mid):
+        for n in (4096 * blk - 1, 4096 * blk, 4096 * blk + 1, 4160 * blk + 377, 5_000_000, 2 * (rng.fill_draws(162000 * 128) + rng.fill_draws(60000 * 128)) + 40,
+                  123_456_789):
+            assert torch.equal(walk(s0, n), rng.advance_state(s0, n, count=False)), n
+    # a chain of jumps = one long walk (the shards of a request)
+    a = b = mid
+    for _ in range(5):
+        a, b = walk(a, 7_000_003), rng.advance_state(b, 7_000_003, count=False)
+    assert torch.equal(a, b)
+    # torch itself
+    g = torch.Generator()
+    g.manual_seed(7)
+    st = g.get_state().clone()
+    torch.empty(6_000_000).normal_(generator=g)
+    assert torch.equal(rng.advance_state(st, 6_000_000, count=False), g.get_state())
+    # the block form and the support list
+    words = np.random.RandomState(3).randint(0, 2 ** 32, 624, dtype=np.uint64).astype(np.uint32)
+    ref = words.copy()
+    N, M = 624, 397
+    for _ in range(70):                                  # 70 plain regenerations in numpy
+        x = np.concatenate([ref, np.zeros(N, dtype=np.uint32)])
+        for k in range(N):
+            y = (x[k] & np.uint32(0x80000000)) | (x[k + 1] & np.uint32(0x7fffffff))
+            x[k + N] = x[k + M] ^ (y >> np.uint32(1)) ^ (np.uint32(0x9908b0df) if (y & np.uint32(1)) else np.uint32(0))
+        ref = x[N:].copy()
+    got = words.copy()
+    nv.check(L.ure_host_mt_jump_blocks(got.ctypes.data, 70), 'ure_host_mt_jump_blocks')
+    assert np.array_equal(got[1:], ref[1:]) and got[0] == ref[0]
+    n_sup = ctypes.c_int32()
+    sup = np.zeros(19937, dtype=np.uint16)
+    nv.check(L.ure_host_mt_jump_support(70, sup.ctypes.data, len(sup), ctypes.byref(n_sup)), 'ure_host_mt_jump_support')
+    assert 0 < n_sup.value < 19937 and np.all(np.diff(sup[:n_sup.value].astype(np.int64)) > 0)
+    assert L.ure_host_mt_jump_blocks(None, 5) != 0 and L.ure_host_mt_jump_support(0, sup.ctypes.data, len(sup), ctypes.byref(n_sup)) != 0
+
+
+def test_shard_streams_at_the_25m_shape_are_cheap_and_exact():
+    """the start states of configs[3]'s 32 shards (56.8 M outputs apart) in a cold process -- no memo -- within 20 ms
+    (round 4's walk: 0.2-0.6 s), and equal to states reached by walking."""
+    import time
+    from ultrare_amd import _native as nv, rng
+    L = nv.lib()
+    os.environ['URE_STREAM_MEMO'] = '0'
+    try:
+        torch.manual_seed(42)
+        s0 = torch.get_rng_state()
+        rng.shard_streams(2, 162000, 60000, 128, 5, True)            # (the polynomial of this distance is computed once per process)
+        torch.manual_seed(42)
+        t0 = time.perf_counter()
+        starts, end, seeds = rng.shard_streams(32, 162000, 60000, 128, 5, True, want_seeds=True)
+        took = time.perf_counter() - t0
+    finally:
+        os.environ.pop('URE_STREAM_MEMO', None)
+    assert took < 0.06, took                                          # (20 ms asked; CI hosts are noisy: 7-9 ms measured)
+    per = sum(rng.model_draws(162000, 60000, 128, 5, True))
+    s = s0.clone()
+    for i in (0, 1, 2):
+        assert torch.equal(starts[i], s)
+        n = per
+        while n > 0:                                                  # walked: pieces below the jump threshold
+            c = min(n, 2_000_000)
+            nv.check(L.ure_host_mt_advance(s.data_ptr(), s.numel(), c), 'ure_host_mt_advance')
+            n -= c
+    g = torch.Generator()
+    g.set_state(rng.advance_state(starts[1], sum(rng.model_draws(162000, 60000, 128, 5, True)[:2]), count=False))
+    assert rng.epoch_seeds(5, True, generator=g) == seeds[1]
+
+
 def test_native_model_init_is_torchs_own_fill_bit_for_bit():
     """ure_host_mf_init (utils.py:31-40's kept fills: uniforms off the generator in bulk, the 16-blocks through the installed
     PyTorch's own AVX2 kernels) against `tensor.normal_()`: tables AND generator state, for lengths with and without the redrawn
@@ -939,3 +1053,17 @@ def test_shard_streams_memo_returns_the_walked_states():
     b[0][0][100] ^= 1                                        # a caller's copy is its own
     torch.manual_seed(42)
     assert torch.equal(rng.shard_streams(3, 40, 30, 4, 2, True)[0][0], a[0][0])
+    # seeds out of the memo: the same total distance split differently -- other table sizes, epochs, draws per epoch -- is
+    # another entry, and a hit returns the seeds the sequential draws give
+    def sequential(n_user, n_item, k, epochs, per):
+        torch.manual_seed(42)
+        out = []
+        for _ in range(3):
+            for n in (n_user * k, n_item * k, n_user * k, n_item * k):
+                torch.empty(n).normal_()
+            out.append(torch.empty(epochs * per, dtype=torch.int64).random_()[1::per].tolist())
+        return out
+    for (n_user, n_item, k, epochs, total) in ((40, 30, 4, 2, True), (40, 30, 4, 2, True), (38, 32, 4, 2, True), (40, 28, 4, 4, True), (40, 30, 4, 2, False)):
+        torch.manual_seed(42)
+        got = rng.shard_streams(3, n_user, n_item, k, epochs, total, want_seeds=True)[2]
+        assert got == sequential(n_user, n_item, k, epochs, 4 if total else 3), (n_user, n_item, epochs, total)

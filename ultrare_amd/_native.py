@@ -11,7 +11,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('URE_LIB') or os.path.join(_PKG, 'libultrare_hip.so')      # URE_LIB: experiment builds (tools/) only
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_MODELS_PER_CALL = 32
 
 _vp = ctypes.c_void_p
@@ -63,6 +63,9 @@ _PROTOTYPES = {
     'ure_device_randperm_tags_scratch': (_i64, [_i64, _i32]),
     'ure_device_randperm_tags': (ctypes.c_int, [_vp, _i32, _i64, _vp, _i64, _i32, _vp]),
     'ure_host_mt_advance': (ctypes.c_int, [_vp, _i64, _i64]),
+    'ure_host_mt_jump_blocks': (ctypes.c_int, [_vp, _i64]),
+    'ure_host_mt_jump_support': (ctypes.c_int, [_i64, _vp, _i32, ctypes.POINTER(_i32)]),
+    'ure_host_mt_charpoly': (ctypes.c_int, [_vp, _i32]),
     'ure_host_draw_int64': (ctypes.c_int, [_vp, _i64, _i64, _i64, _vp]),
     'ure_host_mf_init': (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, ctypes.c_int]),
     'ure_host_mf_init_batch': (ctypes.c_int, [_i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, ctypes.c_int]),

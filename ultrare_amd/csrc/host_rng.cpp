@@ -22,6 +22,7 @@
 namespace ure {
 int fail(int code, const char *fmt, ...);
 int host_threads();
+int mt_jump_blocks(uint32_t *st, int64_t blocks);      // mt_jump.cpp
 }
 
 namespace {
@@ -237,6 +238,8 @@ URE_HOST_CLONES static void mt_regenerate(uint32_t *st, int64_t blocks)
     }
 }
 
+constexpr int64_t kJumpMinBlocks = 4096;      // 2.6 M outputs: ~0.8 ms of walking against ~0.1 ms (+ ~1 ms for a distance not seen before)
+
 extern "C" int ure_host_mt_advance(uint8_t *state, int64_t n_bytes, int64_t n_draws)
 {
     constexpr int N = 624;
@@ -265,7 +268,13 @@ extern "C" int ure_host_mt_advance(uint8_t *state, int64_t n_bytes, int64_t n_dr
         // whole blocks that are skipped entirely are regenerated back to back (AVX2 / AVX-512 clones of the loops: the skip-ahead of
         // a request's shards runs on the calling thread before any draw can start -- 1.0 ms of its critical path at 5 shards)
         const int64_t blocks = 1 + (n - 1) / N;                       // regenerations until fewer than N draws remain to take
-        mt_regenerate(st, blocks);
+        // Long distances are JUMPED (mt_jump.cpp: x^J mod the generator's characteristic polynomial, ~0.1 ms whatever J) in
+        // multiples of 64 blocks -- so that shards whose distances differ by a block share the memoised polynomial -- and the
+        // rest is walked: 56.8 M outputs per shard at BASELINE.json configs[3]'s shape took 19 ms each, on every rank.
+        const int64_t jumped = blocks >= kJumpMinBlocks ? blocks & ~(int64_t)63 : 0;
+        if (jumped)
+            if (const int r = ure::mt_jump_blocks(st, jumped)) return r;
+        mt_regenerate(st, blocks - jumped);
         n -= 1 + (blocks - 1) * (int64_t)N;                            // the last block's state[0] taken; all draws of the blocks before it
         left = N;
         next = 1;

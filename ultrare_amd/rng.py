@@ -241,22 +241,24 @@ def shard_streams(n_shards, n_user, n_item, k, epochs, with_total_test, want_see
     if draws is None:
         return None
     s = torch.get_rng_state()
-    # The walk is a pure function of (generator state, distance, count): 56.8 M outputs per shard at BASELINE.json configs[3]'s shape,
-    # 1.8 G for its 32 shards -- 0.2-0.6 s of MT19937 state updates on one thread in front of every request of every rank.  Requests
-    # that start from a state seen before (the harness seeds the generator before each top-level call: SURVEY D7) take the states
-    # from a small memo instead (32 x 5 KB); URE_STREAM_MEMO=0 walks every time.
+    # The states are a pure function of (generator state, the call's fills and seed draws, count).  Long distances are jumped
+    # (csrc/mt_jump.cpp: 56.8 M outputs per shard at BASELINE.json configs[3]'s shape in 0.2 ms instead of 19 ms of walking -- 7-9 ms for
+    # its 32 shards in a cold process, 0.2-0.6 s in round 4); short ones are walked: ~1 ms for a 5-shard ml-1m request.  Requests
+    # that start from a state seen before (the harness seeds the generator before each top-level call: SURVEY D7) take states and
+    # seeds from a small memo instead (32 x 5 KB); URE_STREAM_MEMO=0 computes every time.
     import hashlib
     import os
+    per = 4 if with_total_test else 3
     key = None
     if os.environ.get('URE_STREAM_MEMO', '1') != '0':
-        key = (hashlib.blake2b(s.numpy().tobytes(), digest_size=16).digest(), int(n_shards), int(sum(draws)))
+        # (everything the seeds depend on, not just the total distance: where the four fills end, how many draws an epoch makes, how many epochs)
+        key = (hashlib.blake2b(s.numpy().tobytes(), digest_size=16).digest(), int(n_shards), int(draws[0]), int(draws[1]), int(draws[2]), per, int(epochs))
         hit = _STREAM_MEMO.get(key)
         if hit is not None:
             _count(memo_hits=1)
             out = [t.clone() for t in hit[0]], hit[1].clone()
             return out + ([list(x) for x in hit[2]],) if want_seeds else out
     from . import _native as nv
-    per = 4 if with_total_test else 3
     starts, seeds = [], []
     for _ in range(n_shards):
         starts.append(s)
