@@ -257,8 +257,20 @@ int ure_host_mf_init(uint8_t *state, int64_t n_bytes, int64_t skip_draws, float 
  * shards side by side on n_threads threads.                                                                                   */
 int ure_host_mf_init_batch(int32_t n_shards, uint8_t *const *states, int64_t n_bytes, const int64_t *skip_draws, float *const *U0, int64_t nu,
                            float *const *V0, int64_t nv, int n_threads);
+/* ABI 8.  The same fills made ON THE DEVICE (csrc/mf_init.hip): U0[s] [nu] and V0[s] [nv] are DEVICE memory, everything else as
+ * ure_host_mf_init_batch -- states[s] (host, in / out) is moved past skip_draws[s] outputs and ends behind the two fills.  The host only
+ * positions generators (ure_host_mt_jump_blocks); the device cuts every shard's draws into segments of 1,024 generator blocks, reaches
+ * their start blocks by a doubling tree of jumps, regenerates and tempers the outputs in LDS and applies csrc/normal_math.h's Box-Muller
+ * -- bit for bit `tensor.normal_()` on an AVX2 host (the Python side checks that once per process and keeps the host fill otherwise).
+ * scratch: device memory of ure_device_mf_init_scratch(n_shards, nu, nv) 32-bit words, alive until the work on `stream` is done. */
+int64_t ure_device_mf_init_scratch(int32_t n_shards, int64_t nu, int64_t nv);
+int ure_device_mf_init(int32_t n_shards, uint8_t *const *states, int64_t n_bytes, const int64_t *skip_draws, float *const *U0, int64_t nu,
+                       float *const *V0, int64_t nv, uint32_t *scratch, int64_t scratch_words, int n_threads, void *stream);
 /* The Box-Muller half alone: data [16 n_blocks] uniforms -> normals in place (ATen's normal_fill_16_AVX2).  0, or -4 as above. */
 int ure_host_normal_blocks(float *data, int64_t n_blocks, float mean, float std_);
+/* ABI 8.  The same through the scalar restatement of that arithmetic which the device kernels run (csrc/normal_math.h), mean 0, std 1;
+ * variant 0 is the arithmetic of record, 1-3 the other readings of its two ambiguous mul + add pairs (tests only). */
+int ure_host_normal_blocks_scalar(float *data, int64_t n_blocks, int32_t variant);
 
 /* ---------------------------------------------------------------------------
  * Host-side ingest (HOST memory throughout; linear time, `n_threads` = 0 means all cores)
@@ -357,6 +369,13 @@ int ure_eval_series(const float *const *U_fixed, const float *const *V_fixed, in
                     const float *rating, int64_t n, int d, const int32_t *off, int32_t n_users, const double *log2_tab, float *base,
                     float *pred, double *sse, int32_t *hits, double *ndcg, double *out, const int32_t *top_rating, int32_t n_wide,
                     int32_t n_half, void *stream);
+
+/* ABI 8.  In ure_eval_series / ure_eval_series_compact / ure_eval_series_own, U_fixed == V_fixed == NULL with n_fixed > 0 means: `base`
+ * already holds the running sum over the n_fixed fixed models (the caller made it: one ure_score per distinct model with n_models = 1,
+ * first = 1, last = 0, then ure_sum_vectors in the ensemble's order -- the additions ure_score makes over a list, so the series'
+ * numbers are the same to the last bit).  A request of S shards scores every model once instead of once per later shard.
+ * ure_sum_vectors: out[j] = ((0 + v_0[j]) + v_1[j]) + ... over n_vectors device vectors of n floats.                       */
+int ure_sum_vectors(const float *const *vectors, int n_vectors, int64_t n, float *out, void *stream);
 
 /* The same series on COMPACT end-of-epoch snapshots (struct ure_shard: snap): member e's own model is
  * row r -> row_slot[r] >= 0 ? snap[e * stride + row_slot[r] * d ..] : snap_a[e] * (U0 | V0)[r], with row ids

@@ -72,6 +72,20 @@ def test_no_step_kernel_instantiation_spills(lib):
     assert all(r['vgpr_spill'] == 0 for r in isa_report.kernels(lib.LIB_PATH))
 
 
+def test_no_kernel_is_built_in_threadgroup_split_mode(lib):
+    """csrc/perm_tags.hip's waves hand inv[] to each other through global memory with workgroup-scope release (s_waitcnt vmcnt(0)) and
+    no acquire-side invalidate -- the LLVM AMDGPU memory model's sequence for NON-tgsplit mode only.  The TG_SPLIT bit of every kernel
+    descriptor of the built library must be clear, and the build refuses the flag."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import isa_report
+    rows = isa_report.kernels(lib.LIB_PATH)
+    assert any(r['name'].startswith('perm_tags_kernel') for r in rows)
+    assert all(r['tg_split'] == 0 for r in rows), [r['name'] for r in rows if r['tg_split'] != 0]
+    from ultrare_amd import build as lib_build
+    with pytest.raises(RuntimeError):
+        lib_build.build(force=True, defines=['X', 'Y -mtgsplit'], out='/tmp/never_built.so')
+
+
 def test_argument_errors_are_reported_not_crashed(lib):
     L = lib.lib()
     out = ctypes.c_void_p()
@@ -770,6 +784,29 @@ def test_native_model_init_is_torchs_own_fill_bit_for_bit():
     assert torch.equal(st, g.get_state())
 
 
+def test_scalar_normal_math_is_torchs_and_the_other_readings_are_not():
+    """csrc/normal_math.h -- the per-lane restatement of ATen's normal_fill_16_AVX2 that the DEVICE kernels run (csrc/mf_init.hip) -- on the
+    host against `tensor.normal_()` over 2^22 uniforms: variant 0 (the first product of an ambiguous mul + add pair is the fused one) is
+    torch's on every value; the three other readings of the two ambiguous pairs are not."""
+    from ultrare_amd import _native as nv
+    L = nv.lib()
+    g = torch.Generator()
+    g.manual_seed(5)
+    n = 1 << 22
+    st = g.get_state()
+    want = torch.empty(n).normal_(0, 1, generator=g)
+    if not torch.backends.cpu.get_cpu_capability().startswith(('AVX2', 'AVX512')):
+        pytest.skip('torch does not run its AVX2 fill on this host')
+    bad = []
+    for variant in range(4):
+        g.set_state(st)
+        u = torch.empty(n).uniform_(0, 1, generator=g)
+        assert L.ure_host_normal_blocks_scalar(u.data_ptr(), n // 16, variant) == 0
+        bad.append(int((u.view(torch.int32) != want.view(torch.int32)).sum()))
+    assert bad[0] == 0 and min(bad[1:]) > 0, bad
+    assert L.ure_host_normal_blocks_scalar(u.data_ptr(), 1, 4) != 0
+
+
 def test_batch_init_and_seed_draws_equal_torchs():
     """ure_host_mf_init_batch (all shards of a request in one call, each from its own generator state) and ure_host_draw_int64 (the per-epoch
     seeds of scratch.py:78-97 off a copy of a state moved past the fills) against torch: tables, end states, seeds."""
@@ -888,8 +925,7 @@ def test_batched_layout_builder_equals_the_single_one(lib):
 def test_draws_of_a_call_on_few_workers_equal_the_sequential_stream():
     """rng.draws_batch_async: the shards of a call on FEWER worker threads than shards (a worker takes several shards: all their
     inits, then their permutation chunks round robin) give every shard the init and the permutations of its place in the one
-    sequential stream; a gate holds the permutations back; a failing worker never leaves a consumer waiting."""
-    import threading
+    sequential stream; a failing worker never leaves a consumer waiting."""
     from ultrare_amd import rng
     S, n_user, n_item, k, E = 5, 37, 23, 8, 4
     torch.manual_seed(11)
@@ -899,15 +935,13 @@ def test_draws_of_a_call_on_few_workers_equal_the_sequential_stream():
         want.append((init, rng.epoch_seeds(E, True)))
     torch.manual_seed(11)
     starts, _ = rng.shard_streams(S, n_user, n_item, k, E, True)
-    gate = threading.Event()
     specs = [dict(start_state=starts[i], n_user=n_user, n_item=n_item, k=k, epochs=E, with_total_test=True, n_rows=300 + 10 * i, shuffle=True,
                   threads=2) for i in range(S)]
     specs[3].update(n_rows=0, shuffle=False, want_perms=False)         # a shard another rank owns: init only
-    draws = rng.draws_batch_async(specs, 2, gate)
-    for i, dr in enumerate(draws):                                     # the inits do not wait for the gate
+    draws = rng.draws_batch_async(specs, 2)
+    for i, dr in enumerate(draws):
         init = dr.init()
         assert torch.equal(init[0], want[i][0][0]) and torch.equal(init[1], want[i][0][1])
-    gate.set()
     for i, dr in enumerate(draws):
         perms = dr.perms()
         if i == 3:

@@ -374,10 +374,11 @@ def test_compact_snapshots_need_lazy_rows(toy):
     job.close()
 
 
-def test_early_own_scores_give_the_same_series(toy):
-    """The two-halves form of a series (TrainJob.early_scores: the shard's own scores on a second stream while training runs,
-    finish_series: fixed models + ranking afterwards) against evaluate_series on the same compact snapshots: identical, with and
-    without fixed models, for shards whose epochs end on different ticks, in both kernels."""
+def test_series_from_own_scores_and_from_cached_bases_are_the_same_series(toy):
+    """Two other routes to a shard's per-epoch series, against evaluate_series on the same compact snapshots, to the last bit:
+    (a) the two-halves form of the C ABI (ure_score_own_compact, then ure_eval_series_own); (b) the fixed models given as a cached base
+    (engine.ScoreCache: every model scored once per request, a shard's base = the vectors' sum in the ensemble's order -- what
+    Sisa(parallel) queues) -- with 0, 2 and 35 fixed models (more than one ure_score / ure_sum_vectors call holds), in both kernels."""
     from ultrare_amd import engine, rng
     from oracle import cpu_ref as O
     train, test = toy
@@ -390,19 +391,23 @@ def test_early_own_scores_give_the_same_series(toy):
     shards = [engine.ShardData(*p, N_USER, N_ITEM) for p in parts]
     total = engine.EvalSet(*test)
     own_sets = [engine.EvalSet(*t) for t in tests]
-    fixed = [tuple(torch.randn(n, engine.pad_dim(k), device=total.device) * 0.3 for n in (N_USER, N_ITEM)) for _ in range(2)]
+    many = [tuple(torch.randn(n, engine.pad_dim(k), device=total.device) * 0.3 for n in (N_USER, N_ITEM)) for _ in range(35)]
+    zeros = lambda: torch.zeros(E, 3, dtype=torch.float64, device=total.device)
     for touch in (False, True):
         job = engine.TrainJob(shards, inits, perms, k, B, E, 1e-3, 0.1, 0.9, 0.95, snapshots='compact', touch=touch, lazy_rows=True)
-        handles = [(job.early_scores(s, own_sets[s]), job.early_scores(s, total)) for s in range(S)]
-        assert all(h is not None for pair in handles for h in pair)
         job.run()
+        caches = {id(ev): engine.ScoreCache(ev, job.d) for ev in own_sets + [total]}
         for s in range(S):
-            for before in ([], fixed):
-                for h, ev in zip(handles[s], (own_sets[s], total)):
-                    got = job.finish_series(h, before, torch.zeros(E, 3, dtype=torch.float64, device=total.device))
-                    want = job.evaluate_series(s, ev, before, torch.zeros(E, 3, dtype=torch.float64, device=total.device))
+            for before in ([], many[:2], many):
+                for ev in (own_sets[s], total):
+                    want = job.evaluate_series(s, ev, before, zeros())
+                    got_own = ev.evaluate_series_own(before, job.own_scores(s, ev), job.d, zeros())
+                    base = caches[id(ev)].base([(('m', j), lambda j: many[j], j) for j in range(len(before))])
+                    assert len(base) == len(before)
+                    got_base = job.evaluate_series(s, ev, base, zeros())
                     torch.cuda.synchronize()
-                    assert torch.isfinite(want).all() and torch.equal(got, want), (touch, s, len(before))
+                    assert torch.isfinite(want).all() and torch.equal(got_own, want) and torch.equal(got_base, want), (touch, s, len(before))
+        assert len(caches[id(total)].vec) == 35                      # every model scored once per set
         job.close()
 
 

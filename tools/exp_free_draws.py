@@ -14,10 +14,10 @@ real = rng.draws_batch_async
 cache = {}
 
 
-def memo(specs, n_workers=0, gate=None):
+def memo(specs, n_workers=0, tasks=None):
     key = json.dumps([(sp.get('n_rows', 0), sp['k'], sp['epochs'], sp['n_user'], sp['n_item']) for sp in specs])
     if key not in cache:
-        cache[key] = real(specs, n_workers, gate)
+        cache[key] = real(specs, n_workers, tasks=tasks)
         for f in cache[key]:
             f.result()
     return cache[key]

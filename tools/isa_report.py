@@ -105,6 +105,27 @@ def metadata(elf):
     return None
 
 
+def kernel_descriptors(elf):
+    """{kernel symbol: its 64-byte kernel descriptor} of one ELF64 code object (the `<kernel>.kd` objects of .rodata)."""
+    shoff, = struct.unpack_from('<Q', elf, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from('<HHH', elf, 0x3A)
+    secs = [struct.unpack_from('<IIQQQQIIQQ', elf, shoff + k * shentsize) for k in range(shnum)]
+    out = {}
+    for (_, typ, _, _, off, size, link, _, _, entsize) in secs:
+        if typ not in (2, 11) or not entsize:          # SHT_SYMTAB / SHT_DYNSYM
+            continue
+        str_off = secs[link][4]
+        for i in range(size // entsize):
+            name_i, info, other, shndx, value, sym_size = struct.unpack_from('<IBBHQQ', elf, off + i * entsize)
+            end = elf.index(b'\0', str_off + name_i)
+            name = elf[str_off + name_i:end].decode()
+            if name.endswith('.kd') and sym_size == 64 and 0 < shndx < shnum:
+                sec = secs[shndx]
+                at = sec[4] + (value - sec[3])
+                out[name[:-3]] = elf[at:at + 64]
+    return out
+
+
 def demangle(names):
     if not os.path.exists(DEMANGLE):
         return names
@@ -118,13 +139,17 @@ def kernels(lib=None):
     rows = []
     for elf in code_objects(lib):
         md = metadata(elf)
+        kds = kernel_descriptors(elf)
         for k in (md or {}).get('amdhsa.kernels', []):
-            rows.append(dict(symbol=k['.name'], vgpr=k.get('.vgpr_count', 0), agpr=k.get('.agpr_count', 0), sgpr=k.get('.sgpr_count', 0),
+            kd = kds.get(k['.name'])
+            # COMPUTE_PGM_RSRC3 (descriptor bytes 44-47), gfx90a and later: bit 16 = TG_SPLIT (the waves of a workgroup may be placed on
+            # different compute units: workgroup-scope acquire / release then need cache maintenance -- csrc/perm_tags.hip must not be built so)
+            rows.append(dict(symbol=k['.name'], tg_split=(struct.unpack_from('<I', kd, 44)[0] >> 16) & 1 if kd else None, vgpr=k.get('.vgpr_count', 0), agpr=k.get('.agpr_count', 0), sgpr=k.get('.sgpr_count', 0),
                              vgpr_spill=k.get('.vgpr_spill_count', 0), sgpr_spill=k.get('.sgpr_spill_count', 0),
                              scratch=k.get('.private_segment_fixed_size', 0), lds=k.get('.group_segment_fixed_size', 0),
                              wg_max=k.get('.max_flat_workgroup_size', 0)))
     for r, n in zip(rows, demangle([r['symbol'] for r in rows])):
-        r['name'] = n.split('(')[0].replace('void ', '').replace('ure::', '')
+        r['name'] = n.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').replace('ure::', '')
     return rows
 
 

@@ -2,10 +2,8 @@
 """Per-rank host timeline of ONE Sisa(parallel).learn at BASELINE.json configs[3]'s shape on R ranks that share the visible GPU
 (gloo; the production transport is RCCL): where a rank's wall time goes between the start of the call and the logs.
 
-    python tools/multirank_timeline.py [--ranks 2] [--k 128] [--epochs 2] [--shards 32] [--redraw 0|1] > timeline.json
+    python tools/multirank_timeline.py [--ranks 2] [--k 128] [--epochs 2] [--shards 32] > timeline.json
 
---redraw 1 makes every rank draw the full U0 of the shards it does not own, as round 3 did (URE_REDRAW_FOREIGN_U0=1; the values
-are discarded), so that the cost the exchange of full user tables replaced can be read off beside the present path.
 Prints one JSON object: {rank: {'learn_s', 'marks': [[label, ms since the call], ...], 'host_cpus', 'owned'}}."""
 import argparse
 import json
@@ -67,7 +65,6 @@ def main():
     ap.add_argument('--k', type=int, default=128)
     ap.add_argument('--epochs', type=int, default=2)
     ap.add_argument('--shards', type=int, default=32)
-    ap.add_argument('--redraw', type=int, default=0)
     ap.add_argument('--port', type=int, default=29671)
     a = ap.parse_args()
     import tempfile
@@ -77,13 +74,13 @@ def main():
         f.write(WORKER)
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK')}
     env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(a.port), WORLD_SIZE=str(a.ranks), LOCAL_WORLD_SIZE=str(a.ranks), URE_HOST_TRACE='1',
-               URE_REDRAW_FOREIGN_U0=str(a.redraw), HSA_ENABLE_IPC_MODE_LEGACY='0')
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
     procs = [subprocess.Popen([sys.executable, script, ROOT, str(a.k), str(a.epochs), str(a.shards), out], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.DEVNULL) for r in range(a.ranks)]
     rc = [p.wait(timeout=1000) for p in procs]
     if any(rc):
         raise SystemExit(f'ranks ended with {rc}')
-    res = {'command': ' '.join(sys.argv), 'redraw_foreign_u0': a.redraw, 'ranks': {}}
+    res = {'command': ' '.join(sys.argv), 'ranks': {}}
     for r in range(a.ranks):
         with open(os.path.join(out, f'rank{r}.json')) as f:
             res['ranks'][str(r)] = json.load(f)

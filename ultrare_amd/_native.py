@@ -69,7 +69,10 @@ _PROTOTYPES = {
     'ure_host_draw_int64': (ctypes.c_int, [_vp, _i64, _i64, _i64, _vp]),
     'ure_host_mf_init': (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, ctypes.c_int]),
     'ure_host_mf_init_batch': (ctypes.c_int, [_i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, ctypes.c_int]),
+    'ure_device_mf_init_scratch': (_i64, [_i32, _i64, _i64]),
+    'ure_device_mf_init': (ctypes.c_int, [_i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, ctypes.c_int, _vp]),
     'ure_host_normal_blocks': (ctypes.c_int, [_vp, _i64, ctypes.c_float, ctypes.c_float]),
+    'ure_host_normal_blocks_scalar': (ctypes.c_int, [_vp, _i64, _i32]),
     'ure_host_read_csv': (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                          ctypes.POINTER(_i64), ctypes.c_int]),
     'ure_host_free': (None, [_vp]),
@@ -95,6 +98,7 @@ _PROTOTYPES = {
     'ure_score_own_compact': (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, ctypes.c_int, _vp, _vp, _i64, ctypes.c_int, _vp, _vp]),
     'ure_eval_series_own': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _i64, ctypes.c_int,
                                            _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    'ure_sum_vectors': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, _i64, _vp, _vp]),
     'ure_eval_subset': (ctypes.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_int, _vp, _vp]),
     'ure_merge_rows': (ctypes.c_int, [_vp, _vp, _vp, _i64, ctypes.c_int, _vp]),
     'ure_ot_cost': (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, ctypes.c_int, _vp, _vp]),

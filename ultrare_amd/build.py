@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libultrare_hip.so')
-SOURCES = ['ure_common.hip', 'mf_train.hip', 'tag_prep.hip', 'mf_eval.hip', 'job_io.hip', 'perm_tags.hip', 'ot.hip', 'ot_solver.cpp', 'host_rng.cpp', 'mt_jump.cpp', 'host_layout.cpp']
+SOURCES = ['ure_common.hip', 'mf_train.hip', 'tag_prep.hip', 'mf_eval.hip', 'job_io.hip', 'perm_tags.hip', 'mf_init.hip', 'ot.hip', 'ot_solver.cpp', 'host_rng.cpp', 'mt_jump.cpp', 'host_layout.cpp']
 # -amdgpu-kernarg-preload-count: gfx950 delivers the first kernel arguments in SGPRs at wave launch, which
 # removes the first of the step kernel's dependent scalar-load rounds (bench: 13.1 -> 12.6 us per launch)
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-munsafe-fp-atomics',
@@ -100,6 +100,10 @@ def build(force=False, verbose=False, timeline=None, defines=(), out=None):
         raise RuntimeError('hipcc not found: libultrare_hip.so cannot be built')
     out = timeline or out or LIB
     extra = (['-DURE_TIMELINE'] if timeline else []) + ['-D' + d for d in defines]
+    # csrc/perm_tags.hip exchanges data between the waves of a workgroup with the workgroup-scope release / acquire of NON-tgsplit mode
+    # (LLVM AMDGPU memory model); in threadgroup-split mode it would read stale lines silently
+    if any('tgsplit' in f and not f.startswith('-mno') for f in FLAGS + extra + os.environ.get('HIPCC_COMPILE_FLAGS_APPEND', '').split()):
+        raise RuntimeError('libultrare_hip.so must not be built with -mtgsplit (csrc/perm_tags.hip: MEMORY MODEL)')
     inc = torch_include()
     obj = out + '.avx2.o'
     cmd0 = [hipcc, '-x', 'c++'] + AVX2_FLAGS + (['-DURE_HAVE_AVX_MATHFUN', '-I', inc] if inc else []) + ['-o', obj, os.path.join(CSRC, AVX2_SOURCE)]

@@ -17,6 +17,7 @@
 #include <thread>
 #include <vector>
 
+#include "normal_math.h"
 #include "ultrare_hip.h"
 
 namespace ure {
@@ -362,6 +363,31 @@ int normal_fill(uint32_t *st, int32_t &left, uint64_t &next, float *out, int64_t
 }
 
 }  // namespace
+
+// The Box-Muller half through the SCALAR restatement the device kernels use (normal_math.h), so that a host without a GPU can hold
+// it against `tensor.normal_()`: data [16 n_blocks] uniforms -> normals in place.  variant 0 is the arithmetic of record; 1-3 are the
+// other readings of the two ambiguous mul + add pairs (tests show that they are NOT torch's).
+template <int kVariant>
+static void scalar_blocks(float *data, int64_t n_blocks)
+{
+    for (int64_t b = 0; b < n_blocks; ++b)
+        for (int j = 0; j < 8; ++j) {
+            float *d = data + 16 * b + j;
+            ure::nm_box_muller<kVariant>(d[0], d[8], d, d + 8);
+        }
+}
+
+extern "C" int ure_host_normal_blocks_scalar(float *data, int64_t n_blocks, int32_t variant)
+{
+    if ((!data && n_blocks) || n_blocks < 0 || variant < 0 || variant > 3) return ure::fail(-1, "ure_host_normal_blocks_scalar: bad arguments");
+    switch (variant) {
+    case 0: scalar_blocks<0>(data, n_blocks); break;
+    case 1: scalar_blocks<1>(data, n_blocks); break;
+    case 2: scalar_blocks<2>(data, n_blocks); break;
+    default: scalar_blocks<3>(data, n_blocks); break;
+    }
+    return 0;
+}
 
 // The per-epoch seeds of scratch.py:78-97 without a generator object: `n` int64 values as `tensor.random_()` draws them (two 32-bit
 // outputs each, the first the high word, bit 63 cleared) from a COPY of the state moved past `skip_draws` outputs.

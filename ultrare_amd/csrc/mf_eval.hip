@@ -956,6 +956,45 @@ static void launch_score_series(const float *U, const float *V, int64_t su, int6
 
 using namespace ure;
 
+namespace ure {
+
+// out[j] = the vectors' sum in list order, as score_kernel adds the models of a list (acc = 0; acc += p_0; acc += p_1; ...): the running
+// sum over an ensemble's FIXED models from score vectors made once per model (ure_score with one model, first = 1, last = 0).
+struct VectorList {
+    const float *v[URE_MAX_MODELS_PER_CALL];
+};
+
+__global__ __launch_bounds__(kBlock) void sum_vectors_kernel(VectorList L, int n_vec, int first, int64_t n, float *__restrict__ out)
+{
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock) {
+        float acc = first ? 0.f : out[j];
+        for (int k = 0; k < n_vec; ++k) acc += L.v[k][j];
+        out[j] = acc;
+    }
+}
+
+}  // namespace ure
+
+extern "C" int ure_sum_vectors(const float *const *vectors, int n_vectors, int64_t n, float *out, void *stream)
+{
+    using namespace ure;
+    URE_ARG(vectors && n_vectors > 0 && n >= 0 && out);
+    if (n == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + kBlock - 1) / kBlock, 8192);
+    for (int c0 = 0; c0 < n_vectors; c0 += URE_MAX_MODELS_PER_CALL) {
+        VectorList L;
+        const int c = std::min(n_vectors - c0, URE_MAX_MODELS_PER_CALL);
+        for (int k = 0; k < c; ++k) {
+            URE_ARG(vectors[c0 + k]);
+            L.v[k] = vectors[c0 + k];
+        }
+        hipLaunchKernelGGL(sum_vectors_kernel, dim3(blocks), dim3(kBlock), 0, st, L, c, c0 == 0, n, out);
+    }
+    URE_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" {
 
 int ure_score(const float *const *U_tables, const float *const *V_tables, int n_models, int n_models_total, int first,
@@ -1047,12 +1086,12 @@ int ure_eval_series(const float *const *U_fixed, const float *const *V_fixed, in
                     void *stream)
 {
     URE_ARG(n_wide >= 0 && n_half >= 0 && n_wide + n_half <= n_users);
-    URE_ARG(n_fixed >= 0 && (n_fixed == 0 || (U_fixed && V_fixed && base)) && U_series && V_series && n_series > 0 && n_series <= 65535);
+    URE_ARG(n_fixed >= 0 && (n_fixed == 0 || (base && !U_fixed == !V_fixed)) && U_series && V_series && n_series > 0 && n_series <= 65535);
     URE_ARG(uid && iid && rating && n > 0 && pow2(d) && d >= 4 && d <= 256 && off && n_users >= 0 && log2_tab && pred && sse && hits &&
             ndcg && out);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // the fixed models' running sum, in list order, once for the whole series
-    for (int c0 = 0; c0 < n_fixed; c0 += URE_MAX_MODELS_PER_CALL) {
+    // the fixed models' running sum, in list order, once for the whole series (U_fixed == NULL: `base` holds it already)
+    for (int c0 = 0; U_fixed && c0 < n_fixed; c0 += URE_MAX_MODELS_PER_CALL) {
         const int c = std::min(n_fixed - c0, URE_MAX_MODELS_PER_CALL);
         if (int rc = ure_score(U_fixed + c0, V_fixed + c0, c, n_fixed + 1, c0 == 0, 0, uid, iid, rating, n, d, base, nullptr, stream)) return rc;
     }
@@ -1125,11 +1164,11 @@ int ure_eval_series_own(const float *const *U_fixed, const float *const *V_fixed
                         int32_t n_half, void *stream)
 {
     URE_ARG(n_wide >= 0 && n_half >= 0 && n_wide + n_half <= n_users);
-    URE_ARG(n_fixed >= 0 && (n_fixed == 0 || (U_fixed && V_fixed && base)) && own && n_series > 0 && n_series <= 65535);
+    URE_ARG(n_fixed >= 0 && (n_fixed == 0 || (base && !U_fixed == !V_fixed)) && own && n_series > 0 && n_series <= 65535);
     URE_ARG(uid && iid && rating && n > 0 && pow2(d) && d >= 4 && d <= 256 && off && n_users >= 0 && log2_tab && pred && sse && hits &&
             ndcg && out);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    for (int c0 = 0; c0 < n_fixed; c0 += URE_MAX_MODELS_PER_CALL) {
+    for (int c0 = 0; U_fixed && c0 < n_fixed; c0 += URE_MAX_MODELS_PER_CALL) {
         const int c = std::min(n_fixed - c0, URE_MAX_MODELS_PER_CALL);
         if (int rc = ure_score(U_fixed + c0, V_fixed + c0, c, n_fixed + 1, c0 == 0, 0, uid, iid, rating, n, d, base, nullptr, stream)) return rc;
     }

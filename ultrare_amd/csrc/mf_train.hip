@@ -647,8 +647,8 @@ static void launch_index_epoch_start(const ure_job *job, int64_t tick, hipStream
     hipLaunchKernelGGL(idx_scan1_kernel, dim3(step_blocks, kIdxSeg, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
     hipLaunchKernelGGL(idx_scan2_kernel, dim3(n_sh), dim3(1024), 0, st, job->dev, job->dev_aux, tick);
     hipLaunchKernelGGL(idx_scan3_kernel, dim3(step_blocks, kIdxSeg, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
-    // (epochs of at most 63 steps: a step's share of 1,024 slots is a run worth sorting in LDS first; URE_INDEX_STAGED=0 keeps the direct scatter)
-    static const bool staged_ok = [] { const char *e = getenv("URE_INDEX_STAGED"); return !e || atoi(e) != 0; }();
+    // (epochs of at most 63 steps: a step's share of 1,024 slots is a run worth sorting in LDS first)
+    constexpr bool staged_ok = true;
     if (steps <= kIdxWin && staged_ok)
         hipLaunchKernelGGL(idx_scatter_short_kernel, dim3(wave_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
     else

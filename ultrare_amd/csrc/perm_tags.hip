@@ -17,7 +17,21 @@
 //
 // One workgroup of 1,024 lanes makes one permutation at a time (its state -- partners and inverse: 8 bytes per row -- stays in its
 // XCD's L2; the reservation words are in LDS) and takes the next of the launch when it is done; `groups` workgroups work side by side.
+//
+// MEMORY MODEL.  inv[] and z[] are exchanged between the WAVES OF ONE WORKGROUP through global memory with plain loads and stores.  The
+// rule this rests on is LLVM's AMDGPU memory model for gfx90a / gfx942 / gfx950 (AMDGPUUsage, "Memory Model", code sequences for
+// workgroup scope in NON-tgsplit mode): all waves of a workgroup run on one compute unit and share its vector L1, so
+//     release at workgroup scope  =  s_waitcnt vmcnt(0) (the wave's stores have reached the L1 / L2) before the s_barrier,
+//     acquire at workgroup scope  =  nothing (no buffer_inv: a load cannot hit a line staler than a store of the same CU),
+// which is exactly what stands below: `s_waitcnt vmcnt(0)` in front of every barrier that ends a round, no cache invalidate behind
+// it.  (A __threadfence_block() would emit the same release but the compiler may keep it weaker than vmcnt(0) for LDS-only
+// traffic; an agent-scope fence writes the L2 back: 27 -> 7.5 us per round, measured.)  In THREADGROUP-SPLIT mode (-mtgsplit) the
+// waves of a workgroup may sit on different CUs, workgroup-scope acquire becomes a buffer_inv sc0 and this code would read stale
+// lines SILENTLY -- a wrong permutation, which the give-up flag cannot see.  Such a build is refused (below).
 #include "ure_internal.h"
+
+// (hipcc 7.2 defines no macro for the tgsplit target feature, so the refusal is made where the build is: ultrare_amd/build.py rejects
+// -mtgsplit, and tests/test_cpu_host.py reads the TG_SPLIT bit of every kernel descriptor of the built library.)
 
 namespace ure {
 namespace {
@@ -143,7 +157,7 @@ __global__ __launch_bounds__(kPermBlock) void perm_tags_kernel(const ure_perm_t 
                     if (got_i == v && got_j == v) {
                         // Position i is touched for the first time by swap i itself (every older swap lies to the right of it): it still holds i, and
                         // nobody has to have written that.  So: one load, two stores, and no pass that writes the identity first.
-                        // (plain accesses: the lanes of a workgroup share their compute unit's L1, which its own stores keep current)
+                        // (plain accesses: workgroup-scope acquire is a no-op in non-tgsplit mode -- see MEMORY MODEL above)
                         if (pj[k] != pi[k]) {
                             const unsigned b = inv[pj[k]];
                             inv[pi[k]] = b;
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(kPermBlock) void perm_tags_kernel(const ure_perm_t 
                         admit(k);                                // the slot's next swap: its partner is loaded beside this round's memory traffic
                     }
                 }
-            __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this round's stores are done (a workgroup fence would not wait for them)
+            __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0) = the workgroup-scope RELEASE of this round's stores (the next barrier publishes them)
         }
         // ---- the tags: file row f trains at position inv[f] of the epoch
         uint16_t *out = perms[perm].tags;

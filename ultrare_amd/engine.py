@@ -27,15 +27,14 @@ SCORE_PARTIALS = 2048     # URE_SCORE_PARTIALS of the C ABI
 SERIES_SCRATCH_BYTES = 256 << 20     # prediction scratch of one ure_eval_series call
 LAZY_ROWS = os.environ.get('URE_LAZY_ROWS', '1') != '0'
 TOUCH_MAX_STEPS = 32000              # kTouchMaxSteps of csrc/mf_touch.h (epochs longer than 64 steps run in windows of 64)
-EARLY_SCORE_EPOCHS = 8               # TrainJob.early_scores: epochs per batch handed to the second stream
 # touch mode, epochs of several windows: rows of up to this many scan passes are one work item.  Full MF at the 25 M shape, us per
 # launch: 106.7 at 1 (a unit per pass), 95.5 at 2, 97.0 at 4, 118.8 at 8, 157.3 at 16, 386.7 at 64 -- a lane group walks its row's
 # passes one after the other (a scan, a compaction and a gather each), units work theirs side by side
-TOUCH_ROW_PASSES = int(os.environ.get('URE_TOUCH_ROW_PASSES', '2'))
+TOUCH_ROW_PASSES = 2
 # ... and the work units of the longer rows take this many passes each (a unit skips the passes without a slot of the step by their masks;
 # fewer, larger units: the step visits 1,700 workgroups of them instead of 13,600).  The same leg: 105.8 us at 1, 81.7 at 2, 68.0 at 4,
 # 62.9 at 8, 61.6 at 16
-TOUCH_UNIT_PASSES = int(os.environ.get('URE_TOUCH_UNIT_PASSES', '8'))
+TOUCH_UNIT_PASSES = 8
 TOUCH_AHEAD_MAX_STEPS = 63           # kAheadMaxSteps of csrc/mf_touch.h
 INDEX_MAX_STEPS = 1008               # kIdxMaxSteps of csrc/mf_index.h (touch_mode 3: the epoch's slots sorted by step)
 INDEX_HEAVY_SLOTS = 16               # touch_mode 3: rows with at least this many slots per step on average get a workgroup per step ...
@@ -590,9 +589,6 @@ class TrainJob:
         t1 = self.ticks if n_ticks is None else min(self.ticks, self.done + int(n_ticks))
         while t1 > self.done:
             t_next = t1
-            if getattr(self, '_early', None):
-                # early own scores (early_scores): hand the second stream a batch of finished epochs every few epochs
-                t_next = min(t1, self.done + EARLY_SCORE_EPOCHS * max(self.steps_per_epoch(s) for s in range(len(self.shards))))
             if self._chunks:
                 # the launches of tick t read the permutation of the epoch AFTER the one a shard is in (the batch tags are
                 # prepared one epoch ahead): wait for the chunk that holds it, and launch only up to where the next one is needed
@@ -623,8 +619,6 @@ class TrainJob:
                     t_next = min(t_next, max(self.done + 1, (horizon - (2 if self.ahead else 1)) * min_steps))
             nv.check(nv.lib().ure_job_train(self._job, self.done, t_next, nv.stream_handle(stream)), 'ure_job_train')
             self.done = t_next
-            if getattr(self, '_early', None):
-                self._score_finished_epochs(stream)
         return self.done
 
     def run_profiled(self, n_ticks, stream=None):
@@ -660,51 +654,19 @@ class TrainJob:
         st = self.state[s]
         return st['snapU'], st['snapV']
 
-    # ---- the own half of a series beside training (ure_score_own_compact / ure_eval_series_own)
-    def early_scores(self, s, eval_set):
-        """Register shard s's per-epoch series on `eval_set` for early scoring: as run() proceeds, the scores of the shard's own
-        model after every finished epoch are computed on a second stream from the compact snapshots (the half of a series that
-        does not depend on other shards); finish_series() adds the fixed models and ranks.  Call before run().  -> handle, or
-        None when the job keeps no compact snapshots (evaluate_series then does everything afterwards)."""
-        if self.snapshots != 'compact' or eval_set.n == 0 or self.done != 0:
-            return None
-        if not hasattr(self, '_early'):
-            self._early = []
-            self._side = torch.cuda.Stream(self.device)
-        own = torch.empty(self.epochs, eval_set.n, dtype=torch.float32, device=self.device)
-        own.record_stream(self._side)
-        h = {'s': s, 'ev': eval_set, 'own': own, 'scored': 0, 'event': None}
-        self._early.append(h)
-        return h
-
-    def _score_finished_epochs(self, stream=None):
-        main = stream if stream is not None else torch.cuda.current_stream(self.device)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        self._side.wait_event(ready)
-        L, st = nv.lib(), nv.stream_handle(self._side)
-        for h in self._early:
-            s, ev = h['s'], h['ev']
-            e_done = min(self.epochs, self.done // self.steps_per_epoch(s))
-            e0 = h['scored']
-            if e_done <= e0:
-                continue
-            state, sh = self.state[s], self.shards[s]
-            snap = state['snap']
-            nv.check(L.ure_score_own_compact(nv.ptr(snap[e0]), snap.stride(0), nv.ptr(sh.row_slot()), nv.ptr(state['U0']), nv.ptr(state['V0']),
-                                             nv.ptr(state['snap_a'][e0:]), sh.n_user, e_done - e0, nv.ptr(ev.uid), nv.ptr(ev.iid), ev.n, self.d,
-                                             nv.ptr(h['own'][e0]), st), 'ure_score_own_compact')
-            h['scored'] = e_done
-            h['event'] = torch.cuda.Event()
-            h['event'].record(self._side)
-
-    def finish_series(self, h, fixed, out, stream=None):
-        """The rest of a series registered with early_scores(): out [epochs, 3] (device float64) = (rmse, ndcg, hr) of every epoch's
-        ensemble `fixed` + the shard's model of that epoch.  Identical to evaluate_series()."""
-        assert h['scored'] == self.epochs, 'finish_series: the job has not run to its end'
-        main = stream if stream is not None else torch.cuda.current_stream(self.device)
-        main.wait_event(h['event'])
-        return h['ev'].evaluate_series_own(fixed, h['own'], self.d, out, stream)
+    def own_scores(self, s, eval_set, stream=None):
+        """own [epochs, n] float32: the score of every pair of `eval_set` under shard s's own model after every epoch, from the compact
+        snapshots (ure_score_own_compact) -- the half of a series that does not depend on other shards; EvalSet.evaluate_series_own adds
+        the fixed models and ranks.  After run()."""
+        assert self.snapshots == 'compact' and self.done == self.ticks
+        own = torch.empty(self.epochs, max(eval_set.n, 1), dtype=torch.float32, device=self.device)
+        state, sh = self.state[s], self.shards[s]
+        snap = state['snap']
+        if eval_set.n:
+            nv.check(nv.lib().ure_score_own_compact(nv.ptr(snap), snap.stride(0), nv.ptr(sh.row_slot()), nv.ptr(state['U0']), nv.ptr(state['V0']),
+                                                    nv.ptr(state['snap_a']), sh.n_user, self.epochs, nv.ptr(eval_set.uid), nv.ptr(eval_set.iid), eval_set.n,
+                                                    self.d, nv.ptr(own), nv.stream_handle(stream)), 'ure_score_own_compact')
+        return own
 
     def evaluate_series(self, s, eval_set, fixed, out, stream=None, subset=None, lane=0):
         """scratch.py:83-97 for every epoch of shard s on `eval_set`: member e = the ensemble `fixed` + the shard's model
@@ -809,6 +771,54 @@ _IDCG = 1.0 + np.sum(np.ones(9) / _LOG2_TAB)                   # computeDCG(np.o
 _LOG2_TAB = np.concatenate([_LOG2_TAB, [_IDCG]])
 
 
+class FixedBase:
+    """The fixed models of a series given as their running sum on the set's pairs (ScoreCache.base): n models, base [n_pairs] float32."""
+
+    def __init__(self, n, base):
+        self.n, self.base = int(n), base
+
+    def __len__(self):
+        return self.n
+
+
+class ScoreCache:
+    """Score vectors of a request's models on ONE test set, each model scored once (ure_score with one model: what it adds to an ensemble's
+    running sum), and an ensemble's base as their sum in list order (ure_sum_vectors) -- the additions ure_score makes over a list of
+    tables, so a series evaluated from such a base has the same bits.  Everything is queued on the current stream."""
+    LIMIT_BYTES = 4 << 30
+
+    def __init__(self, eval_set, d):
+        self.ev, self.d, self.vec = eval_set, int(d), {}
+
+    def fits(self, n_vectors):
+        return int(n_vectors) * 4 * self.ev.n <= self.LIMIT_BYTES
+
+    def base(self, before):
+        """before: [(key, get_tables, arg)] in the ensemble's order; get_tables(arg) -> padded (U, V) of the model `key` names.  -> FixedBase"""
+        if not before:
+            return FixedBase(0, None)
+        for key, get, arg in before:
+            if key not in self.vec:
+                U, V = get(arg)
+                self.vec[key] = self.ev.score_vector(U, V, self.d)
+        out = torch.empty(max(self.ev.n, 1), dtype=torch.float32, device=self.ev.device)
+        n = len(before)
+        ptrs = (ctypes.c_void_p * n)(*[self.vec[key].data_ptr() for key, _, _ in before])
+        nv.check(nv.lib().ure_sum_vectors(ptrs, n, self.ev.n, nv.ptr(out), nv.stream_handle()), 'ure_sum_vectors')
+        return FixedBase(n, out)
+
+
+def _fixed_args(fixed, d, own_base):
+    """-> (U pointers, V pointers, n_fixed, base pointer) of a series call for `fixed` = a list of padded (U, V) or a FixedBase."""
+    if isinstance(fixed, FixedBase):
+        return None, None, fixed.n, (nv.ptr(fixed.base) if fixed.n else nv.ptr(own_base))
+    for U, V in fixed:
+        assert U.is_contiguous() and V.is_contiguous() and U.shape[1] == d and V.shape[1] == d
+    Up = (ctypes.c_void_p * max(len(fixed), 1))(*[U.data_ptr() for U, _ in fixed])
+    Vp = (ctypes.c_void_p * max(len(fixed), 1))(*[V.data_ptr() for _, V in fixed])
+    return Up, Vp, len(fixed), nv.ptr(own_base)
+
+
 class EvalSet:
     """Test interactions grouped by user (first-appearance order, utils.py:156-163)
     and resident on the device, plus the output buffers of the two eval kernels."""
@@ -864,8 +874,8 @@ class EvalSet:
         when every user of this set is in `total` with exactly the same (item, rating) rows in the same order -- the reference's total test
         set is the shards' test sets side by side (config.py:144-148) --, else None.  Checked on the host once per pair of sets and kept
         (the sets live with their loaders).  With a plan, a series on `total` also yields this set's three numbers (ure_eval_subset)
-        instead of a second series on the same models and pairs.  URE_EVAL_SUBSET=0: never."""
-        if os.environ.get('URE_EVAL_SUBSET', '1') == '0' or total is self or self.n == 0 or total.n == 0:
+        instead of a second series on the same models and pairs."""
+        if total is self or self.n == 0 or total.n == 0:
             return None
         key = id(total)
         hit = self._subsets.get(key)
@@ -944,6 +954,17 @@ class EvalSet:
                                       'ndcg': torch.empty(per_call, max(self.n_users, 1), dtype=torch.float64, device=dev)})
         return lanes[lane][1], per_call
 
+    def score_vector(self, U, V, d, stream=None):
+        """What the model (U, V) (padded, device) adds to an ensemble's running sum on this set's pairs: 0 + <u, v> per pair, float32
+        [n] in the set's own order (ure_score with one model, first = 1, last = 0)."""
+        assert U.is_contiguous() and V.is_contiguous() and U.shape[1] == d and V.shape[1] == d
+        out = torch.empty(max(self.n, 1), dtype=torch.float32, device=self.device)
+        if self.n:
+            Up, Vp = (ctypes.c_void_p * 1)(U.data_ptr()), (ctypes.c_void_p * 1)(V.data_ptr())
+            nv.check(nv.lib().ure_score(Up, Vp, 1, 1, 1, 0, nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating), self.n, d, nv.ptr(out), None,
+                                        nv.stream_handle(stream)), 'ure_score')
+        return out
+
     def evaluate_series(self, fixed, U_series, V_series, d, out, stream=None, subset=None, lane=0):
         """scratch.py:83-97 for every epoch of a shard in four launches (ure_eval_series): member e of
         the series is the ensemble `fixed` + [(U_series[e], V_series[e])]; out[e] (device float64
@@ -955,15 +976,12 @@ class EvalSet:
             return out.fill_(float('nan'))
         L, st = nv.lib(), nv.stream_handle(stream)
         b, per_call = self._series_buffers(E, lane)
-        for U, V in fixed:
-            assert U.is_contiguous() and V.is_contiguous() and U.shape[1] == d and V.shape[1] == d
-        Up = (ctypes.c_void_p * max(len(fixed), 1))(*[U.data_ptr() for U, _ in fixed])
-        Vp = (ctypes.c_void_p * max(len(fixed), 1))(*[V.data_ptr() for _, V in fixed])
+        Up, Vp, n_fixed, base_ptr = _fixed_args(fixed, d, b['base'])
         for e0 in range(0, E, per_call):
             m = min(per_call, E - e0)
-            nv.check(L.ure_eval_series(Up, Vp, len(fixed), nv.ptr(U_series[e0]), nv.ptr(V_series[e0]), U_series.stride(0),
+            nv.check(L.ure_eval_series(Up, Vp, n_fixed, nv.ptr(U_series[e0]), nv.ptr(V_series[e0]), U_series.stride(0),
                                        V_series.stride(0), m, nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating), self.n, d,
-                                       nv.ptr(self.off), self.n_users, nv.ptr(self.log2), nv.ptr(b['base']), nv.ptr(b['pred']),
+                                       nv.ptr(self.off), self.n_users, nv.ptr(self.log2), base_ptr, nv.ptr(b['pred']),
                                        nv.ptr(b['sse']), nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating),
                                        self.n_wide, self.n_half, st),
                      'ure_eval_series')
@@ -982,15 +1000,12 @@ class EvalSet:
             return out.fill_(float('nan'))
         L, st = nv.lib(), nv.stream_handle(stream)
         b, per_call = self._series_buffers(E, lane)
-        for U, V in fixed:
-            assert U.is_contiguous() and V.is_contiguous() and U.shape[1] == d and V.shape[1] == d
-        Up = (ctypes.c_void_p * max(len(fixed), 1))(*[U.data_ptr() for U, _ in fixed])
-        Vp = (ctypes.c_void_p * max(len(fixed), 1))(*[V.data_ptr() for _, V in fixed])
+        Up, Vp, n_fixed, base_ptr = _fixed_args(fixed, d, b['base'])
         for e0 in range(0, E, per_call):
             m = min(per_call, E - e0)
-            nv.check(L.ure_eval_series_compact(Up, Vp, len(fixed), nv.ptr(snap[e0]), snap.stride(0), nv.ptr(row_slot), nv.ptr(U0), nv.ptr(V0),
+            nv.check(L.ure_eval_series_compact(Up, Vp, n_fixed, nv.ptr(snap[e0]), snap.stride(0), nv.ptr(row_slot), nv.ptr(U0), nv.ptr(V0),
                                                nv.ptr(snap_a[e0:]), int(n_user_rows), m, nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating),
-                                               self.n, d, nv.ptr(self.off), self.n_users, nv.ptr(self.log2), nv.ptr(b['base']), nv.ptr(b['pred']),
+                                               self.n, d, nv.ptr(self.off), self.n_users, nv.ptr(self.log2), base_ptr, nv.ptr(b['pred']),
                                                nv.ptr(b['sse']), nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating),
                                                self.n_wide, self.n_half, st), 'ure_eval_series_compact')
             if subset is not None:
@@ -1003,14 +1018,11 @@ class EvalSet:
         assert out.shape == (E, 3) and out.dtype == torch.float64 and out.is_contiguous() and own.is_contiguous() and own.shape[1] == self.n
         L, st = nv.lib(), nv.stream_handle(stream)
         b, per_call = self._series_buffers(E)
-        for U, V in fixed:
-            assert U.is_contiguous() and V.is_contiguous() and U.shape[1] == d and V.shape[1] == d
-        Up = (ctypes.c_void_p * max(len(fixed), 1))(*[U.data_ptr() for U, _ in fixed])
-        Vp = (ctypes.c_void_p * max(len(fixed), 1))(*[V.data_ptr() for _, V in fixed])
+        Up, Vp, n_fixed, base_ptr = _fixed_args(fixed, d, b['base'])
         for e0 in range(0, E, per_call):
             m = min(per_call, E - e0)
-            nv.check(L.ure_eval_series_own(Up, Vp, len(fixed), nv.ptr(own[e0]), m, nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating), self.n, d,
-                                           nv.ptr(self.off), self.n_users, nv.ptr(self.log2), nv.ptr(b['base']), nv.ptr(b['pred']), nv.ptr(b['sse']),
+            nv.check(L.ure_eval_series_own(Up, Vp, n_fixed, nv.ptr(own[e0]), m, nv.ptr(self.uid), nv.ptr(self.iid), nv.ptr(self.rating), self.n, d,
+                                           nv.ptr(self.off), self.n_users, nv.ptr(self.log2), base_ptr, nv.ptr(b['pred']), nv.ptr(b['sse']),
                                            nv.ptr(b['hits']), nv.ptr(b['ndcg']), nv.ptr(out[e0]), nv.ptr(self.top_rating), self.n_wide, self.n_half, st),
                      'ure_eval_series_own')
         return out

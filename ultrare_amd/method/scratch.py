@@ -36,7 +36,8 @@ def prepare_shard(train_loader, n_user, n_item, k, epochs, has_total, given_mode
     caller's next draws."""
     loader = as_loader(train_loader)
     if _is_empty(given_model) or given_model == '':
-        U0, V0 = rng.mf_init(n_user, n_item, k)            # the stream of MF(...): 2 discarded + 2 kept fills (utils.py:31-40)
+        # the stream of MF(...): 2 discarded + 2 kept fills (utils.py:31-40); big tables are made on the device
+        U0, V0 = rng.mf_init(n_user, n_item, k, device=engine._device())
     else:
         U0 = given_model.user_mat.weight.detach().float().cpu()
         V0 = given_model.item_mat.weight.detach().float().cpu()

@@ -78,64 +78,41 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
         # every shard's start state by skip-ahead; then, in the order of what the job waits for longest: the owned shards' model inits
         # (a worker each, started at once: rng.start_inits), the layouts (one native call on a worker, the device allocations beside
         # it), and last the permutations' buffers and chunk workers (rng.draws_batch_async: seeds by skip-ahead, chunks round robin)
-        import threading
         starts, end, seeds = streams
         torch.set_rng_state(end)
-        mine = [pos for pos in range(len(ids)) if owner[pos] == rank]
-        # `gate` can hold the permutation expansion back until the layouts are built (URE_GATE=1).  Measured with the layouts as
-        # ONE native call on a worker (tools/ab_host.py, medians of 5 alternating runs): 5 shards 13.8 / 13.1 ms without the gate,
-        # 15.1 / 14.0 with it; 16 shards 24.6 / 22.5 against 24.1 / 20.9 (noise); with the chunks beside the inits (round 4,
-        # tools/host_timeline.py --ab, 20 interleaved requests each): 9.4 ms without, 9.9 with.  Open by default.
-        gate = threading.Event()
-        if os.environ.get('URE_GATE', '0') != '1':
-            gate.set()
         futures = {}
+        specs, order = [], []
+        # permutation chunks: 8 epochs each for a few shards (a 5-shard call: 8 -> 13.8 / 11.7 ms learn / unlearn, 17 -> 19.7 /
+        # 14.2), larger ones when many shards make many chunk uploads (16 shards: 8 -> 21.6 / 23.2, 13 -> 20.9 / 20.1;
+        # tools/ab_host.py medians): about 64 chunks per call.
+        n_owned = sum(1 for pos in range(len(ids)) if owner[pos] == rank)
+        chunk_epochs = max(8, -(-epochs * n_owned // 64))
+        for pos, i in enumerate(ids):
+            loader = as_loader(train_dlist[i])
+            base = dict(start_state=starts[pos], n_user=n_user, n_item=n_item, k=k, epochs=epochs, with_total_test=True, seeds=seeds[pos])
+            if owner[pos] == rank:
+                specs.append(dict(base, n_rows=len(loader.dataset), shuffle=loader.shuffle, device=engine._device(),
+                                  tags_batch=loader.batch_size if os.environ.get('URE_HOST_TAGS', '1') != '0' else 0,
+                                  chunk_epochs=chunk_epochs))
+                order.append(i)
+        tasks = rng.start_inits(specs)
+        engine.mark('inits started')
+        # the layouts' native builder goes first (a worker); then the epochs' batch tags are put on their way (rng.draws_batch_async: made on
+        # the device from the seeds, or by host workers); the layouts' device allocations -- which the builder's worker needs only when it
+        # is done -- come last
+        layouts, allocate_layouts = start_layouts(allocate=False)
+        # few workers, several shards each (rng.draws_batch_async): the expansion threads of a worker's native calls share
+        # the rank's CPUs
+        W = max(1, min(len(specs), max(2, rng.host_cpus() // 2)))
+        for sp in specs:
+            sp['threads'] = max(2, PERM_THREADS // W)
         try:
-            specs, order = [], []
-            # permutation chunks: 8 epochs each for a few shards (a 5-shard call: 8 -> 13.8 / 11.7 ms learn / unlearn, 17 -> 19.7 /
-            # 14.2), larger ones when many shards make many chunk uploads (16 shards: 8 -> 21.6 / 23.2, 13 -> 20.9 / 20.1;
-            # tools/ab_host.py medians): about 64 chunks per call.  URE_CHUNK_EPOCHS overrides.
-            n_owned = sum(1 for pos in range(len(ids)) if owner[pos] == rank)
-            chunk_epochs = int(os.environ.get('URE_CHUNK_EPOCHS', '0')) or max(8, -(-epochs * n_owned // 64))
-            for pos, i in enumerate(ids):
-                loader = as_loader(train_dlist[i])
-                base = dict(start_state=starts[pos], n_user=n_user, n_item=n_item, k=k, epochs=epochs, with_total_test=True, seeds=seeds[pos])
-                if owner[pos] == rank:
-                    specs.append(dict(base, n_rows=len(loader.dataset), shuffle=loader.shuffle, device=engine._device(),
-                                      tags_batch=loader.batch_size if os.environ.get('URE_HOST_TAGS', '1') != '0' else 0,
-                                      chunk_epochs=chunk_epochs))
-                    order.append(i)
-            early = os.environ.get('URE_INITS_FIRST', '1') != '0'
-            tasks = rng.start_inits(specs) if early else None
-            engine.mark('inits started')
-            # the layouts' native builder goes first (a worker); then the epochs' batch tags are put on their way (rng.draws_batch_async: made on
-            # the device from the seeds, or by host workers); the layouts' device allocations -- which the builder's worker needs only when it
-            # is done -- come last
-            layouts, allocate_layouts = start_layouts(allocate=False)
-            # few workers, several shards each (rng.draws_batch_async): the expansion threads of a worker's native calls share
-            # the rank's CPUs
-            W = max(1, min(len(specs), int(os.environ.get('URE_DRAW_WORKERS', '0')) or max(2, rng.host_cpus() // 2)))
-            for sp in specs:
-                sp['threads'] = max(2, PERM_THREADS // W)
-            try:
-                futures = dict(zip(order, rng.draws_batch_async(specs, W, gate, tasks=tasks)))
-            finally:
-                allocate_layouts()                           # (whatever happened: the builder's worker waits for it)
-            engine.mark('draws submitted')
-            shards = dict(zip(own_ids, layouts.result()))
+            futures = dict(zip(order, rng.draws_batch_async(specs, W, tasks=tasks)))
         finally:
-            gate.set()
+            allocate_layouts()                           # (whatever happened: the builder's worker waits for it)
+        engine.mark('draws submitted')
+        shards = dict(zip(own_ids, layouts.result()))
         engine.mark('layouts')
-        if os.environ.get('URE_REDRAW_FOREIGN_U0', '0') == '1':
-            # measurement aid (tools/multirank_timeline.py, profiles/r04): what round 3 did here -- the full U0 of every shard another
-            # rank owns, drawn on this rank from the shard's start state and then not needed any more -- so that its cost can be
-            # timed beside the exchange that replaced it.  The values are discarded; results do not change.
-            for pos, i in enumerate(ids):
-                if owner[pos] != rank:
-                    g = torch.Generator()
-                    g.set_state(starts[pos])
-                    rng.mf_init(n_user, n_item, k, generator=g)
-            engine.mark('foreign U0 redrawn (round-3 behaviour, URE_REDRAW_FOREIGN_U0=1)')
         for pos, i in enumerate(ids):
             if i not in futures:
                 continue
@@ -294,7 +271,7 @@ class Sisa(Scratch):
         # native call of its own -- 10 ms between two marks of a 16-shard call.  A short interval for the duration of the call.
         import sys
         switch = sys.getswitchinterval()
-        sys.setswitchinterval(float(os.environ.get('URE_SWITCH_INTERVAL', '2e-4')))
+        sys.setswitchinterval(2e-4)
         from .. import rng
         try:
             with rng.torch_threads():
@@ -320,7 +297,7 @@ class Sisa(Scratch):
             import warnings
             warnings.warn(f'per-epoch test logs of this call are NaN: {snap_bytes / 2**30:.1f} GiB of end-of-epoch snapshots '
                           f'exceed URE_SNAPSHOT_LIMIT_GB ({snapshot_limit() / 2**30:.3g}); train_loss and log0 are complete')
-        models, job, early = {}, None, {}
+        models, job = {}, None
         if mine:
             batch = as_loader(train_dlist[mine[0]]).batch_size
             job = engine.TrainJob([prepared[i][0] for i in mine], [prepared[i][1] for i in mine],
@@ -329,15 +306,6 @@ class Sisa(Scratch):
                                   final_only=True)       # (the tables are read once, after the last epoch)
             from .. import rng
             engine.mark('job_created')
-            # the per-epoch test series of every shard (scratch.py:83-97).  URE_EARLY_SCORES=1: the shard's own half is scored on a
-            # second stream from the snapshots of the finished epochs while training continues, the rest follows below once all
-            # models are final.  Built for VERDICT r2 item 7b and measured: the device tail after the last launch shrinks by 1.2 ms,
-            # the launch loop grows by as much (70 more launches, an event pair per batch) -- 15.2-17.4 ms either way at configs[1],
-            # 0.20 vs 0.21 s at configs[3] size.  Off by default (profiles/r03/NOTES.md 6).
-            if keep_logs and os.environ.get('URE_EARLY_SCORES', '0') == '1':
-                total_ev = as_loader(test_data).eval_set()
-                for pos, i in enumerate(mine):
-                    early[i] = (job.early_scores(pos, as_loader(test_dlist[i]).eval_set()), job.early_scores(pos, total_ev))
             job.run()
             self._rows_dev(mine[0])             # (the merge's row lists go up while the device works through the launches)
             engine.mark(f'launched (waited {getattr(job, "chunk_wait_s", 0.0) * 1e3:.2f} ms for permutation chunks)')
@@ -355,49 +323,41 @@ class Sisa(Scratch):
             job.epoch_sse_queue(out=flat[n_res:].view(len(mine), self.epochs))         # (one launch, right behind the last step)
 
         def queue_series(fixed_of):
-            """Every shard's two test series (scratch.py:83-97) go into the queue; fixed_of(j) = the padded (U, V) of shard j's final model.
-            A series is a chain of short launches that cannot fill the device, and the shards' series do not depend on each other:
-            URE_SERIES_STREAMS = n > 1 deals them out to n streams, joined at the end (built and measured: tools/host_timeline.py --ab, 20
-            interleaved requests per setting, twice: the tail of a 5-shard request 2.54 -> 2.75 and 2.41 -> 2.62 ms with 4 streams -- the
-            events cost more than the overlap of such short chains gives --, so the default is 1: all on the current stream)."""
+            """Every shard's two test series (scratch.py:83-97) go into the queue, all on the current stream (the shards' series on four
+            streams were measured: the events cost more than such short chains overlap -- NOTES r4 6); fixed_of(j) = the padded (U, V) of
+            shard j's final model.
+            Member e of shard i's series is the mean over an ensemble of FIXED models -- learn: the shards trained before i
+            (scratch.py:83-86); unlearn: every shard's model, retrained if it came before i in this call, else the old one (sisa.py:89) --
+            and i's own model after epoch e.  The fixed models' share is the same sum for every epoch and nearly the same for every
+            shard: each distinct model is scored ONCE on the total test set (engine.ScoreCache) and a shard's base is the sum of
+            those vectors in the ensemble's order -- the additions ure_score makes, so every number of every series is unchanged --
+            instead of scoring i models again for shard i: S instead of S^2 / 2 table passes (S^2 when unlearning), which at
+            BASELINE.json configs[3] (32 shards, 2.5 M test pairs, d = 128) was 1.3 TB of gathers per learn."""
             if not keep_logs:
                 return
-            dev = engine._device()
-            n_lanes = max(1, min(len(mine), int(os.environ.get('URE_SERIES_STREAMS', '1')))) if not early else 1
-            main = torch.cuda.current_stream(dev)
-            sides = engine.side_streams(dev, n_lanes - 1)
-            work = []
-            for i in mine:                      # first everything that is queued on THIS stream: the rows brought up to date, padded copies
-                total_ev = as_loader(test_data).eval_set()
+            total_ev = as_loader(test_data).eval_set()
+            cache = engine.ScoreCache(total_ev, job.d)
+            old = {}
+
+            def old_tables(j):
+                if j not in old:
+                    old[j] = padded_tables(self.model_list[j])[:2]
+                return old[j]
+            for i in mine:
                 test_ev = as_loader(test_dlist[i]).eval_set()
                 if unlearning:                              # sisa.py:89: the shards before i in the retraining order are already replaced
                     replaced = set(ids[:ids.index(i)])
-                    before = [fixed_of(j) if j in replaced else padded_tables(m)[:2] for j, m in enumerate(self.model_list)]
+                    before = [(('new', j), fixed_of, j) if j in replaced else (('old', j), old_tables, j) for j in range(len(self.model_list))]
                 else:
-                    before = [fixed_of(j) for j in ids[:ids.index(i)]]
-                test_ev.subset_of(total_ev)                 # (its index lists go up on this stream too, the first time)
-                work.append((i, mine.index(i), test_ev, total_ev, before))
-            if sides:
-                fork = torch.cuda.Event()
-                fork.record(main)
-                for st in sides:
-                    st.wait_event(fork)
-            for i, pos, test_ev, total_ev, before in work:
-                # all epochs of the shard at once: the ensembles differ in their last model only
+                    before = [(('new', j), fixed_of, j) for j in ids[:ids.index(i)]]
+                pos = mine.index(i)
                 res = res_all[pos]
-                if early.get(i, (None, None))[0] is None:
-                    lane = pos % n_lanes
-                    with torch.cuda.stream(sides[lane - 1] if lane else main):
-                        job.evaluate_series_pair(pos, test_ev, total_ev, before, res[0], res[1], lane=lane)      # (one series where the shard's set is a subset of the total set)
-                else:
-                    for which, ev in enumerate((test_ev, total_ev)):
-                        job.finish_series(early[i][which], before, res[which])
+                if test_ev.subset_of(total_ev) is not None and cache.fits(len({key for key, _, _ in before}) + len(cache.vec)):
+                    fixed = cache.base(before)
+                else:                                       # (the shard's own set is not the total set's rows of its users: two series, models scored per series)
+                    fixed = [get(j) for _, get, j in before]
+                job.evaluate_series_pair(pos, test_ev, total_ev, fixed, res[0], res[1])
                 queued[i] = pos
-            for st in sides:
-                done = torch.cuda.Event()
-                done.record(st)
-                main.wait_event(done)
-            # (`work` -- the padded copies of earlier models among it -- lives until here: the side streams are joined)
 
         if mine and not dist:
             # one process: every final model is in the job's own tables -- the series are queued from THOSE, right behind the last

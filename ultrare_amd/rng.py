@@ -165,19 +165,86 @@ def native_fill_ok():
     return _NATIVE_FILL[0]
 
 
+_DEVICE_FILL = {}
+DEVICE_INIT_MIN_NORMALS = 1 << 20      # requests with fewer N(0, 1) values keep the host's batch fill (an ml-1m shard: 0.3 M)
+
+
+def device_fill_ok(device):
+    """Whether ure_device_mf_init (csrc/mf_init.hip: MT19937 and the Box-Muller arithmetic of csrc/normal_math.h on the device)
+    reproduces THIS torch build's CPU `tensor.normal_()` bit for bit on `device`, established once per process: two shards from states in
+    the middle of a generator block, a table with the re-drawn tail and one of several segments (a jump tree of two levels) -- tables
+    and end states compared.  URE_DEVICE_INIT=0 keeps the host fill."""
+    import os
+    key = str(device)
+    if key not in _DEVICE_FILL:
+        ok = os.environ.get('URE_DEVICE_INIT', '1') != '0' and torch.device(device).type == 'cuda'
+        if ok:
+            try:
+                g = torch.Generator()
+                g.manual_seed(20240609)
+                torch.empty(7, dtype=torch.int64).random_(generator=g)
+                nu, nv_ = 1616 * 1024 + 5, 4099
+                states, want = [], []
+                for _ in range(2):
+                    states.append(g.get_state().clone())
+                    want.append([torch.empty(n).normal_(0, 1, generator=g) for n in (nu, nv_)] + [g.get_state().clone()])
+                got = mf_init_device([st.clone() for st in states], nu, nv_, 0, device, keep_states=True)
+                torch.cuda.synchronize(device)
+                for (U, V, end), (Ud, Vd, st) in zip(want, got):
+                    ok = ok and torch.equal(U.view(torch.int32), Ud.cpu().view(torch.int32)) and torch.equal(V.view(torch.int32), Vd.cpu().view(torch.int32)) \
+                        and torch.equal(end, st)
+            except Exception:
+                ok = False
+        _DEVICE_FILL[key] = bool(ok)
+    return _DEVICE_FILL[key]
+
+
+def mf_init_device(states, nu, nv_, skip_draws, device, stream=None, keep_states=False):
+    """The kept fills of len(states) models made on `device` (ure_device_mf_init), queued on `stream` (default: the current one):
+    states[s] = the torch CPU generator state of shard s (moved, in place, past skip_draws outputs and the two fills).
+    -> [(U0 [nu], V0 [nv_]) device views (+ the state with keep_states)] of ONE allocation; the caller orders its reads behind `stream`."""
+    from . import _native as nv
+    L = nv.lib()
+    S = len(states)
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        st = stream if stream is not None else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(st):
+            block = torch.empty((S, nu + nv_), dtype=torch.float32, device=dev)
+            words = int(L.ure_device_mf_init_scratch(S, nu, nv_))
+            scratch = torch.empty(words, dtype=torch.int32, device=dev)
+            base, row = block.data_ptr(), 4 * (nu + nv_)
+            st_a = (ctypes.c_void_p * S)(*[x.data_ptr() for x in states])
+            u_a = (ctypes.c_void_p * S)(*[base + s * row for s in range(S)])
+            v_a = (ctypes.c_void_p * S)(*[base + s * row + 4 * nu for s in range(S)])
+            skip = (ctypes.c_int64 * S)(*([int(skip_draws)] * S))
+            nv.check(L.ure_device_mf_init(S, st_a, states[0].numel(), skip, u_a, nu, v_a, nv_, scratch.data_ptr(), words, host_cpus(), st.cuda_stream),
+                     'ure_device_mf_init')
+            del scratch            # (back to this stream's pool: reused only behind the kernels that read it)
+    _count(skipped_draws=S * int(skip_draws), device_normals=S * (nu + nv_))
+    return [((block[s, :nu], block[s, nu:]) + ((states[s],) if keep_states else ())) for s in range(S)]
+
+
 def fill_threads(n_normals, sharers=1):
     """Host threads for the 16-blocks of a model init of n_normals values when `sharers` inits run side by side: one for small tables
     (an ml-1m shard: 0.3 M values, 0.5 ms), up to eight for big ones (the 25 M shape at d = 128: 28 M values)."""
     return 1 if n_normals < (2 << 20) else max(1, min(8, host_cpus() // max(1, int(sharers))))
 
 
-def mf_init(n_user, n_item, k, generator=None, threads=None):
+def mf_init(n_user, n_item, k, generator=None, threads=None, device=None):
     """The four N(0,1) fills of `MF(n_user, n_item, k)` (utils.py:31-40).  The first two (the nn.Embedding
     constructors') are overwritten by init_weight: the stream is moved past them without computing them.  The two kept ones come
     from ONE native call (ure_host_mf_init: the uniforms in bulk, the 16-blocks through the installed PyTorch's own kernels on
-    `threads` threads) where that reproduces torch's fill bit for bit (native_fill_ok), else from torch itself."""
+    `threads` threads) where that reproduces torch's fill bit for bit (native_fill_ok), else from torch itself.
+    device: tables of DEVICE_INIT_MIN_NORMALS values or more are made there instead (mf_init_device, queued on the current stream) and
+    returned as device tensors."""
     g = generator
     draws = model_draws(n_user, n_item, k, 0, False)
+    if device is not None and draws is not None and _device_init_wanted((n_user + n_item) * k, device):
+        state = (torch.get_rng_state() if g is None else g.get_state()).clone()
+        U0, V0 = mf_init_device([state], n_user * k, n_item * k, draws[0], device)[0]
+        (torch.set_rng_state if g is None else g.set_state)(state)
+        return U0.view(n_user, k), V0.view(n_item, k)
     if draws is not None and native_fill_ok():
         from . import _native as nv
         state = (torch.get_rng_state() if g is None else g.get_state()).clone()
@@ -540,12 +607,11 @@ class _DrawsTask:
         """The per-epoch seeds WITHOUT the model init: they follow the four fills in the stream, whose lengths are known, so a generator
         moved past them (ure_host_mt_advance) draws them at once -- and the permutations, the bulk of a request's host work, are expanded
         beside the inits instead of behind them.  False: the tables are too small to skip (the seeds come with init())."""
-        import os
         if self.seeds is not None:
             return True
         start_state, n_user, n_item, k, epochs, with_total_test = self.args[:6]
         draws = model_draws(n_user, n_item, k, 0, False)
-        if draws is None or os.environ.get('URE_SEEDS_FIRST', '1') == '0':
+        if draws is None:
             return False
         # (one native call: the state is copied, moved past the four fills and asked for the epochs' int64 draws -- as `random_()` makes them)
         from . import _native as nv
@@ -736,8 +802,7 @@ def device_tags(tasks):
     main = torch.cuda.current_stream(dev)
     dev_all = torch.empty(at, dtype=torch.int16, device=dev)
     # chunks of epochs, the same for every shard: about DEVICE_TAGS_GROUPS permutations per launch (a workgroup each)
-    import os
-    max_groups = int(os.environ.get('URE_DEVICE_TAGS_GROUPS', '0')) or DEVICE_TAGS_GROUPS
+    max_groups = DEVICE_TAGS_GROUPS
     per = max(2, min(epochs, max_groups // max(1, len(tasks))))
     bounds = list(range(0, epochs, per)) + [epochs]
     # the table in launch order -- (chunk, shard, epoch) --, built shard by epoch and reordered once
@@ -825,14 +890,66 @@ def start_inits(specs):
     -> the tasks, to be handed to draws_batch_async(tasks=...) once the caller has done what is more urgent than the permutations'
     buffers (a request: getting its layouts under way)."""
     tasks = [_task_of(sp, buffers=False) for sp in specs]
-    pool = worker_pool()
-    if len(tasks) > 1 and _batch_init_possible(tasks):
-        pool.submit(_batch_init, tasks)                 # ONE worker, one native call for all shards' fills, one upload
-        return tasks
-    for t in tasks:
-        t.sharers = len(tasks)
-        pool.submit(_guarded_init, t)
+    _submit_inits(tasks)
     return tasks
+
+
+def _submit_inits(tasks):
+    """The model inits of a call's shards: on the device where the tables are big enough to be worth it (_device_init), else ONE native
+    call for all shards' fills and one upload (_batch_init), else a worker per shard."""
+    pool = worker_pool()
+    if tasks and _device_init_possible(tasks):
+        pool.submit(_device_init, tasks)
+    elif len(tasks) > 1 and _batch_init_possible(tasks):
+        pool.submit(_batch_init, tasks)
+    else:
+        for t in tasks:
+            t.sharers = len(tasks)
+            pool.submit(_guarded_init, t)
+
+
+def _device_init_wanted(n_normals, device):
+    return device is not None and torch.device(device).type == 'cuda' and n_normals >= DEVICE_INIT_MIN_NORMALS and device_fill_ok(device)
+
+
+def _device_init_possible(tasks):
+    a = tasks[0].args
+    if tasks[0].device is None or not all(t.args[1:4] == a[1:4] and t.args[4:6] == a[4:6] and t.device == tasks[0].device for t in tasks):
+        return False
+    return model_draws(a[1], a[2], a[3], 0, False) is not None and _device_init_wanted(len(tasks) * (a[1] + a[2]) * a[3], tasks[0].device)
+
+
+def _device_init(tasks):
+    """The model inits of all shards of a call made on the device (mf_init_device): the host positions the generators (microseconds per
+    shard: csrc/mt_jump.cpp), the kernels run on this worker's side stream, every task gets its views and the event consumers wait for.
+    No host normals, no upload -- 909 M values and 3.6 GB at BASELINE.json configs[3]."""
+    from .engine import mark
+    try:
+        mark('w: init start')
+        _, n_user, n_item, k, epochs, with_total_test = tasks[0].args[:6]
+        draws = model_draws(n_user, n_item, k, 0, False)
+        dev = tasks[0].device
+        states = [t.args[0].clone() for t in tasks]
+        with torch.cuda.device(dev):
+            up = tasks[0]._upload_stream()
+            out = mf_init_device(states, n_user * k, n_item * k, draws[0], dev, stream=up)
+            ev = torch.cuda.Event()
+            ev.record(up)
+        for t, st, (U0, V0) in zip(tasks, states, out):
+            if t.seeds is None:                          # (the epochs' seeds follow the fills in the stream)
+                g = torch.Generator()
+                g.set_state(st)
+                t.seeds = epoch_seeds(epochs, with_total_test, generator=g)
+            U0, V0 = U0.view(n_user, k), V0.view(n_item, k)
+            U0._ure_event = V0._ure_event = ev
+            t.init_value = (U0, V0)
+        mark('w: init queued on the device')
+        for t in tasks:
+            t.init_done.set()
+    except BaseException as e:
+        for t in tasks:
+            t.fail(e)
+        raise
 
 
 def _batch_init_possible(tasks):
@@ -895,9 +1012,9 @@ def _batch_init(tasks):
         raise
 
 
-def draws_batch_async(specs, n_workers=0, gate=None, tasks=None):
+def draws_batch_async(specs, n_workers=0, tasks=None):
     """shard_draws_async for the shards of one call: every model init on a worker of its own, and beside them FEW chunk workers --
-    worker w takes the shards w, w + W, ...: their seeds first (_DrawsTask.seeds_first: no init needed), then (once `gate` is set)
+    worker w takes the shards w, w + W, ...: their seeds first (_DrawsTask.seeds_first: no init needed), then
     their permutation chunks round robin, so that the first chunk of every shard arrives before anybody's second.  One thread per shard -- round 2 -- meant 16 Python threads taking turns on the GIL
     with the calling thread for a 16-shard call (10 ms between two of its marks).  specs: list of dicts of shard_draws_async's
     arguments.  -> [ShardDraws]."""
@@ -921,8 +1038,6 @@ def draws_batch_async(specs, n_workers=0, gate=None, tasks=None):
                     t.init_done.wait()                  # (tables too small to skip: the seeds come with the init)
                     if t.error is not None:
                         raise t.error
-            if gate is not None:
-                gate.wait()
             gens = [(t, t.chunks()) for t in mine]
             while gens:
                 for t, g in list(gens):
@@ -937,9 +1052,7 @@ def draws_batch_async(specs, n_workers=0, gate=None, tasks=None):
             raise
 
     if not started:
-        for t in tasks:
-            t.sharers = len(tasks)
-            pool.submit(_guarded_init, t)               # the model inits, a worker each ...
+        _submit_inits(tasks)                            # the model inits ...
     if on_device:                                       # (the tags are being made on the device: nothing left for chunk workers)
         from concurrent.futures import Future
         done = Future()
@@ -950,18 +1063,16 @@ def draws_batch_async(specs, n_workers=0, gate=None, tasks=None):
 
 
 def shard_draws_async(start_state, n_user, n_item, k, epochs, with_total_test, n_rows, shuffle, threads=0, device=None, want_perms=True,
-                      chunk_epochs=8, gate=None):
+                      chunk_epochs=8):
     """Everything random of ONE Scratch.train call, taken on a worker thread from its own generator positioned at
     `start_state` (shard_streams): the model init (utils.py:31-40), the per-epoch seeds and the expanded
     permutations.  The shards of a SISA call are independent streams once their start states are known, so their
     draws run side by side instead of one after the other (draws_batch_async).  With a HIP `device` the init tables and
     the permutations are uploaded on a side stream, the permutations in chunks of epochs so that training starts on the first
-    epochs while the later ones are still being expanded.  gate (threading.Event): the permutation expansion -- the bulk of
-    the CPU work -- starts only once it is set, so that whatever the caller needs first (the layouts) gets the cores first.
-    -> ShardDraws."""
+    epochs while the later ones are still being expanded.  -> ShardDraws."""
     return draws_batch_async([dict(start_state=start_state, n_user=n_user, n_item=n_item, k=k, epochs=epochs, with_total_test=with_total_test,
                                    n_rows=n_rows, shuffle=shuffle, threads=threads, device=device, want_perms=want_perms,
-                                   chunk_epochs=chunk_epochs)], 1, gate)[0]
+                                   chunk_epochs=chunk_epochs)], 1)[0]
 
 
 def seed_all(seed):
