@@ -61,6 +61,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-unlearn', action='store_true', help='skip the learn/unlearn wall-time leg')
     ap.add_argument('--no-hbm-leg', action='store_true', help='N = 1: skip the configs[3]-shape leg (roofline_hbm)')
+    ap.add_argument('--no-ot', action='store_true', help='N = 1: skip the OT grouping leg (ot)')
     ap.add_argument('--no-cold', action='store_true', help='N = 1: skip the cold unlearning request (unlearn.cold_request_s)')
     ap.add_argument('--extras-budget', type=float, default=240.0, help='N = 1: seconds after which no further optional leg is started')
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU baseline work')
@@ -194,24 +195,57 @@ def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_st
     sizes = [all_sizes[s] for s in mine]
     steps_per_epoch = [(n + batch - 1) // batch for n in (all_sizes if split else sizes)]
     tps = max(steps_per_epoch)                                     # ticks per bench step (job-wide)
-    n_bench_steps = warmup + steps + roofline_steps
-    epochs = int(np.ceil(n_bench_steps * tps / min(steps_per_epoch))) + 1
+    # The epochs' batches are part of what is timed (the reference's baseTrain iterates the DataLoader, utils.py:58 --
+    # read.py:127-133 shuffles inside it): the tags come from the PRODUCT's path, rng.device_tags (csrc/perm_tags.hip: torch.randperm's
+    # permutations made on the device from the epochs' seeds, on a side stream), and the shuffles of the epochs the timed ticks read are
+    # launched AFTER the clock has started.  A second timed region of K steps with every tag resident gives `value_resident_tags`
+    # (round 4's headline).  Shards beyond 2^20 rows / URE_DEVICE_TAGS=0: host-made tags, resident, one region.
+    dev_tags = bool(mine) and rng.device_tags_wanted() and all(all_sizes[s] <= rng.DEVICE_TAGS_MAX_ROWS and -(-all_sizes[s] // batch) <= 65535 for s in mine)
+    resident_steps = steps if dev_tags else 0
+    n_bench_steps = warmup + steps + resident_steps + roofline_steps
+    min_steps = min(steps_per_epoch)
+    epochs = int(np.ceil(n_bench_steps * tps / min_steps)) + 2
     t_rng = time.perf_counter()
-    inits, perms = [], []
+    inits, perms, seeds = [], [], []
     if not split:
         torch.manual_seed(42 + D.rank)
     for s in mine:
         if split:
             torch.manual_seed(42 + 1000 * s)                       # own shards only: any fixed init serves a throughput leg
         inits.append(rng.mf_init(spec['n_user'], spec['n_item'], d))
-        # the epochs' batches as the product hands them to the device (method/sisa.py, method/scratch.py): batch tags made of the
-        # permutations on the host (struct ure_shard: file_tags); URE_HOST_TAGS=0: the permutations themselves, partitioned on the device
-        seeds_s = rng.epoch_seeds(epochs, True)
-        if os.environ.get('URE_HOST_TAGS', '1') != '0' and -(-all_sizes[s] // batch) <= 65535:
-            perms.append(rng.epoch_tags(seeds_s, all_sizes[s], batch, threads=min(8, os.cpu_count() or 1)))
-        else:
-            perms.append(rng.epoch_perms(seeds_s, all_sizes[s], threads=min(8, os.cpu_count() or 1)))
+        seeds.append(rng.epoch_seeds(epochs, True))
     t_rng = time.perf_counter() - t_rng
+    t_tags = time.perf_counter()
+    fire, fired, bounds = None, 0, None
+    if dev_tags:
+        dev = engine._device()
+        tasks = [rng._task_of(dict(start_state=None, n_user=spec['n_user'], n_item=spec['n_item'], k=d, epochs=epochs, with_total_test=True,
+                                   n_rows=all_sizes[s], shuffle=True, device=dev, tags_batch=batch, seeds=seeds[k]), buffers=False) for k, s in enumerate(mine)]
+        # tick t reads the tags of epoch t // steps + 1 of a shard (prepared one epoch ahead; touch_mode 2: two) -- the smallest shard is the
+        # furthest along.  Chunk 0: what the warm-up reads; chunk 1: what the timed ticks read beyond that; chunk 2: the rest.
+        ahead = 2
+        t0w, t1w = warmup * tps, (warmup + steps) * tps
+        b1 = min(epochs, ((t0w - 1) // min_steps + 1 + ahead) if t0w > 0 else ahead)
+        b2 = min(epochs, (t1w - 1) // min_steps + 1 + ahead)
+        bounds = [0] + sorted({b1, b2, epochs})
+        fire = rng.device_tags(tasks, bounds=bounds, defer=True)
+        assert fire, 'rng.device_tags refused the bench shards'
+        perms = [t.perms_value for t in tasks]
+    else:
+        for k, s in enumerate(mine):
+            # host-made batch tags (struct ure_shard: file_tags), resident before the clock starts; URE_HOST_TAGS=0: the permutations themselves
+            if os.environ.get('URE_HOST_TAGS', '1') != '0' and -(-all_sizes[s] // batch) <= 65535:
+                perms.append(rng.epoch_tags(seeds[k], all_sizes[s], batch, threads=min(8, os.cpu_count() or 1)))
+            else:
+                perms.append(rng.epoch_perms(seeds[k], all_sizes[s], threads=min(8, os.cpu_count() or 1)))
+    t_tags = time.perf_counter() - t_tags
+
+    def fire_until(epoch_end):
+        nonlocal fired
+        while fire is not None and fired + 1 < len(bounds) and bounds[fired + 1] <= epoch_end:
+            fire(fired)
+            fired += 1
+    fire_until(bounds[1] if fire else 0)
     job, shards = None, []
     if mine:
         shards = [engine.ShardData(*parts[s], spec['n_user'], spec['n_item']) for s in mine]
@@ -221,29 +255,43 @@ def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_st
     if job is not None:
         job.run(warmup * tps)
     torch.cuda.synchronize()
-    t0_tick = job.done if job is not None else 0
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides -------------------
-    D.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    w0 = time.perf_counter()
-    ev0.record()
-    if job is not None:
-        job.run(steps * tps)
-    ev1.record()
-    torch.cuda.synchronize()
-    w1 = time.perf_counter()
-    D.barrier()
-    my_wall = w1 - w0
-    dev_ms = ev0.elapsed_time(ev1)
-    t1_tick = job.done if job is not None else 0
-    n_inter, _, _ = interactions_in_ticks(sizes, batch, t0_tick, t1_tick, epochs)
-    wall = D.max(my_wall)
-    n_total = D.sum(n_inter)
+
+    def timed(n_steps, fire_to=None):
+        """Exactly n_steps bench steps between barrier + synchronize on both sides; fire_to: the shuffles of the epochs up to there are launched
+        right behind the region's first event."""
+        t0_tick = job.done if job is not None else 0
+        D.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0 = time.perf_counter()
+        ev0.record()
+        if fire_to is not None:
+            fire_until(fire_to)
+        if job is not None:
+            job.run(n_steps * tps)
+        ev1.record()
+        torch.cuda.synchronize()
+        w1 = time.perf_counter()
+        D.barrier()
+        t1_tick = job.done if job is not None else 0
+        n_inter, _, _ = interactions_in_ticks(sizes, batch, t0_tick, t1_tick, epochs)
+        return {'wall': D.max(w1 - w0), 'my_wall': w1 - w0, 'dev_ms': ev0.elapsed_time(ev1), 'n_total': D.sum(n_inter), 'n_inter': n_inter,
+                't0_tick': t0_tick, 'n_launch': t1_tick - t0_tick}
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides; the epochs' shuffles inside it ----------------------
+    shuffles_timed = (bounds[2] - bounds[1]) * len(mine) if (fire and len(bounds) > 2) else 0
+    r = timed(steps, bounds[2] if (fire and len(bounds) > 2) else None)
+    resident = None
+    if resident_steps:
+        fire_until(epochs)
+        torch.cuda.synchronize()
+        resident = timed(resident_steps)
     out = {'spec': spec, 'data': data, 'groups': groups, 'mine': mine, 'owner': owner, 'sizes': sizes, 'all_sizes': all_sizes,
-           'tps': tps, 'epochs': epochs, 'wall': wall, 'my_wall': my_wall, 'dev_ms': dev_ms, 'n_total': n_total, 'n_inter': n_inter,
-           't_rng': t_rng, 't0_tick': t0_tick, 'n_launch': t1_tick - t0_tick, 'shards': shards, 'job': job,
-           'value': n_total / wall if wall > 0 else 0.0}
+           'tps': tps, 'epochs': epochs, 'wall': r['wall'], 'my_wall': r['my_wall'], 'dev_ms': r['dev_ms'], 'n_total': r['n_total'], 'n_inter': r['n_inter'],
+           't_rng': t_rng, 't_tags': t_tags, 't0_tick': r['t0_tick'], 'n_launch': r['n_launch'], 'shards': shards, 'job': job,
+           'value': r['n_total'] / r['wall'] if r['wall'] > 0 else 0.0,
+           'batch_tags': ('device (rng.device_tags -> perm_tags_kernel on a side stream), launched inside the timed region' if dev_tags else
+                          'host-made, resident before the timed region'),
+           'shuffles_in_timed_region': shuffles_timed, 'resident': resident}
     if not keep_job and job is not None:
         job.close()
         out['job'] = None
@@ -275,7 +323,8 @@ def roofline_of(a, leg, d, batch):
     b_sparse = 16 + 16 * dp
     alg20 = float((per_tick * b_sparse + dense20).sum()) / n_launch
     alg16 = float((per_tick * b_sparse + dense20 * 16 // 20).sum()) / n_launch
-    avg_ms = leg['dev_ms'] / n_launch
+    avg_ms = leg['dev_ms'] / n_launch                      # (the region that holds the epochs' shuffles on the side stream: the headline's launches)
+    res = leg.get('resident')
     step_ms, n_step, _, _ = job.run_profiled(a.roofline_steps * leg['tps'])
     if job.touch and n_step:
         # touch mode: the timed region also holds the three preparation launches of every epoch start, so the step kernel's
@@ -297,6 +346,7 @@ def roofline_of(a, leg, d, batch):
             'alg_gbs_16B_dense': round(alg16 / (avg_ms * 1e-3) / 1e9, 1),
             'avg_launch_us': round(avg_ms * 1e3, 2), 'avg_launch_from': 'event pair per launch' if job.touch else 'events around the timed region / launches',
             'launches_timed': n_launch,
+            'avg_launch_us_resident_tags': round(res['dev_ms'] / max(res['n_launch'], 1) * 1e3, 2) if res else None,
             # (the pass with an event pair around EVERY launch reads higher than region / launches: the two event records a launch is
             # bracketed with take ~1.5-2 us of their own on the stream; it is what splits step launches from epoch-start launches)
             'event_pair_pass_us': round(step_ms / max(n_step, 1) * 1e3, 2),
@@ -401,6 +451,32 @@ def unlearn_leg(a, data, shards, d):
            'batch_tags': 'device' if __import__('ultrare_amd.rng', fromlist=['rng']).device_tags_wanted() else 'host',
            'final_test': {'learn': r['log0'], 'unlearn': r['unlearn_log0']}, 'nan_shards': r['nan_shards']}
     return out, e2e
+
+
+def ot_leg(a):
+    """`ot_cluster` (utils.py:628-656, the `group.py` half of the north-star path) on the driver's clock: n = 6,040 / k = 5 / d = 32 to
+    convergence or 10 rounds, labels asserted equal to the reference's own run (tests/golden/ot_ml1m.npz), and ONE round at n = 162,000 /
+    k = 32 / d = 128; the CPU oracle (oracle.cpu_ref.ot_cluster: the same algorithm with an exact HiGHS LP where the reference calls POT's
+    ot.emd -- SURVEY 8c) timed beside the first within a budget."""
+    from ultrare_amd import measure, synth
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'ot_ml1m.npz'))
+    n, d, seed = int(g['n']), int(g['d']), int(g['seed'])
+    out = {'ml1m_k5': measure.ot_request(n, d, 5, seed, 10, want_label=g['k5_label'])}
+    out['ml25m_k32_one_round'] = measure.ot_request(162000, 128, 32, 20240608, 1)
+    if not a.no_cpu_baseline:
+        from oracle import cpu_ref as O
+        X = synth.ot_embedding(n, d, seed)
+        rounds = 2
+        np.random.seed(0)
+        np.random.choice(n, int(2 / 100 * n), replace=False)
+        t0 = time.perf_counter()
+        O.ot_cluster(X, 5, max_iters=rounds)
+        spent = time.perf_counter() - t0
+        gpu_round = out['ml1m_k5']['wall_s'] / max(out['ml1m_k5']['rounds'], 1)
+        out['cpu_baseline'] = {'kind': 'port', 'value': round(spent / rounds, 3), 'unit': 's per round', 'cores': 1,
+                               'sample': f'oracle.cpu_ref.ot_cluster, n={n}, k=5, d={d}: {rounds} rounds in {spent:.1f}s (numpy cost matrix, exact LP by HiGHS, numpy centroids)',
+                               'gpu_s_per_round': round(gpu_round, 5)}
+    return out
 
 
 def hbm_leg(a, D):
@@ -588,7 +664,13 @@ def main():
                    'shards_per_gpu': len(leg['mine']), 'shard_rows': leg['sizes'], 'ticks_per_step': leg['tps'],
                    'parallelism': f'shards x{world}', 'backend': a.backend if world > 1 else None, 'arch': arch},
         'device_ms_timed': round(leg['dev_ms'], 3), 'interactions_timed': leg['n_total'],
-        'host_rng_prep_s': round(leg['t_rng'], 3),
+        # `value` times the launches AND the epochs' shuffles (the product's device path, launched inside the region); the same K steps with
+        # every tag resident beforehand -- what rounds 1-4 reported as `value` -- stand beside it
+        'batch_tags': leg['batch_tags'], 'shuffles_in_timed_region': leg['shuffles_in_timed_region'],
+        'value_resident_tags': round(leg['resident']['n_total'] / leg['resident']['wall'], 1) if leg.get('resident') else None,
+        'ms_per_step_resident_tags': round(leg['resident']['wall'] * 1e3 / a.steps, 4) if leg.get('resident') else None,
+        'host_rng_prep_s': round(leg['t_rng'], 3), 'host_rng_prep_covers': "model inits and the epochs' seeds (no shuffle is made on the host)",
+        'tag_setup_s': round(leg['t_tags'], 4),
         'roofline': roofline, 'cpu_baseline': None, 'unlearn': None,
     }
     printed = threading.Lock()
@@ -645,6 +727,9 @@ def main():
                                            # MSELoss(sum), lr 1e-3, users with ~2,800 ratings)
                                            'nan_shards': r16['nan_shards']}
             out['unlearn'] = un
+            # the whole learn request on the same clock as the headline: interactions of a 50-epoch learn / its wall time
+            out['value_request'] = round(leg['spec']['n_train'] * 50 / un['learn_wall_s'], 1)
+            out['value_request_note'] = 'Sisa.learn through the operator surface (layouts, inits, shuffles, 50 epochs, per-epoch tests, merge, final test): interactions / learn_wall_s'
             cb = out.get('cpu_baseline')
             if cb and cb.get('end_to_end_value') and un.get('unlearn_interactions'):
                 # both halves of the metric get a stated CPU figure: the unlearn request's interactions at the CPU path's end-to-end rate
@@ -657,6 +742,8 @@ def main():
                 un['cold_request_s'] = c['unlearn']['total_s']
                 un['cold_request'] = {'unlearn': c['unlearn'], 'learn': c['learn'], 'retrained_shards': c['retrained'],
                                       'deleted_users': c['deleted_users'], 'flow': c['flow'], 'final_test': c['unlearn_log0']}
+        if a.workload == 'ml1m' and not a.no_ot and time.perf_counter() - t_start < a.extras_budget:
+            out['ot'] = ot_leg(a)
         if a.workload == 'ml1m' and not a.no_hbm_leg and time.perf_counter() - t_start < a.extras_budget:
             if job is not None:
                 job.close()

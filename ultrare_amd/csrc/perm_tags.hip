@@ -125,9 +125,11 @@ __global__ __launch_bounds__(kPermBlock) void perm_tags_kernel(const ure_perm_t 
 #pragma unroll
         for (int k = 0; k < kPermInFlight; ++k) admit(k);
         unsigned spins = 0;
+        bool failed = false;
         for (;;) {
             if (++spins > 4u * total + 1024u) {                   // (cannot happen: the oldest pending swap is carried out in every round)
                 if (tid == 0) gave_up[blockIdx.x] = 0xdeadu;
+                failed = true;                                    // (uniform: every lane counts the same rounds)
                 break;
             }
             unsigned mine = 0;
@@ -172,8 +174,10 @@ __global__ __launch_bounds__(kPermBlock) void perm_tags_kernel(const ure_perm_t 
             __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0) = the workgroup-scope RELEASE of this round's stores (the next barrier publishes them)
         }
         // ---- the tags: file row f trains at position inv[f] of the epoch
+        // (a shuffle that was given up leaves tags that match NO batch: nothing trains on a wrong permutation, and the host finds the
+        // flag when it reads the job's results -- ultrare_amd.engine.TrainJob.check_tags)
         uint16_t *out = perms[perm].tags;
-        for (int f = tid; f < n; f += kPermBlock) out[f] = (uint16_t)(inv[f] / (unsigned)batch);
+        for (int f = tid; f < n; f += kPermBlock) out[f] = failed ? (uint16_t)0xFFFFu : (uint16_t)(inv[f] / (unsigned)batch);
         __syncthreads();
     }
 }

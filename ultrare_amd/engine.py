@@ -749,15 +749,25 @@ class TrainJob:
         """epoch_sse of every shard, [n_shards, epochs] (host; synchronises once)."""
         return self.epoch_sse_queue().cpu().numpy()
 
+    def check_tags(self):
+        """Device-made batch tags (rng.device_tags): did a workgroup of perm_tags_kernel give up on a shuffle?  It cannot -- and its tags
+        then match no batch, so nothing trained on a wrong permutation -- but a job that trained on fewer rows must not pass silently.
+        Reads one small flag array (synchronises): called by close() and by callers right after they read a job's results."""
+        from . import rng
+        rng.device_tags_check(self._perms or [])
+
     def close(self):
         if self._job:
             nv.lib().ure_job_destroy(self._job)
             self._job = ctypes.c_void_p()
-            # the device memory goes back now (ure_job_destroy has waited for the device): tables, snapshots, batch tags and what made them
-            self._pool = self._snap_pool = self._small = None
-            self._perms = []
-            if isinstance(getattr(self, 'state', None), _States):
-                self.state._got.clear()
+            try:
+                self.check_tags()                 # (ure_job_destroy has waited for the device)
+            finally:
+                # the device memory goes back now: tables, snapshots, batch tags and what made them
+                self._pool = self._snap_pool = self._small = None
+                self._perms = []
+                if isinstance(getattr(self, 'state', None), _States):
+                    self.state._got.clear()
 
     def __del__(self):
         try:

@@ -159,3 +159,53 @@ def cold_request(shards=5, k=32, epochs=50, data=None):
             'deleted_users': len(del_user), 'log0': s.log0, 'unlearn_log0': s2.log0,
             'flow': 'config.py:139-172: CSV files on disk -> readRating (partition with the deletion set) -> loaders -> HBM layouts '
                     '(uploaded over PCIe) -> Sisa.learn / unlearn (50 epochs, per-epoch logs) -> merge -> final test'}
+
+
+def ot_request(n, d, k, seed, max_iters=10, want_label=None, cost_reps=20):
+    """The other half of the north-star path: `ot_cluster` (utils.py:628-656) on a synthetic user embedding (synth.ot_embedding), preceded by the
+    draws the reference's CLI makes before it (config.py:47-49).  -> dict: wall time of the call (no synchronisation added), the same call once
+    more with every round's parts timed apart (centroid upload, cost kernel, device potentials, cost matrix to the host, exact host solver,
+    centroid kernel + copy back), and the cost kernel alone between HIP events (algorithmic bytes: X read once, the [k, n] matrix written).
+    want_label: the labels the reference's own run gave (tests/golden/ot_ml1m.npz) -- asserted equal."""
+    from ultrare_amd import _native as nv, engine, synth
+    from ultrare_amd.method.utils import ot_cluster
+    X = synth.ot_embedding(n, d, seed)
+
+    def call(timing=None):
+        np.random.seed(0)
+        np.random.choice(n, int(2 / 100 * n), replace=False)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):           # (ot_cluster prints its inertia and @time as the reference does)
+            t0 = time.perf_counter()
+            inertia, label = ot_cluster(X, k, max_iters, timing=timing)
+            return time.perf_counter() - t0, float(inertia), label
+    call()                                                        # warm-up: library, allocator, solver threads
+    walls = sorted(call()[0] for _ in range(3))
+    parts = []
+    _, inertia, label = call(parts)
+    if want_label is not None:
+        assert np.array_equal(label, want_label), 'ot_cluster: labels differ from the reference run recorded in tests/golden/ot_ml1m.npz'
+    # the cost kernel alone
+    dev = engine._device()
+    L, st = nv.lib(), nv.stream_handle()
+    Xd = torch.from_numpy(X).to(dev)
+    Cd = Xd[:k].clone()
+    dist_d = torch.empty(k, n, dtype=torch.float32, device=dev)
+    nv.check(L.ure_ot_cost(nv.ptr(Xd), nv.ptr(Cd), n, k, d, nv.ptr(dist_d), st), 'ure_ot_cost')
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(cost_reps):
+        nv.check(L.ure_ot_cost(nv.ptr(Xd), nv.ptr(Cd), n, k, d, nv.ptr(dist_d), st), 'ure_ot_cost')
+    ev1.record()
+    torch.cuda.synchronize()
+    cost_us = ev0.elapsed_time(ev1) * 1e3 / cost_reps
+    alg = 4 * (n * d + k * d + k * n)
+    keys = sorted({key for p in parts for key in p})
+    return {'n': n, 'd': d, 'k': k, 'rounds': len(parts), 'wall_s': round(walls[len(walls) // 2], 5), 'wall_s_all': [round(w, 5) for w in walls],
+            'per_round_ms': {key: round(float(np.mean([p[key] for p in parts])), 4) for key in keys},
+            'per_round_ms_note': 'a second call with a synchronisation between the parts; wall_s is the call as the product makes it',
+            'inertia': inertia, 'labels_equal_reference_run': (True if want_label is not None else None),
+            'group_sizes': np.bincount(label, minlength=k).tolist() if k <= 32 else None,
+            'cost_kernel': {'us': round(cost_us, 2), 'alg_bytes': alg, 'achieved_gbs': round(alg / cost_us / 1e3, 1), 'peak_gbs': 8000.0,
+                            'frac': round(alg / cost_us / 1e3 / 8000.0, 4),
+                            'note': 'algorithmic bytes = X read once + centroids + the [k, n] cost matrix written; HIP events around %d launches' % cost_reps}}

@@ -157,11 +157,21 @@ def timefn(fn):
     return measure_time
 
 
-def _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi=None, mfma_check=None):
+def _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi=None, mfma_check=None, timing=None):
     """One round of utils.py:637-648 on the device + the exact host LP.  mfma_check (a list): the round is also
     solved on the MFMA form of the cost matrix (ure_ot_cost_mfma) and the number of labels that differ from the
-    exact path's is appended -- the cross-check that form needs before anyone may rely on it."""
+    exact path's is appended -- the cross-check that form needs before anyone may rely on it.
+    timing (a list): the round's parts are timed on the host's clock with a synchronisation between them (bench.py's OT leg) and
+    appended as a dict of milliseconds."""
     L, st = nv.lib(), nv.stream_handle()
+    tick = None
+    if timing is not None:
+        marks = []
+
+        def tick(name):
+            torch.cuda.synchronize()
+            marks.append((name, time.perf_counter()))
+        tick('start')
     cd = torch.from_numpy(np.ascontiguousarray(centroid, dtype=np.float32)).to(Xd.device)
     fast_label = None
     if mfma_check is not None:
@@ -169,13 +179,23 @@ def _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi=None,
         fpi = np.zeros(k, dtype=np.float64) if pi is None else pi.copy()
         nv.check(L.ure_ot_potentials(nv.ptr(dist_d), n, k, ot_warm_iters(n), fpi.ctypes.data, None, st), 'ure_ot_potentials')
         fast_label, _, _, _ = nv.ot_assign_warm(dist_d.cpu().numpy(), fpi, want_plan=False)
+    if tick:
+        tick('centroid_upload')
     nv.check(L.ure_ot_cost(nv.ptr(Xd), nv.ptr(cd), n, k, d, nv.ptr(dist_d), st), 'ure_ot_cost')
+    if tick:
+        tick('cost_kernel')
     # cluster potentials by dual ascent on the device (a warm start only: the LP below is solved exactly for any
     # potentials), while the cost matrix travels to the host
     pi = np.zeros(k, dtype=np.float64) if pi is None else pi         # in: the previous round's, out: this round's
     nv.check(L.ure_ot_potentials(nv.ptr(dist_d), n, k, ot_warm_iters(n), pi.ctypes.data, None, st), 'ure_ot_potentials')
+    if tick:
+        tick('device_potentials')
     dist = dist_d.cpu().numpy()                                       # [k, n] fp32 (synchronises)
+    if tick:
+        tick('cost_to_host')
     label, _, _, _ = nv.ot_assign_warm(dist, pi, want_plan=False)     # exact EMD + argmax (host)
+    if tick:
+        tick('host_solver')
     if fast_label is not None:
         mfma_check.append(int((fast_label != label).sum()))
     # utils.py:648 from member lists: a stable sort of the labels (ascending id inside a cluster = numpy's order of addition)
@@ -183,13 +203,17 @@ def _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi=None,
     off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(label, minlength=k))]).astype(np.int64)).to(Xd.device)
     nv.check(L.ure_ot_centroids_members(nv.ptr(Xd), nv.ptr(order), nv.ptr(off), n, k, d, nv.ptr(cent_d), nv.ptr(counts_d), st),
              'ure_ot_centroids_members')
-    return dist, label, cent_d.cpu().numpy()
+    new_centroid = cent_d.cpu().numpy()
+    if tick:
+        tick('centroids')
+        timing.append({b[0] + '_ms': round((b[1] - a[1]) * 1e3, 4) for a, b in zip(marks[:-1], marks[1:])})
+    return dist, label, new_centroid
 
 
 @timefn
-def ot_cluster(X, k, max_iters=10):
+def ot_cluster(X, k, max_iters=10, timing=None):
     """utils.py:628-656.  Initial centroids come from the global numpy generator, as in
-    the reference.  Returns (inertia, label[int64])."""
+    the reference.  Returns (inertia, label[int64]).  timing (a list, optional): every round's parts in milliseconds (_ot_round)."""
     X = np.ascontiguousarray(X, dtype=np.float32)
     n, d = X.shape
     if k < 1 or k > n:
@@ -207,7 +231,7 @@ def ot_cluster(X, k, max_iters=10):
     check = [] if os.environ.get('URE_OT_MFMA', '0') == '1' else None
     ot_cluster.mfma_mismatches = check
     for _ in range(max_iters):
-        dist, label, new_centroid = _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi, check)
+        dist, label, new_centroid = _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi, check, timing)
         inertia = np.min(dist, axis=0).sum()
         if np.allclose(centroid, new_centroid):
             break

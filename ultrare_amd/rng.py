@@ -777,12 +777,14 @@ def device_tags_wanted():
     return os.environ.get('URE_DEVICE_TAGS', '1') != '0'
 
 
-def device_tags(tasks):
+def device_tags(tasks, bounds=None, defer=False):
     """The batch tags of a call's shards made on the DEVICE (ure_device_randperm_tags: csrc/perm_tags.hip) instead of by host threads:
     the seeds come by skip-ahead (_DrawsTask.seeds_first), every (shard, epoch) is one entry of ONE descriptor table, and the epochs go
     out in a few launches on a side stream -- chunk c of all shards together --, each with the event TrainJob.run waits for before
     the launches that read it.  No host buffer, no upload, no expansion threads.  -> False when a shard cannot take this path (too
-    many rows, no tags, tables too small to skip ahead): the caller falls back to the host path for the whole call."""
+    many rows, no tags, tables too small to skip ahead): the caller falls back to the host path for the whole call.
+    bounds: the chunks' epoch boundaries [0, ..., epochs] instead of ~DEVICE_TAGS_GROUPS permutations per launch.  defer: nothing is
+    launched here; -> fire(c), which launches chunk c (in order) -- bench.py puts the shuffles of the epochs it times inside its clock."""
     from . import _native as nv
     from .engine import upload_many
     plans = [t._buffer_plan() for t in tasks]
@@ -803,8 +805,11 @@ def device_tags(tasks):
     dev_all = torch.empty(at, dtype=torch.int16, device=dev)
     # chunks of epochs, the same for every shard: about DEVICE_TAGS_GROUPS permutations per launch (a workgroup each)
     max_groups = DEVICE_TAGS_GROUPS
-    per = max(2, min(epochs, max_groups // max(1, len(tasks))))
-    bounds = list(range(0, epochs, per)) + [epochs]
+    if bounds is None:
+        per = max(2, min(epochs, max_groups // max(1, len(tasks))))
+        bounds = list(range(0, epochs, per)) + [epochs]
+    bounds = [int(b) for b in bounds]
+    assert bounds[0] == 0 and bounds[-1] == epochs and all(a < b for a, b in zip(bounds[:-1], bounds[1:]))
     # the table in launch order -- (chunk, shard, epoch) --, built shard by epoch and reordered once
     S = len(tasks)
     n_of = np.array([p[2] for p in plans], dtype=np.int64)
@@ -830,19 +835,26 @@ def device_tags(tasks):
     side = _PERM_STREAMS.get(str(dev))
     if side is None:
         side = _PERM_STREAMS[str(dev)] = torch.cuda.Stream(dev)
+    # (the three blocks are made on the caller's stream and worked on by the side stream: the allocator must not hand them to anybody
+    # else before the side stream is through with them, whatever becomes of the request -- ADVICE r4)
+    for block in (scratch, dev_all, table_dev):
+        block.record_stream(side)
     ready = torch.cuda.Event()
     ready.record(main)
     side.wait_event(ready)
-    events = []
-    for c1, lo, hi in launches:
+    chunks = [(c1, threading.Event(), [None]) for c1, _, _ in launches]    # (the same for every shard: a launch holds chunk c of all of them)
+
+    def fire(c):
+        c1, lo, hi = launches[c]
         nv.check(L.ure_device_randperm_tags(table_dev.data_ptr() + lo * PERM_DTYPE.itemsize, hi - lo, n_max, scratch.data_ptr(), words, groups,
                                             side.cuda_stream), 'ure_device_randperm_tags')
         ev = torch.cuda.Event()
         ev.record(side)
-        events.append((c1, ev))
-    flag = threading.Event()
-    flag.set()
-    chunks = [(c1, flag, [ev]) for c1, ev in events]              # (the same for every shard: a launch holds chunk c of all of them)
+        chunks[c][2][0] = ev
+        chunks[c][1].set()
+    if not defer:
+        for c in range(len(launches)):
+            fire(c)
     for t, (_, e, n_rows), o in zip(tasks, plans, offs):
         on_dev = dev_all[o:o + e * n_rows].view(e, n_rows)
         t.host, t.on_dev, t.ready = None, on_dev, ready
@@ -851,7 +863,7 @@ def device_tags(tasks):
         on_dev._ure_flags = flags
         on_dev._ure_chunks = list(chunks)
         t.perms_value = on_dev
-    return True
+    return fire if defer else True
 
 
 def device_tags_check(perms):

@@ -128,3 +128,13 @@ def split_shards(triple, shard_of, n_group, max_rating=5):
         m = s == g
         out.append((u[m].astype(np.int32), i[m].astype(np.int32), (r[m] / max_rating).astype(np.float32)))
     return out
+
+
+def ot_embedding(n, d, seed):
+    """A user embedding of 12 blurred clusters for the OT grouping legs (the generator tests/golden/make_golden.py used for ot_ml1m.npz:
+    the fixture stores its checksum).  float32 [n, d]."""
+    rs = np.random.RandomState(seed)
+    centers = rs.standard_normal((12, d)) * 0.8
+    which = rs.randint(0, 12, n)
+    X = centers[which] + rs.standard_normal((n, d)) * 0.6
+    return X.astype(np.float32)
