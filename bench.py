@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', choices=['ml1m', 'ml25m'], default='ml1m',
                     help="ml1m: BASELINE configs[1] (default); ml25m: configs[3] shape (32 shards, d=128)")
@@ -216,7 +216,7 @@ def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_st
         seeds.append(rng.epoch_seeds(epochs, True))
     t_rng = time.perf_counter() - t_rng
     t_tags = time.perf_counter()
-    fire, fired, bounds = None, 0, None
+    fire, fired, bounds, b1, timed_to, perms_methods = None, 0, None, 0, 0, []
     if dev_tags:
         dev = engine._device()
         tasks = [rng._task_of(dict(start_state=None, n_user=spec['n_user'], n_item=spec['n_item'], k=d, epochs=epochs, with_total_test=True,
@@ -227,10 +227,18 @@ def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_st
         t0w, t1w = warmup * tps, (warmup + steps) * tps
         b1 = min(epochs, ((t0w - 1) // min_steps + 1 + ahead) if t0w > 0 else ahead)
         b2 = min(epochs, (t1w - 1) // min_steps + 1 + ahead)
-        bounds = [0] + sorted({b1, b2, epochs})
+        # ... each cut into the chunks the product launches a request's shuffles in (rng.default_tag_bounds: two small ones first)
+        n_max = max(all_sizes[s] for s in mine)
+        cuts = [0]
+        for lo, hi in zip([0, b1, b2], [b1, b2, epochs]):
+            if hi > lo:
+                cuts += [lo + x for x in rng.default_tag_bounds(hi - lo, len(mine), n_max)[1:]]
+        bounds = sorted(set(cuts))
+        timed_to = b2
         fire = rng.device_tags(tasks, bounds=bounds, defer=True)
         assert fire, 'rng.device_tags refused the bench shards'
         perms = [t.perms_value for t in tasks]
+        perms_methods = list(perms[0]._ure_methods)
     else:
         for k, s in enumerate(mine):
             # host-made batch tags (struct ure_shard: file_tags), resident before the clock starts; URE_HOST_TAGS=0: the permutations themselves
@@ -245,7 +253,7 @@ def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_st
         while fire is not None and fired + 1 < len(bounds) and bounds[fired + 1] <= epoch_end:
             fire(fired)
             fired += 1
-    fire_until(bounds[1] if fire else 0)
+    fire_until(b1 if fire else 0)
     job, shards = None, []
     if mine:
         shards = [engine.ShardData(*parts[s], spec['n_user'], spec['n_item']) for s in mine]
@@ -268,18 +276,23 @@ def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_st
         if fire_to is not None:
             fire_until(fire_to)
         if job is not None:
+            job.wait_marks = []                                 # (event pairs around the stream's waits for tag chunks)
             job.run(n_steps * tps)
         ev1.record()
         torch.cuda.synchronize()
         w1 = time.perf_counter()
         D.barrier()
         t1_tick = job.done if job is not None else 0
+        waited = 0.0
+        if job is not None:
+            waited = sum(e0.elapsed_time(e1) for e0, e1 in job.wait_marks)
+            job.wait_marks = None
         n_inter, _, _ = interactions_in_ticks(sizes, batch, t0_tick, t1_tick, epochs)
         return {'wall': D.max(w1 - w0), 'my_wall': w1 - w0, 'dev_ms': ev0.elapsed_time(ev1), 'n_total': D.sum(n_inter), 'n_inter': n_inter,
-                't0_tick': t0_tick, 'n_launch': t1_tick - t0_tick}
+                't0_tick': t0_tick, 'n_launch': t1_tick - t0_tick, 'waited_ms': waited}
     # ---- timed region: exactly K steps, barrier + synchronize on both sides; the epochs' shuffles inside it ----------------------
-    shuffles_timed = (bounds[2] - bounds[1]) * len(mine) if (fire and len(bounds) > 2) else 0
-    r = timed(steps, bounds[2] if (fire and len(bounds) > 2) else None)
+    shuffles_timed = (timed_to - b1) * len(mine) if fire else 0
+    r = timed(steps, timed_to if fire else None)
     resident = None
     if resident_steps:
         fire_until(epochs)
@@ -287,9 +300,10 @@ def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_st
         resident = timed(resident_steps)
     out = {'spec': spec, 'data': data, 'groups': groups, 'mine': mine, 'owner': owner, 'sizes': sizes, 'all_sizes': all_sizes,
            'tps': tps, 'epochs': epochs, 'wall': r['wall'], 'my_wall': r['my_wall'], 'dev_ms': r['dev_ms'], 'n_total': r['n_total'], 'n_inter': r['n_inter'],
-           't_rng': t_rng, 't_tags': t_tags, 't0_tick': r['t0_tick'], 'n_launch': r['n_launch'], 'shards': shards, 'job': job,
+           't_rng': t_rng, 't_tags': t_tags, 't0_tick': r['t0_tick'], 'n_launch': r['n_launch'], 'shards': shards, 'job': job, 'waited_ms': r['waited_ms'],
+           'tag_chunks': ([{'epochs': [a_, b_], 'by': m} for a_, b_, m in zip(bounds[:-1], bounds[1:], perms_methods)] if fire else None),
            'value': r['n_total'] / r['wall'] if r['wall'] > 0 else 0.0,
-           'batch_tags': ('device (rng.device_tags -> perm_tags_kernel on a side stream), launched inside the timed region' if dev_tags else
+           'batch_tags': ('device (rng.device_tags -> csrc/perm_chain.hip / perm_tags.hip on two side streams, in the product\'s chunks), launched inside the timed region' if dev_tags else
                           'host-made, resident before the timed region'),
            'shuffles_in_timed_region': shuffles_timed, 'resident': resident}
     if not keep_job and job is not None:
@@ -323,7 +337,9 @@ def roofline_of(a, leg, d, batch):
     b_sparse = 16 + 16 * dp
     alg20 = float((per_tick * b_sparse + dense20).sum()) / n_launch
     alg16 = float((per_tick * b_sparse + dense20 * 16 // 20).sum()) / n_launch
-    avg_ms = leg['dev_ms'] / n_launch                      # (the region that holds the epochs' shuffles on the side stream: the headline's launches)
+    # the region holds the epochs' shuffles on the side streams and, on the launch stream, the waits for their chunks: the step kernel's
+    # own duration is the region minus those waits (event pairs around them) over its launches -- what rocprofv3 reads for the kernel
+    avg_ms = (leg['dev_ms'] - leg.get('waited_ms', 0.0)) / n_launch
     res = leg.get('resident')
     step_ms, n_step, _, _ = job.run_profiled(a.roofline_steps * leg['tps'])
     if job.touch and n_step:
@@ -344,7 +360,8 @@ def roofline_of(a, leg, d, batch):
             'fabric_gbs': round(fabric, 1) if fabric else None, 'fabric_frac': round(fabric / HBM_PEAK_GBS, 4) if fabric else None,
             'alg_bytes_per_launch': round(alg20), 'alg_bytes_per_launch_16B_dense': round(alg16),
             'alg_gbs_16B_dense': round(alg16 / (avg_ms * 1e-3) / 1e9, 1),
-            'avg_launch_us': round(avg_ms * 1e3, 2), 'avg_launch_from': 'event pair per launch' if job.touch else 'events around the timed region / launches',
+            'avg_launch_us': round(avg_ms * 1e3, 2), 'avg_launch_from': 'event pair per launch' if job.touch else 'events around the timed region minus the stream\'s waits for tag chunks (event pairs), / launches',
+            'stream_waited_for_tags_ms': round(leg.get('waited_ms', 0.0), 3), 'avg_launch_us_region': round(leg['dev_ms'] / n_launch * 1e3, 2),
             'launches_timed': n_launch,
             'avg_launch_us_resident_tags': round(res['dev_ms'] / max(res['n_launch'], 1) * 1e3, 2) if res else None,
             # (the pass with an event pair around EVERY launch reads higher than region / launches: the two event records a launch is
@@ -535,7 +552,17 @@ def fullmf_leg(a, D, data):
     torch.manual_seed(42)
     init = tuple(t * 0.3 for t in rng.mf_init(spec_u, spec_i, 128))          # (0.3: predictions of +-1 at the start, the tables stay finite)
     E = 3
-    tags = rng.epoch_tags(rng.epoch_seeds(E, True), n, a.batch, threads=min(16, os.cpu_count() or 1))
+    # the epochs' batch tags as Scratch.train gets them: made on the device (rng.epoch_tags_device -> csrc/perm_chain.hip; 22.5 M rows are
+    # beyond perm_tags.hip's 2^20), a launch per epoch on the side streams, inside this leg; the host's Fisher-Yates only under URE_DEVICE_TAGS=0
+    seeds = rng.epoch_seeds(E, True)
+    torch.cuda.synchronize()
+    t_sh = time.perf_counter()
+    tags = rng.epoch_tags_device(seeds, n, a.batch, engine._device())
+    tags_by = 'device (csrc/perm_chain.hip)'
+    if tags is None:
+        tags, tags_by = rng.epoch_tags(seeds, n, a.batch, threads=min(16, os.cpu_count() or 1)), 'host threads'
+    torch.cuda.synchronize()
+    t_sh = (time.perf_counter() - t_sh) / E
     sh = engine.ShardData(u, i, (r / 5.0).astype(np.float32), spec_u, spec_i)
     job = engine.TrainJob([sh], [init], [tags], 128, a.batch, E, 1e-3, 0.1, 0.9, 0.95, final_only=True)
     steps = job.steps_per_epoch(0)
@@ -549,7 +576,9 @@ def fullmf_leg(a, D, data):
     finite = bool(np.isfinite(job.epoch_sse(0)).all())
     job.close()
     traffic, traffic_src, traffic_note = pmc_traffic_of(f'ml25m_s1_d128_b{a.batch}', 'mf_index_step_kernel' if job.index else 'mf_touch_step_kernel')
-    return {'workload': f'full MF, synthetic {spec_u}x{spec_i}, {n} train rows, ONE shard, d=128, batch={a.batch}: {steps} optimizer steps per epoch',
+    return {'workload': f'full MF, synthetic {spec_u}x{spec_i}, {n} train rows, ONE shard, d=128, batch={a.batch}: {steps} optimizer steps per epoch; '
+                        'inits = 0.3 x the reference\'s N(0, 1) draws and ratings / 5 (with N(0, 1) at d = 128 the reference\'s own arithmetic is NaN from epoch 2)',
+            'batch_tags': tags_by, 'shuffle_ms_per_epoch': round(t_sh * 1e3, 2),
             'traffic': traffic, 'traffic_source': traffic_src, 'traffic_note': traffic_note,
             'traffic_over_algorithmic': round(traffic / alg, 3) if traffic else None,
             'fabric_frac': round(traffic / us / 1e3 / HBM_PEAK_GBS, 4) if traffic else None,
@@ -666,7 +695,7 @@ def main():
         'device_ms_timed': round(leg['dev_ms'], 3), 'interactions_timed': leg['n_total'],
         # `value` times the launches AND the epochs' shuffles (the product's device path, launched inside the region); the same K steps with
         # every tag resident beforehand -- what rounds 1-4 reported as `value` -- stand beside it
-        'batch_tags': leg['batch_tags'], 'shuffles_in_timed_region': leg['shuffles_in_timed_region'],
+        'batch_tags': leg['batch_tags'], 'shuffles_in_timed_region': leg['shuffles_in_timed_region'], 'tag_chunks': leg.get('tag_chunks'),
         'value_resident_tags': round(leg['resident']['n_total'] / leg['resident']['wall'], 1) if leg.get('resident') else None,
         'ms_per_step_resident_tags': round(leg['resident']['wall'] * 1e3 / a.steps, 4) if leg.get('resident') else None,
         'host_rng_prep_s': round(leg['t_rng'], 3), 'host_rng_prep_covers': "model inits and the epochs' seeds (no shuffle is made on the host)",
@@ -742,6 +771,9 @@ def main():
                 un['cold_request_s'] = c['unlearn']['total_s']
                 un['cold_request'] = {'unlearn': c['unlearn'], 'learn': c['learn'], 'retrained_shards': c['retrained'],
                                       'deleted_users': c['deleted_users'], 'flow': c['flow'], 'final_test': c['unlearn_log0']}
+            if time.perf_counter() - t_start < a.extras_budget:
+                # the full-MF stage as a request (config.py:182-188; BASELINE.json configs[0]'s shape): its epochs' shuffles made on the device
+                un['run_full'] = e2e.full_request(a.d, 50, data=leg['data'], reps=4)
         if a.workload == 'ml1m' and not a.no_ot and time.perf_counter() - t_start < a.extras_budget:
             out['ot'] = ot_leg(a)
         if a.workload == 'ml1m' and not a.no_hbm_leg and time.perf_counter() - t_start < a.extras_budget:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define URE_ABI_VERSION 8
+#define URE_ABI_VERSION 9
 #define URE_MAX_MODELS_PER_CALL 32
 #define URE_SCORE_PARTIALS 2048       /* length of ure_score's sse buffer */
 
@@ -229,6 +229,19 @@ typedef struct ure_perm {
 int64_t ure_device_randperm_tags_scratch(int64_t n_max, int32_t groups);
 int ure_device_randperm_tags(const ure_perm_t *perms, int32_t n_perms, int64_t n_max, uint32_t *scratch, int64_t scratch_words, int32_t groups,
                              void *stream);
+/* ABI 9.  The same tags by MANY workgroups per permutation and for up to 2^27 rows (csrc/perm_chain.hip): the shuffle's result in closed
+ * form -- the swaps grouped by the position they target, a row's value = the smallest swap that targets it or a short chase along
+ * "largest member" links -- in four stream-ordered launches (MT19937 targets + counts per range of 4,096 targets; the swaps bucketed by
+ * range; per (permutation, range) the target lists in LDS; resolve + divide).  No 2^20-row limit (read.py:127-133 for config.py:182-188's
+ * full-MF run: 22.5 M rows at the 25 M shape) and a fraction of perm_tags.hip's latency for a request's first epochs.  perms: DEVICE
+ * memory, as above; scratch: device memory of ure_device_shuffle_tags_scratch(largest n, n_perms) words (20 bytes per row and permutation
+ * of the call), reusable by the next call on the same stream.  range_log2: 0 (the library chooses: 11 up to 2^24 rows, 12 up to 2^25, else 14), 11, 12 or 14.
+ * Word ure_device_shuffle_tags_flag(n_max, n_perms) of the scratch is set to 0xdead if the resolve pass met a link it cannot follow (it
+ * cannot; such a row gets tag 0xFFFF, which matches no batch; the caller clears the word when it makes the scratch).                  */
+int64_t ure_device_shuffle_tags_scratch(int64_t n_max, int32_t n_perms);
+int64_t ure_device_shuffle_tags_flag(int64_t n_max, int32_t n_perms);
+int ure_device_shuffle_tags(const ure_perm_t *perms, int32_t n_perms, int64_t n_max, uint32_t *scratch, int64_t scratch_words, int32_t range_log2,
+                            void *stream);
 /* Moves a torch CPU generator state (the bytes of torch.get_rng_state(): u64 seed, i32 left, i32 seeded,
  * u64 next, u64 state[624], ...) past `n_draws` 32-bit MT19937 outputs without producing them: the model
  * init fills the reference discards (utils.py:31-40: the nn.Embedding constructors' fills) and, in a

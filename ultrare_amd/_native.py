@@ -11,7 +11,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('URE_LIB') or os.path.join(_PKG, 'libultrare_hip.so')      # URE_LIB: experiment builds (tools/) only
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_MODELS_PER_CALL = 32
 
 _vp = ctypes.c_void_p
@@ -62,6 +62,9 @@ _PROTOTYPES = {
     'ure_host_randperm_tags': (ctypes.c_int, [_vp, ctypes.c_int, _i64, _i32, _vp, ctypes.c_int]),
     'ure_device_randperm_tags_scratch': (_i64, [_i64, _i32]),
     'ure_device_randperm_tags': (ctypes.c_int, [_vp, _i32, _i64, _vp, _i64, _i32, _vp]),
+    'ure_device_shuffle_tags_scratch': (_i64, [_i64, _i32]),
+    'ure_device_shuffle_tags_flag': (_i64, [_i64, _i32]),
+    'ure_device_shuffle_tags': (ctypes.c_int, [_vp, _i32, _i64, _vp, _i64, _i32, _vp]),
     'ure_host_mt_advance': (ctypes.c_int, [_vp, _i64, _i64]),
     'ure_host_mt_jump_blocks': (ctypes.c_int, [_vp, _i64]),
     'ure_host_mt_jump_support': (ctypes.c_int, [_i64, _vp, _i32, ctypes.POINTER(_i32)]),

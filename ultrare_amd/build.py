@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libultrare_hip.so')
-SOURCES = ['ure_common.hip', 'mf_train.hip', 'tag_prep.hip', 'mf_eval.hip', 'job_io.hip', 'perm_tags.hip', 'mf_init.hip', 'ot.hip', 'ot_solver.cpp', 'host_rng.cpp', 'mt_jump.cpp', 'host_layout.cpp']
+SOURCES = ['ure_common.hip', 'mf_train.hip', 'tag_prep.hip', 'mf_eval.hip', 'job_io.hip', 'perm_tags.hip', 'perm_chain.hip', 'mf_init.hip', 'ot.hip', 'ot_solver.cpp', 'host_rng.cpp', 'mt_jump.cpp', 'host_layout.cpp']
 # -amdgpu-kernarg-preload-count: gfx950 delivers the first kernel arguments in SGPRs at wave launch, which
 # removes the first of the step kernel's dependent scalar-load rounds (bench: 13.1 -> 12.6 us per launch)
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-munsafe-fp-atomics',

@@ -605,7 +605,15 @@ class TrainJob:
                     chunk[1].wait()
                     if chunk[2][0] is None:
                         raise nv.NativeError('the permutation worker failed before this chunk was uploaded')
-                    st.wait_event(chunk[2][0])
+                    marks = getattr(self, 'wait_marks', None)
+                    if marks is None:
+                        st.wait_event(chunk[2][0])
+                    else:           # (measurement: how long the stream stood still for the chunk -- bench.py takes it out of the launches' time)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(st)
+                        st.wait_event(chunk[2][0])
+                        e1.record(st)
+                        marks.append((e0, e1))
                 for ch in self._chunks:
                     while ch and ch[0][0] <= need and len(ch) > 1:      # chunks that end at or before `need`, then the one holding it
                         wait(ch.pop(0))

@@ -88,6 +88,44 @@ def sisa_request(shards=5, k=32, epochs=50, parallel=1, delper=2.0, data=None, r
     return out
 
 
+def full_request(k=32, epochs=50, data=None, reps=4, workload='ml1m'):
+    """Wall time of the full-MF stage as a request (config.py:182-188 runFull: Scratch.train on the whole training set, verbose 0, the
+    run whose user_mat0.npy every `--group N` run clusters): its layout, the model init, the epochs' shuffles (on the device:
+    rng.epoch_tags_device), `epochs` epochs, the per-epoch test series.  Median of the repetitions after the first, every one a new
+    request (freshly made loaders: the layout is built and uploaded inside the timed call)."""
+    from ultrare_amd import engine, synth
+    from ultrare_amd.method.scratch import Scratch
+    from ultrare_amd.read import RatingData, loadData
+
+    data = data or synth.make_dataset(**(synth.ML1M if workload == 'ml1m' else synth.ML25M))
+
+    class P:
+        lam, seed, batch, lr, lr_decay, momentum = 0.1, 42, 30000, 0.001, 0.95, 0.9
+    P.k, P.epochs, P.n_user, P.n_item = k, epochs, data['n_user'], data['n_item']
+    te = loadData(RatingData(np.vstack(data['test'])), P.batch, 24, False)
+    ts, model, sc = [], None, None
+    for rep in range(reps):
+        tr = loadData(RatingData(np.vstack(data['train'])), P.batch, 24, True)
+        sc = Scratch(P, 'mf')
+        torch.manual_seed(42)
+        torch.cuda.synchronize()
+        built0 = engine.ShardData.built
+        t0 = time.perf_counter()
+        model = sc.train(tr, te, [], 0, '')
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if rep > 0 or reps == 1:
+            ts.append(t1 - t0)
+        built = engine.ShardData.built - built0
+    n = int(len(data['train'][0]))
+    t = float(np.median(ts))
+    return {'workload': f'full MF (runFull), {n} train rows, k={k}, {epochs} epochs, verbose 0', 'wall_s': round(t, 4), 'wall_s_all': [round(x, 4) for x in ts],
+            'timed': 'median of the repetitions after the first; every one a new request', 'layouts_built_in_timed_call': built,
+            'interactions_per_s': round(n * epochs / t, 1), 'batch_tags': 'device' if __import__('ultrare_amd.rng', fromlist=['rng']).device_tags_wanted() else 'host',
+            'last_epoch': {key: float(v[-1]) for key, v in sc.log.items() if key != 'time' and len(v)},
+            'finite_tables': bool(torch.isfinite(model.user_mat.weight).all() and torch.isfinite(model.item_mat.weight).all())}
+
+
 def cold_request(shards=5, k=32, epochs=50, data=None):
     """-> dict: phases of a cold learn request and of a cold unlearn request (a fresh 2 % deletion set), after one
     warm-up request that loads the library and warms the device allocator and the pinned pool.  Nothing of a request's

@@ -46,7 +46,14 @@ def prepare_shard(train_loader, n_user, n_item, k, epochs, has_total, given_mode
     # the permutations go to the device as batch tags (rng.epoch_tags; struct ure_shard: file_tags): half the bytes, and the device
     # does not partition them (URE_HOST_TAGS=0: as permutations)
     tags = loader.batch_size if os.environ.get('URE_HOST_TAGS', '1') != '0' and 0 < -(-n // max(loader.batch_size, 1)) <= 65535 else 0
-    if loader.shuffle and defer:
+    on_dev = None
+    if loader.shuffle and tags and n < (2 ** 32 - 1) // 20:
+        # ... and they are MADE on the device (rng.epoch_tags_device -> csrc/perm_chain.hip / perm_tags.hip): no sequential Fisher-Yates per
+        # epoch on the host in front of the device's epochs (22.5 M rows per epoch for config.py:182-188's run at the 25 M shape)
+        on_dev = rng.epoch_tags_device(seeds, n, tags, engine._device())
+    if on_dev is not None:
+        perms = on_dev
+    elif loader.shuffle and defer:
         perms = rng.epoch_perms_async(seeds, n, threads=PERM_THREADS, pooled=True, device=engine._device(), tags_batch=tags)
     elif loader.shuffle and tags and n < (2 ** 32 - 1) // 20:
         perms = rng.epoch_tags(seeds, n, tags, threads=PERM_THREADS)

@@ -450,6 +450,21 @@ def epoch_tags(seeds, n, batch, threads=0):
     return out
 
 
+def epoch_tags_device(seeds, n, batch, device, bounds=None, method=None):
+    """epoch_tags made on the device (device_tags: no host shuffle, no upload) for ONE shard -- Scratch.train's path (config.py:182-188's
+    full-MF run: 896,914 rows per epoch at ml-1m, 22.5 M at the 25 M shape).  -> the [len(seeds), n] int16 tensor on `device`, arriving in
+    chunks of epochs TrainJob.run waits for; None when the device path does not apply (URE_DEVICE_TAGS=0, no device, too many rows or steps)."""
+    n, batch = int(n), int(batch)
+    if (device is None or torch.device(device).type != 'cuda' or not device_tags_wanted() or n < 1 or n > DEVICE_TAGS_MAX_ROWS
+            or batch < 1 or -(-n // batch) > 65535 or len(seeds) == 0):
+        return None
+    t = _task_of(dict(start_state=None, n_user=0, n_item=0, k=0, epochs=len(seeds), with_total_test=True, n_rows=n, shuffle=True,
+                      device=torch.device(device), tags_batch=batch, seeds=list(seeds)), buffers=False)
+    if not device_tags([t], bounds=bounds, method=method):
+        return None
+    return t.perms_value
+
+
 def epoch_perms_async(seeds, n, threads=0, pooled=False, device=None, tags_batch=0):
     """epoch_perms on a background thread (tags_batch = B > 0: the batch tags of those permutations instead, int16: epoch_tags): returns a future whose result() is the tensor.  The seeds
     are already drawn, so expanding them needs nothing from torch's generator and overlaps with the
@@ -766,25 +781,66 @@ def make_buffers_together(tasks):
 
 
 PERM_DTYPE = np.dtype([('seed', '<i8'), ('tags', '<u8'), ('n', '<i4'), ('batch', '<i4')])        # struct ure_perm
-DEVICE_TAGS_MAX_ROWS = 1 << 20
+DEVICE_TAGS_MAX_ROWS = 1 << 27      # csrc/perm_chain.hip: 8,192 ranges of 16,384 targets (csrc/perm_tags.hip alone stopped at 2^20)
+RESERVATIONS_MAX_ROWS = 1 << 20     # csrc/perm_tags.hip: a swap's index shares a 32-bit reservation word with the round counter
 DEVICE_TAGS_GROUPS = 256            # workgroups (= permutations at a time) per launch: 32 / 64 / 128 / 256 -> 13.4 / 11.2 / 9.8 / 9.7 ms per 5-shard request, 18.4 / 14.8 / 12.8 / 12.3 at 16 shards
+# Which of the two device shuffles makes a chunk (URE_SHUFFLE=chain / reservations overrides; profiles/r05/exp_shuffle.json):
+#   perm_chain.hip -- many workgroups per permutation, six launches -- has the latency (5 x 180 k rows 0.31 ms against 0.59, one 897 k-row
+#   epoch 0.88 against 3.41), the big shards (50 x 897 k rows 1.98 ms against 4.41; beyond 2^20 rows it is the only one) and, from
+#   ~130 k rows per shard, the throughput too (250 x 180 k rows 1.37 ms against 1.63);
+#   perm_tags.hip -- one workgroup per permutation, one launch -- keeps the many small ones (800 x 56 k rows 1.28 ms against 1.48).
+CHAIN_MIN_ROWS = 1 << 17            # shards beyond this: chain for every chunk
+CHAIN_MAX_PERMS = 128               # smaller shards: chain for chunks of up to this many permutations (the first ones of a request)
 _PERM_STREAMS = {}
 
 
 def device_tags_wanted():
-    """URE_DEVICE_TAGS=0 keeps the host's expansion threads (the path of shards of more than 2^20 rows in any case)."""
+    """URE_DEVICE_TAGS=0 keeps the host's expansion threads."""
     import os
     return os.environ.get('URE_DEVICE_TAGS', '1') != '0'
 
 
-def device_tags(tasks, bounds=None, defer=False):
-    """The batch tags of a call's shards made on the DEVICE (ure_device_randperm_tags: csrc/perm_tags.hip) instead of by host threads:
-    the seeds come by skip-ahead (_DrawsTask.seeds_first), every (shard, epoch) is one entry of ONE descriptor table, and the epochs go
-    out in a few launches on a side stream -- chunk c of all shards together --, each with the event TrainJob.run waits for before
-    the launches that read it.  No host buffer, no upload, no expansion threads.  -> False when a shard cannot take this path (too
-    many rows, no tags, tables too small to skip ahead): the caller falls back to the host path for the whole call.
-    bounds: the chunks' epoch boundaries [0, ..., epochs] instead of ~DEVICE_TAGS_GROUPS permutations per launch.  defer: nothing is
-    launched here; -> fire(c), which launches chunk c (in order) -- bench.py puts the shuffles of the epochs it times inside its clock."""
+def shuffle_method(n_max, n_perms, method=None):
+    """-> 'chain' (csrc/perm_chain.hip) or 'reservations' (csrc/perm_tags.hip) for a launch of n_perms permutations of up to n_max rows."""
+    import os
+    method = method or os.environ.get('URE_SHUFFLE', 'auto')
+    if n_max > RESERVATIONS_MAX_ROWS or method == 'chain':
+        return 'chain'
+    if method == 'reservations':
+        return 'reservations'
+    return 'chain' if (n_max > CHAIN_MIN_ROWS or n_perms <= CHAIN_MAX_PERMS) else 'reservations'
+
+
+def default_tag_bounds(epochs, n_shards, n_max):
+    """The chunks of epochs a call's shuffles are launched in (the same for every shard; TrainJob.run waits for a chunk right before the
+    launches that read it).  Small shards: the first epochs in two small chunks -- the chain shuffle makes them in ~0.4 ms, training can
+    start --, the rest about DEVICE_TAGS_GROUPS permutations per launch (a workgroup each).  Big shards (chain throughout): about eight
+    permutations per launch, a launch per epoch beyond 4 M rows -- a chunk of those keeps up with the epochs that consume it."""
+    S = max(1, n_shards)
+    if n_max > (1 << 18):
+        per = 1 if n_max > (4 << 20) else max(1, (8 if n_max >= (1 << 19) else 32) // S)
+        return list(range(0, epochs, per)) + [epochs]
+    bounds, at = [0], 0
+    for perms in (16, 48):
+        if at < epochs:
+            at = min(epochs, at + max(1, perms // S))
+            bounds.append(at)
+    per = max(2, DEVICE_TAGS_GROUPS // S)
+    while at < epochs:
+        at = min(epochs, at + per)
+        bounds.append(at)
+    return bounds
+
+
+def device_tags(tasks, bounds=None, defer=False, method=None):
+    """The batch tags of a call's shards made on the DEVICE instead of by host threads: the seeds come by skip-ahead
+    (_DrawsTask.seeds_first), every (shard, epoch) is one entry of ONE descriptor table, and the epochs go out in a few launches on two
+    side streams -- chunk c of all shards together, by ure_device_shuffle_tags (csrc/perm_chain.hip) or ure_device_randperm_tags
+    (csrc/perm_tags.hip), whichever suits the chunk (shuffle_method) --, each with the event TrainJob.run waits for before the launches
+    that read it.  No host buffer, no upload, no expansion threads.  -> False when a shard cannot take this path (no tags, more than 2^27
+    rows, tables too small to skip ahead): the caller falls back to the host path for the whole call.
+    bounds: the chunks' epoch boundaries [0, ..., epochs] instead of default_tag_bounds.  defer: nothing is launched here; -> fire(c),
+    which launches chunk c (in order) -- bench.py puts the shuffles of the epochs it times inside its clock."""
     from . import _native as nv
     from .engine import upload_many
     plans = [t._buffer_plan() for t in tasks]
@@ -803,15 +859,13 @@ def device_tags(tasks, bounds=None, defer=False):
         at += al(e * n_rows)
     main = torch.cuda.current_stream(dev)
     dev_all = torch.empty(at, dtype=torch.int16, device=dev)
-    # chunks of epochs, the same for every shard: about DEVICE_TAGS_GROUPS permutations per launch (a workgroup each)
-    max_groups = DEVICE_TAGS_GROUPS
+    S = len(tasks)
+    n_max = max(p[2] for p in plans)
     if bounds is None:
-        per = max(2, min(epochs, max_groups // max(1, len(tasks))))
-        bounds = list(range(0, epochs, per)) + [epochs]
+        bounds = default_tag_bounds(epochs, S, n_max)
     bounds = [int(b) for b in bounds]
     assert bounds[0] == 0 and bounds[-1] == epochs and all(a < b for a, b in zip(bounds[:-1], bounds[1:]))
     # the table in launch order -- (chunk, shard, epoch) --, built shard by epoch and reordered once
-    S = len(tasks)
     n_of = np.array([p[2] for p in plans], dtype=np.int64)
     full = np.zeros((S, epochs), dtype=PERM_DTYPE)
     full['seed'] = np.array([t.seeds for t in tasks], dtype=np.uint64).astype(np.int64)
@@ -820,36 +874,60 @@ def device_tags(tasks, bounds=None, defer=False):
     full['batch'] = np.array([t.tags_batch for t in tasks], dtype=np.int64)[:, None]
     table = np.concatenate([full[:, c0:c1].reshape(-1) for c0, c1 in zip(bounds[:-1], bounds[1:])])
     launches, at_row = [], 0
-    for c0, c1 in zip(bounds[:-1], bounds[1:]):
-        launches.append((c1, at_row, at_row + S * (c1 - c0)))
-        at_row += S * (c1 - c0)
-    n_max = max(p[2] for p in plans)
-    groups = min(max_groups, max(hi - lo for _, lo, hi in launches))
+    for c, (c0, c1) in enumerate(zip(bounds[:-1], bounds[1:])):
+        n_p = S * (c1 - c0)
+        launches.append((c1, at_row, at_row + n_p, shuffle_method(n_max, n_p, method), c & 1))      # (chunks alternate between the two side streams)
+        at_row += n_p
     L = nv.lib()
-    words = int(L.ure_device_randperm_tags_scratch(n_max, groups))
-    scratch = torch.empty(words, dtype=torch.int32, device=dev)
-    n_al = (n_max + 63) // 64 * 64
-    flags = scratch[2 * n_al * groups:2 * n_al * groups + groups]      # a word per workgroup: 0xdead if it ever gave up (device_tags_check)
-    flags.zero_()
+    sides = _PERM_STREAMS.get(str(dev))
+    if sides is None:
+        sides = _PERM_STREAMS[str(dev)] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+    # scratch per (side stream, method): the launches of a stream follow each other, so they share it
+    scratch, flags, keep = {}, [], [dev_all]
+    for _, lo, hi, how, side in launches:
+        if how == 'chain':
+            want = (int(L.ure_device_shuffle_tags_scratch(n_max, hi - lo)), hi - lo)
+        else:
+            groups = min(DEVICE_TAGS_GROUPS, hi - lo)
+            want = (int(L.ure_device_randperm_tags_scratch(n_max, groups)), groups)
+        have = scratch.get((side, how))
+        if have is None or want[1] > have[1]:
+            scratch[(side, how)] = want
+    n_al = al(n_max)
+    for (side, how), (words, n_p) in list(scratch.items()):
+        block = torch.empty(words, dtype=torch.int32, device=dev)
+        if how == 'chain':
+            flag_at = int(L.ure_device_shuffle_tags_flag(n_max, n_p))
+            f = block[flag_at:flag_at + 1]
+        else:
+            f = block[2 * n_al * n_p:2 * n_al * n_p + n_p]           # a word per workgroup: 0xdead if it ever gave up (device_tags_check)
+        f.zero_()
+        flags.append(f)
+        keep.append(block)
+        scratch[(side, how)] = (block, words, n_p)
     table_dev = upload_many([table.view(np.uint8)], dev)[0]
-    side = _PERM_STREAMS.get(str(dev))
-    if side is None:
-        side = _PERM_STREAMS[str(dev)] = torch.cuda.Stream(dev)
-    # (the three blocks are made on the caller's stream and worked on by the side stream: the allocator must not hand them to anybody
-    # else before the side stream is through with them, whatever becomes of the request -- ADVICE r4)
-    for block in (scratch, dev_all, table_dev):
-        block.record_stream(side)
+    keep.append(table_dev)
+    # (the blocks are made on the caller's stream and worked on by the side streams: the allocator must not hand them to anybody
+    # else before the side streams are through with them, whatever becomes of the request -- ADVICE r4)
+    for block in keep:
+        for side in sides:
+            block.record_stream(side)
     ready = torch.cuda.Event()
     ready.record(main)
-    side.wait_event(ready)
-    chunks = [(c1, threading.Event(), [None]) for c1, _, _ in launches]    # (the same for every shard: a launch holds chunk c of all of them)
+    for side in sides:
+        side.wait_event(ready)
+    chunks = [(c1, threading.Event(), [None]) for c1, *_ in launches]    # (the same for every shard: a launch holds chunk c of all of them)
 
     def fire(c):
-        c1, lo, hi = launches[c]
-        nv.check(L.ure_device_randperm_tags(table_dev.data_ptr() + lo * PERM_DTYPE.itemsize, hi - lo, n_max, scratch.data_ptr(), words, groups,
-                                            side.cuda_stream), 'ure_device_randperm_tags')
+        c1, lo, hi, how, side = launches[c]
+        block, words, n_p = scratch[(side, how)]
+        ptr = table_dev.data_ptr() + lo * PERM_DTYPE.itemsize
+        if how == 'chain':
+            nv.check(L.ure_device_shuffle_tags(ptr, hi - lo, n_max, block.data_ptr(), words, 0, sides[side].cuda_stream), 'ure_device_shuffle_tags')
+        else:
+            nv.check(L.ure_device_randperm_tags(ptr, hi - lo, n_max, block.data_ptr(), words, n_p, sides[side].cuda_stream), 'ure_device_randperm_tags')
         ev = torch.cuda.Event()
-        ev.record(side)
+        ev.record(sides[side])
         chunks[c][2][0] = ev
         chunks[c][1].set()
     if not defer:
@@ -859,25 +937,26 @@ def device_tags(tasks, bounds=None, defer=False):
         on_dev = dev_all[o:o + e * n_rows].view(e, n_rows)
         t.host, t.on_dev, t.ready = None, on_dev, ready
         on_dev._ure_host, on_dev._ure_shared = None, None
-        on_dev._ure_keep = (scratch, table_dev, dev_all)          # (alive as long as the tags are: the side stream works on them)
+        on_dev._ure_keep = tuple(keep)                            # (alive as long as the tags are: the side streams work on them)
         on_dev._ure_flags = flags
         on_dev._ure_chunks = list(chunks)
+        on_dev._ure_methods = [how for *_, how, _ in launches]
         t.perms_value = on_dev
     return fire if defer else True
 
 
 def device_tags_check(perms):
-    """After the request's device work is done (the caller has synchronised): did a workgroup of perm_tags_kernel give up?  It cannot -- the
-    oldest pending swap is carried out in every round -- but tags that were not made must not train silently.  perms: the tag tensors of
-    the call's shards (one shared flag array; read once)."""
+    """After the request's device work is done (the caller has synchronised): did a workgroup of perm_tags_kernel give up, did the resolve
+    pass of perm_chain.hip meet a link it cannot follow?  Neither can happen -- and their tags match no batch, so nothing trained on them --,
+    but tags that were not made must not go unnoticed.  perms: the tag tensors of the call's shards (shared flag words; read once)."""
     seen = set()
     for p in perms:
-        f = getattr(p, '_ure_flags', None)
-        if f is not None and f.data_ptr() not in seen:
-            seen.add(f.data_ptr())
-            if bool(f.ne(0).any()):
-                from ._native import NativeError
-                raise NativeError('ure_device_randperm_tags: a workgroup gave up on a shuffle (URE_DEVICE_TAGS=0 takes the host path)')
+        for f in getattr(p, '_ure_flags', None) or ():
+            if f.data_ptr() not in seen:
+                seen.add(f.data_ptr())
+                if bool(f.ne(0).any()):
+                    from ._native import NativeError
+                    raise NativeError('device shuffle: a permutation was given up (URE_DEVICE_TAGS=0 takes the host path)')
 
 
 def _task_of(sp, buffers=True):
