@@ -215,6 +215,49 @@ def check_ml1m_size_against_reference(ml1m, tmp_path):
             np.testing.assert_allclose(sisa.log[key], g['sisa_log_' + key], rtol=1e-4, err_msg=key)
 
 
+def test_configs1_full_length_50_epochs_vs_oracle(ml1m):
+    """BASELINE configs[1] -- the headline: ml-1m size, 5 shards, d = 32 -- over the reference's full 50 epochs (sisa.py:25-63) through
+    Sisa(parallel), as the CLI runs it, against the oracle on the same stream: every shard's item table and the merged user table to
+    1e-4 relative (north_star's tolerance for learned embeddings), the 250 entries of the train-loss series, the final log0 against the
+    oracle's baseTest on its own models.  (One epoch of this configuration is pinned to the REAL reference by
+    check_ml1m_size_against_reference; the oracle is pinned to the reference over 50 epochs at toy size by tests/test_oracle_golden.py.)"""
+    from ultrare_amd import synth
+    from ultrare_amd.method.sisa import Sisa
+    from ultrare_amd.read import RatingData, loadData
+
+    S, E = 5, 50
+
+    class P:
+        k, lam, seed, batch, lr, lr_decay, momentum, epochs, parallel = 32, 0.1, 42, 30000, 0.001, 0.95, 0.9, E, True
+        n_user, n_item = ml1m['n_user'], ml1m['n_item']
+    shard_of, groups = synth.uniform_shards(P.n_user, S)
+    parts = synth.split_shards(ml1m['train'], shard_of, S)
+    tests = synth.split_shards(ml1m['test'], shard_of, S)
+    total = O.hstack(tests)
+    trd = [loadData(RatingData(np.vstack(p)), P.batch, 24) for p in parts]
+    ted = [loadData(RatingData(np.vstack(p)), P.batch, 24, False) for p in tests]
+    tot = loadData(RatingData(np.vstack(total)), P.batch, 24, False)
+    sisa = Sisa(P, 'mf', S, groups)
+    torch.manual_seed(42)
+    ml = sisa.learn(trd, ted, tot, 0, '')
+    h = O.Hyper(k=P.k, batch=P.batch, epochs=E)
+    torch.manual_seed(42)
+    ref = O.sisa_learn(h, P.n_user, P.n_item, groups, parts, tests, total, with_eval=False)
+    worst = 0.0
+    for i in range(S):
+        worst = max(worst, rel(ml[i].item_mat.weight, ref['models'][i][1]))
+    worst = max(worst, rel(ml[0].user_mat.weight, ref['merged']))
+    assert worst < 1e-4, worst
+    want_loss = np.concatenate([ref['logs'][i]['train_loss'] for i in range(S)])
+    assert np.isfinite(want_loss).all() and len(sisa.log['train_loss']) == S * E
+    np.testing.assert_allclose(sisa.log['train_loss'], want_loss, rtol=1e-4)
+    np.testing.assert_allclose([sisa.log0['total_rmse'], sisa.log0['total_ndcg'], sisa.log0['total_hr']], ref['log0'], rtol=1e-4)
+    # the per-epoch series the reference logs beside training (scratch.py:83-97): finite, and their last entry of the last shard IS the
+    # final ensemble on the total test set before the merge -- within a few percent of log0 (the merge only swaps user rows between models)
+    for key in ('test_rmse', 'test_ndcg', 'test_hr', 'total_rmse', 'total_ndcg', 'total_hr'):
+        assert len(sisa.log[key]) == S * E and np.isfinite(sisa.log[key]).all(), key
+
+
 def test_configs4_shards_50_epochs_vs_oracle_including_the_ones_that_diverge(ml1m):
     """BASELINE configs[4] (ml-1m, 16 shards, k = 16) over the full 50 epochs.  On the synthetic set two shards hold a
     user with ~2,800 ratings and the reference's summed-loss SGD diverges on them: the engine must follow
