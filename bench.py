@@ -529,7 +529,9 @@ def hbm_leg(a, D):
     r['k16'] = {'workload': 'the same 32 shards at k = 16 (finite tables)', 'value': round(leg16['value'], 1), 'unit_value': 'interactions/s',
                 'avg_launch_us': r16['avg_launch_us'], 'achieved': r16['achieved'], 'frac': r16['frac'], 'alg_bytes_per_launch': r16['alg_bytes_per_launch'],
                 'touch_mode': r16['touch_mode'], 'finite_tables': r16['finite_tables'], 'epochs_run': r16['epochs_run'],
-                'prep_share_of_device_time': round(p16 / max(p16 + s16, 1e-9), 4)}
+                'prep_share_of_device_time': round(p16 / max(p16 + s16, 1e-9), 4),
+                'traffic': r16['traffic'], 'traffic_source': r16['traffic_source'], 'traffic_note': r16['traffic_note'], 'fabric_frac': r16['fabric_frac'],
+                'traffic_over_algorithmic': round(r16['traffic'] / r16['alg_bytes_per_launch'], 3) if r16['traffic'] else None}
     r['full_mf'] = fullmf_leg(a, D, data)
     r.update({'workload': 'BASELINE.json configs[3] shape on one GPU: synthetic 162000x60000, 22500000 train rows, 32-shard SISA '
                           '(uniform grouping), d=128, batch=30000, all shards side by side, touch mode',

@@ -38,6 +38,7 @@ if has pmc; then
   python3 "$ROOT/tools/pmc_traffic.py" "$OUT/pmc" --tag "$TAG" > "$OUT/pmc_ml1m.log" 2>&1; echo "pmc ml1m rc=$?"
   python3 "$ROOT/tools/pmc_traffic.py" "$OUT/pmc" --tag "$TAG" -- --workload ml25m > "$OUT/pmc_ml25m.log" 2>&1; echo "pmc ml25m rc=$?"
   python3 "$ROOT/tools/pmc_traffic.py" "$OUT/pmc" --tag "$TAG" -- --workload ml25m --shards 1 --d 128 --steps 1 --warmup 1 --roofline-steps 1 > "$OUT/pmc_fullmf.log" 2>&1; echo "pmc fullmf touch rc=$?"
+  python3 "$ROOT/tools/pmc_traffic.py" "$OUT/pmc" --tag "$TAG" -- --workload ml25m --d 16 > "$OUT/pmc_ml25m_k16.log" 2>&1; echo "pmc ml25m k16 rc=$?"
   cp "$OUT"/pmc/*_pmc_hbm_traffic_*.json "$OUT"/ 2>/dev/null
   rm -rf "$OUT/pmc" "$OUT/pmc_dense"
 fi

@@ -6,7 +6,11 @@ Same flags, defaults and assertions; additions are optional:
                  (1) trains them side by side (and across ranks when launched with torch.distributed.run, one process per GPU) and
                  rebuilds the per-epoch tests from end-of-epoch snapshots: models, log0 and every log series are bit-identical
                  (tests/test_gpu_surface.py::test_parallel_equals_sequential_bitwise), the same lines are printed -- after the
-                 call instead of during it -- and a 5-shard ml-1m learn takes 12 ms instead of 50
+                 call instead of during it -- and a 5-shard ml-1m learn takes 10 ms instead of 50.  One exception to
+                 "bit-identical": a shard's own test_rmse comes from the total set's predictions (ure_eval_subset) when the shard's test
+                 set is the total set's rows of its users, and is then summed pair by pair in double instead of by float wave partials --
+                 equal to rounding (1e-12 relative), not to the bit, with a run that evaluates the shard's set on its own (another test
+                 set, URE_EVAL_SUBSET=0, snapshots beyond URE_SNAPSHOT_LIMIT_GB); NDCG and HR are the same bits on both routes
   --dataset toy  the small rating set shipped with the reference (data/toy)
   --data-dir / --save-dir   roots of data/ and result/ (default: ./data, ./result)
 """

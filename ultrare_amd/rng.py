@@ -881,7 +881,7 @@ def device_tags(tasks, bounds=None, defer=False, method=None):
     L = nv.lib()
     sides = _PERM_STREAMS.get(str(dev))
     if sides is None:
-        sides = _PERM_STREAMS[str(dev)] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        sides = _PERM_STREAMS[str(dev)] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))      # (stream priorities change nothing here: measured, profiles/r05/NOTES.md)
     # scratch per (side stream, method): the launches of a stream follow each other, so they share it
     scratch, flags, keep = {}, [], [dev_all]
     for _, lo, hi, how, side in launches:
