@@ -57,8 +57,8 @@ def test_shuffle_tags_equal_the_hosts(fill, range_log2):
     L, tab_d, n_tab, n_max, scratch, words = _run(cases, lambda n: 1 if n > 100000 else 3, scratch_fill=fill, range_log2=range_log2)
     # refusals: scratch too small, 2^31 rows
     assert L.ure_device_shuffle_tags(tab_d.data_ptr(), n_tab, n_max, scratch.data_ptr(), 16, 0, None) != 0
-    assert L.ure_device_shuffle_tags(tab_d.data_ptr(), 1, (1 << 27) + 1, scratch.data_ptr(), 1 << 40, 0, None) != 0
-    assert L.ure_device_shuffle_tags(tab_d.data_ptr(), 1, (1 << 25) + 1, scratch.data_ptr(), 1 << 40, 12, None) != 0
+    assert L.ure_device_shuffle_tags(tab_d.data_ptr(), 1, (1 << 28) + 1, scratch.data_ptr(), 1 << 40, 0, None) != 0
+    assert L.ure_device_shuffle_tags(tab_d.data_ptr(), 1, (1 << 26) + 1, scratch.data_ptr(), 1 << 40, 12, None) != 0
     assert L.ure_device_shuffle_tags(tab_d.data_ptr(), n_tab, n_max, scratch.data_ptr(), words, 13, None) != 0
 
 
@@ -69,8 +69,11 @@ def test_shuffle_tags_many_permutations_of_a_request():
     _run(cases, lambda n: 12, seed=11)
 
 
-@pytest.mark.parametrize('n', [4 * 1024 * 1024 + 3, 22_500_000])
-def test_shuffle_tags_beyond_2_to_20_rows(n):
+@pytest.mark.parametrize('sizes', [[4 * 1024 * 1024 + 3], [22_500_000], [3_000_001, 2_200_000, 700_000, 638_977, 5]])
+def test_shuffle_tags_beyond_2_to_20_rows(sizes):
     """config.py:182-188's full-MF run at the 25 M shape shuffles 22.5 M rows per epoch (750 steps of 30,000): the path perm_tags.hip
-    refuses and the host made with one sequential Fisher-Yates per epoch."""
-    _run([(n, 30000)], lambda n: 1, seed=3, range_log2=14 if n < 5_000_000 else 12)
+    refuses and the host made with one sequential Fisher-Yates per epoch.  Beyond 2^21 rows the generator's stream is cut into segments of
+    1,024 blocks whose start blocks come from the device-side jump tree (csrc/mt_jump_dev.h): permutations of several lengths in one
+    launch, one of them a word longer than a segment, one of a few rows."""
+    n = max(sizes)
+    _run([(x, 30000) for x in sizes], lambda n: 1, seed=3, range_log2=14 if n < 5_000_000 and len(sizes) == 1 else 0)

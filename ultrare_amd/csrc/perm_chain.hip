@@ -38,6 +38,7 @@
 // by other waves of the SAME workgroup: workgroup-scope release (fence + barrier) / acquire (fence), as the language defines them -- no
 // assumption about which compute unit a wave is on.
 #include "ure_internal.h"
+#include "mt_jump_dev.h"
 
 namespace ure {
 namespace {
@@ -46,7 +47,8 @@ constexpr int kMtN = 624, kMtLag = 227;
 constexpr int kDrawBlock = 640;                  // ten wavefronts: lanes 0..622 own a word of the step
 constexpr int kDrawWide = 623;                   // words per dependent step
 constexpr int kDrawRing = 8192;                  // the generator's words kept in LDS (a step reads 1,305 back)
-constexpr int kMaxBuckets = 8192;                // per permutation (LDS counters of the draw and bucket passes)
+constexpr int64_t kSegmentedRows = 1 << 21;      // permutations beyond this: the generator's stream in segments (mt_jump_dev.h)
+constexpr int kMaxBuckets = 16384;               // per permutation (LDS counters of the draw and bucket passes)
 constexpr int kTileBlock = 1024;
 constexpr int kTileLoads = 4;                    // 16-byte loads per lane: a tile of the bucket pass is 16,384 swaps
 constexpr int kTile = kTileBlock * 4 * kTileLoads;
@@ -106,25 +108,54 @@ __device__ __forceinline__ unsigned mt_mix(unsigned a, unsigned b)
     return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
 
-// One workgroup per permutation: the generator's raw words, in order, into t[] (the targets pass turns them into targets in place);
-// the words live in a ring of 8,192 in LDS.  Also clears the permutation's bucket counters.
+// The seed blocks of a launch whose permutations are cut into segments (beyond kSegmentedRows rows): segment 0 of every permutation =
+// init_genrand(seed), the other segments zero -- the jump tree (mt_jump_dev.h) adds their start blocks into them.
+__global__ __launch_bounds__(kDrawBlock) void shuffle_seed_kernel(const ure_perm_t *__restrict__ perms, int n_perms, unsigned *__restrict__ states, int J)
+{
+    const int perm = blockIdx.x, tid = threadIdx.x;
+    if (perm >= n_perms) return;
+    unsigned *mine = states + (size_t)perm * J * kMtN;
+    for (int k = kMtN + tid; k < J * kMtN; k += kDrawBlock) mine[k] = 0u;
+    if (tid == 0) {
+        unsigned v = (unsigned)((unsigned long long)perms[perm].seed & 0xffffffffull);
+        mine[0] = v;
+        for (int j = 1; j < kMtN; ++j) {
+            v = 1812433253u * (v ^ (v >> 30)) + (unsigned)j;
+            mine[j] = v;
+        }
+    }
+}
+
+// One workgroup per (permutation, segment): the generator's raw words, in order, into t[] (the targets pass turns them into targets in
+// place); the words live in a ring of 8,192 in LDS.  states == nullptr: ONE segment, from the permutation's seed (at::mt19937(seed):
+// init_genrand; the first draw regenerates); else segment `seg` starts behind the block states[perm][seg].  Segment 0 also clears the
+// permutation's bucket counters.
 __global__ __launch_bounds__(kDrawBlock) void shuffle_words_kernel(const ure_perm_t *__restrict__ perms, int n_perms, unsigned *__restrict__ scratch, int64_t n_al,
-                                                                   int64_t b_al, int range_log2)
+                                                                   int64_t b_al, int range_log2, const unsigned *__restrict__ states, int J)
 {
     constexpr unsigned M = kDrawRing - 1;
     __shared__ unsigned ring[kDrawRing];
     const int tid = threadIdx.x;
-    const int perm = blockIdx.x;
+    const int perm = blockIdx.x / J, seg = blockIdx.x % J;
     if (perm >= n_perms) return;
     const int n = perms[perm].n;
     if (n <= 0) return;
     const perm_view P = view_of(scratch, perm, n_al, b_al);
-    const int n_buckets = (int)((((int64_t)n - 1) >> range_log2) + 1);
-    for (int b = tid; b < n_buckets; b += kDrawBlock) {
-        P.totals[b] = 0u;
-        P.cursors[b] = 0u;
+    if (seg == 0) {
+        const int n_buckets = (int)((((int64_t)n - 1) >> range_log2) + 1);
+        for (int b = tid; b < n_buckets; b += kDrawBlock) {
+            P.totals[b] = 0u;
+            P.cursors[b] = 0u;
+        }
     }
-    if (tid == 0) {                                             // (at::mt19937(seed): init_genrand; the first draw regenerates)
+    const int64_t w_lo = (int64_t)seg * jmp::kSegWords;
+    const int64_t total_all = (int64_t)n - 1;
+    if (w_lo >= total_all) return;
+    const int total = (int)min<int64_t>(states ? jmp::kSegWords : total_all, total_all - w_lo);       // this segment's words
+    if (states) {
+        const unsigned *blk = states + ((size_t)perm * J + seg) * kMtN;
+        for (int k = tid; k < kMtN; k += kDrawBlock) ring[((unsigned)k - kMtN) & M] = blk[k];
+    } else if (tid == 0) {
         unsigned v = (unsigned)((unsigned long long)perms[perm].seed & 0xffffffffull);
         ring[(0u - kMtN) & M] = v;
         for (int j = 1; j < kMtN; ++j) {
@@ -133,12 +164,12 @@ __global__ __launch_bounds__(kDrawBlock) void shuffle_words_kernel(const ure_per
         }
     }
     __syncthreads();
-    const int total = n - 1;
+    unsigned *out = P.t + w_lo;
 #pragma unroll 1
     for (int g0 = 0; g0 < total; g0 += kDrawWide) {
         const unsigned g = (unsigned)(g0 + tid);
         if (tid < kDrawWide && (int)g < total) {
-            // (all seven reads at once -- one LDS round trip per step; the first 454 words leave the terms they do not have out)
+            // (all seven reads at once -- one LDS round trip per step; the first 454 words behind the start block leave the terms they do not have out)
             const bool two = g >= (unsigned)kMtLag, three = g >= 2u * kMtLag;
             const unsigned a0 = ring[(g - kMtN) & M], a1 = ring[(g - kMtN + 1) & M];
             const unsigned b0 = ring[(g - kMtLag - kMtN) & M], b1 = ring[(g - kMtLag - kMtN + 1) & M];
@@ -146,7 +177,7 @@ __global__ __launch_bounds__(kDrawBlock) void shuffle_words_kernel(const ure_per
             const unsigned x = ring[(g - (three ? 3u * kMtLag : two ? 2u * kMtLag : (unsigned)kMtLag)) & M];
             const unsigned v = x ^ mt_mix(a0, a1) ^ (two ? mt_mix(b0, b1) : 0u) ^ (three ? mt_mix(c0, c1) : 0u);
             ring[g & M] = v;
-            P.t[g] = v;
+            out[g] = v;
         }
         lds_barrier();
     }
@@ -529,7 +560,8 @@ extern "C" int64_t ure_device_shuffle_tags_flag(int64_t n_max, int32_t n_perms)
 extern "C" int64_t ure_device_shuffle_tags_scratch(int64_t n_max, int32_t n_perms)
 {
     if (n_max <= 0 || n_perms <= 0) return 0;
-    return ure_device_shuffle_tags_flag(n_max, n_perms) + 64;
+    const int64_t J = n_max > ure::kSegmentedRows ? (n_max - 1 + ure::jmp::kSegWords - 1) / ure::jmp::kSegWords : 0;
+    return ure_device_shuffle_tags_flag(n_max, n_perms) + 64 + (int64_t)n_perms * J * ure::kMtN;       // (+ the segments' start blocks)
 }
 
 extern "C" int ure_device_shuffle_tags(const ure_perm_t *perms, int32_t n_perms, int64_t n_max, uint32_t *scratch, int64_t scratch_words, int32_t range_log2,
@@ -550,7 +582,20 @@ extern "C" int ure_device_shuffle_tags(const ure_perm_t *perms, int32_t n_perms,
     const int64_t tiles = std::max<int64_t>(1, (n_max - 1 + kTile - 1) / kTile), ranges = ((n_max - 1) >> rl) + 1, rows = (n_max + kResolveRows - 1) / kResolveRows;
     if (8 * slots * std::max(ranges, rows) > 0x7fffffffll)
         return fail(-1, "ure_device_shuffle_tags: %d permutations of up to %lld rows are too many for one launch", (int)n_perms, (long long)n_max);
-    hipLaunchKernelGGL(shuffle_words_kernel, dim3((unsigned)n_perms), dim3(kDrawBlock), 0, st, perms, (int)n_perms, scratch, n_al, b_al, rl);
+    if (n_max > kSegmentedRows) {
+        // millions of rows: the generator's stream in segments of 1,024 blocks, their start blocks by the jump tree -- one workgroup walking
+        // 22.5 M words took 12.5 ms of an 18.5 ms shuffle
+        const int64_t J = (n_max - 1 + jmp::kSegWords - 1) / jmp::kSegWords;
+        uint32_t *states = broken + 64;
+        const uint32_t *levels = nullptr;
+        if (jmp::device_levels(jmp::levels_of(J), st, &levels)) return fail(-1, "ure_device_shuffle_tags: the jump polynomials could not be made / uploaded");
+        hipLaunchKernelGGL(shuffle_seed_kernel, dim3((unsigned)n_perms), dim3(kDrawBlock), 0, st, perms, (int)n_perms, states, (int)J);
+        jmp::launch_tree(states, (int)n_perms, J, levels, st);
+        hipLaunchKernelGGL(shuffle_words_kernel, dim3((unsigned)(n_perms * J)), dim3(kDrawBlock), 0, st, perms, (int)n_perms, scratch, n_al, b_al, rl, states, (int)J);
+    } else {
+        hipLaunchKernelGGL(shuffle_words_kernel, dim3((unsigned)n_perms), dim3(kDrawBlock), 0, st, perms, (int)n_perms, scratch, n_al, b_al, rl,
+                           static_cast<const unsigned *>(nullptr), 1);
+    }
     hipLaunchKernelGGL(shuffle_targets_kernel, dim3((unsigned)(8 * slots * tiles)), dim3(kTileBlock), 0, st, perms, (int)n_perms, (int)tiles, scratch, n_al, b_al, rl);
     hipLaunchKernelGGL(shuffle_bucket_kernel, dim3((unsigned)(8 * slots * tiles)), dim3(kTileBlock), 0, st, perms, (int)n_perms, (int)tiles, scratch, n_al, b_al, rl);
     for (int heavy = 0; heavy < 2; ++heavy) {

@@ -781,7 +781,7 @@ def make_buffers_together(tasks):
 
 
 PERM_DTYPE = np.dtype([('seed', '<i8'), ('tags', '<u8'), ('n', '<i4'), ('batch', '<i4')])        # struct ure_perm
-DEVICE_TAGS_MAX_ROWS = 1 << 27      # csrc/perm_chain.hip: 8,192 ranges of 16,384 targets (csrc/perm_tags.hip alone stopped at 2^20)
+DEVICE_TAGS_MAX_ROWS = 1 << 27      # csrc/perm_chain.hip takes 2^28 (16,384 ranges of 16,384 targets); a row index keeps a bit free here (csrc/perm_tags.hip alone stopped at 2^20)
 RESERVATIONS_MAX_ROWS = 1 << 20     # csrc/perm_tags.hip: a swap's index shares a 32-bit reservation word with the round counter
 DEVICE_TAGS_GROUPS = 256            # workgroups (= permutations at a time) per launch: 32 / 64 / 128 / 256 -> 13.4 / 11.2 / 9.8 / 9.7 ms per 5-shard request, 18.4 / 14.8 / 12.8 / 12.3 at 16 shards
 # Which of the two device shuffles makes a chunk (URE_SHUFFLE=chain / reservations overrides; profiles/r05/exp_shuffle.json):
