@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything profiles/r05/ holds, on the GPU box:  bash tools/collect_profiles_r5.sh [part ...]   (parts: bench stats pmc e2e fullmf cfg4 big multirank; default all)
+# Everything profiles/r05/ holds, on the GPU box:  bash tools/collect_profiles_r5.sh [part ...]   (parts: bench stats pmc e2e fullmf cfg4 big multirank shuffle; default all)
 # Writes gpurun_out/profiles_r05/ ; copy what should be judged into profiles/r05/.
 # rocprofv3 runs the program itself after `--` (python3 <script>), kernel-trace / stats only; the PMC passes are separate
 # runs (tools/pmc_traffic.py), never combined with another tracing domain.
@@ -7,7 +7,7 @@ TAG=r05
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
-PARTS=${*:-bench stats pmc e2e fullmf cfg4 big multirank}
+PARTS=${*:-bench stats pmc e2e fullmf cfg4 big multirank shuffle}
 cd /tmp && export TMPDIR=/tmp
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 stats() {   # name, [VAR=VALUE ...] script, args...
@@ -70,5 +70,13 @@ if has big; then
   timeout -k 10 900 python3 "$ROOT/tools/e2e_sisa.py" --workload ml25m --shards 32 --k 128 --epochs 5 --reps 4 > "$OUT/e2e_sisa_ml25m_s32_k128_e5.json" 2> "$OUT/e2e_sisa_ml25m.err"; echo "e2e ml25m rc=$?"
   # the same at the reference's default width k = 16 (config.py:19), where the arithmetic stays finite
   timeout -k 10 900 python3 "$ROOT/tools/e2e_sisa.py" --workload ml25m --shards 32 --k 16 --epochs 5 --reps 4 > "$OUT/e2e_sisa_ml25m_s32_k16_e5.json" 2>> "$OUT/e2e_sisa_ml25m.err"; echo "e2e ml25m k16 rc=$?"
+fi
+if has shuffle; then
+  # the two device shuffles on the shapes a request makes (csrc/perm_chain.hip against csrc/perm_tags.hip), and the chain's kernels per shape
+  timeout -k 10 300 python3 "$ROOT/tools/exp_shuffle.py" > "$OUT/exp_shuffle.json" 2> /dev/null; echo "exp_shuffle rc=$?"
+  stats exp_shuffle_request "$ROOT/tools/exp_shuffle.py" --only request_5x50x180k --which chain --reps 10
+  stats exp_shuffle_first_epoch "$ROOT/tools/exp_shuffle.py" --only first_epoch_5x180k --which chain --reps 10
+  stats exp_shuffle_22m "$ROOT/tools/exp_shuffle.py" --only one_epoch_22.5M --which chain --reps 10
+  URE_SHUFFLE=reservations timeout -k 10 300 python3 "$ROOT/bench.py" --no-cpu-baseline --no-hbm-leg --no-cold --no-ot > "$OUT/bench_shuffle_reservations.json" 2> /dev/null; echo "bench reservations rc=$?"
 fi
 ls -la "$OUT"
