@@ -813,18 +813,18 @@ def shuffle_method(n_max, n_perms, method=None):
 
 def default_tag_bounds(epochs, n_shards, n_max):
     """The chunks of epochs a call's shuffles are launched in (the same for every shard; TrainJob.run waits for a chunk right before the
-    launches that read it).  Small shards: the first epochs in two small chunks -- the chain shuffle makes them in ~0.4 ms, training can
-    start --, the rest about DEVICE_TAGS_GROUPS permutations per launch (a workgroup each).  Big shards (chain throughout): about eight
+    launches that read it).  Small shards: the first epochs in one small chunk -- the chain shuffle makes it in ~0.4 ms, training can
+    start --, the rest about DEVICE_TAGS_GROUPS permutations per launch (two small chunks first cost a request 0.35 ms more device time for 0.1 ms
+    less waiting).  Big shards (chain throughout): about eight
     permutations per launch, a launch per epoch beyond 4 M rows -- a chunk of those keeps up with the epochs that consume it."""
     S = max(1, n_shards)
     if n_max > (1 << 18):
         per = 1 if n_max > (4 << 20) else max(1, (8 if n_max >= (1 << 19) else 32) // S)
         return list(range(0, epochs, per)) + [epochs]
     bounds, at = [0], 0
-    for perms in (16, 48):
-        if at < epochs:
-            at = min(epochs, at + max(1, perms // S))
-            bounds.append(at)
+    if epochs > 1:                                       # (one small chunk first: ~64 permutations, 0.4-0.5 ms by the chain shuffle)
+        at = min(epochs, max(1, 64 // S))
+        bounds.append(at)
     per = max(2, DEVICE_TAGS_GROUPS // S)
     while at < epochs:
         at = min(epochs, at + per)
