@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void score_own_epochs_kernel(const float *_
 {
     constexpr int D = LPR * 4;
     constexpr int G = kWave / LPR;
-    constexpr int kE = 8;                 // epochs in flight per pair
+    constexpr int kE = 4;                 // epochs in flight per pair (8: 61.6 -> 65.7 us per call, measured r5)
     const int lane = threadIdx.x & 63;
     const int sub = lane & (LPR - 1), grp = lane / LPR;
     const int64_t wave_id = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;

@@ -148,18 +148,13 @@ class Scratch(object):
         times = []
         if series:
             sets = (test_ev, total_ev if has_total else test_ev)
-            # URE_EARLY_SCORES=1: the shard's own half of both series beside training (engine.TrainJob.early_scores; off by default)
-            early = [job.early_scores(0, ev) if os.environ.get('URE_EARLY_SCORES', '0') == '1' else None for ev in sets]
             job.run()
             res = torch.zeros(2, self.epochs, 3, dtype=torch.float64, device=shard.device)
-            if early[0] is None and has_total:
+            if has_total:
                 job.evaluate_series_pair(0, sets[0], sets[1], before, res[0], res[1])
             else:
                 for which, ev in enumerate(sets):
-                    if early[which] is not None:
-                        job.finish_series(early[which], before, res[which])
-                    else:
-                        job.evaluate_series(0, ev, before, res[which])
+                    job.evaluate_series(0, ev, before, res[which])
             res = res.transpose(0, 1).contiguous()
             times = ['00:00:00'] * self.epochs
         for t in range(0 if not series else self.epochs, self.epochs):
