@@ -231,11 +231,11 @@ int ure_device_randperm_tags(const ure_perm_t *perms, int32_t n_perms, int64_t n
                              void *stream);
 /* ABI 9.  The same tags by MANY workgroups per permutation and for up to 2^28 rows (csrc/perm_chain.hip): the shuffle's result in closed
  * form -- the swaps grouped by the position they target, a row's value = the smallest swap that targets it or a short chase along
- * "largest member" links -- in four stream-ordered launches (MT19937 targets + counts per range of 4,096 targets; the swaps bucketed by
+ * "largest member" links -- in six stream-ordered launches (MT19937 words; targets + counts per range of 1,024 targets; the swaps bucketed by
  * range; per (permutation, range) the target lists in LDS; resolve + divide).  No 2^20-row limit (read.py:127-133 for config.py:182-188's
  * full-MF run: 22.5 M rows at the 25 M shape) and a fraction of perm_tags.hip's latency for a request's first epochs.  perms: DEVICE
  * memory, as above; scratch: device memory of ure_device_shuffle_tags_scratch(largest n, n_perms) words (20 bytes per row and permutation
- * of the call), reusable by the next call on the same stream.  range_log2: 0 (the library chooses: 11 up to 2^25 rows, 12 up to 2^26, else 14), 11, 12 or 14.
+ * of the call), reusable by the next call on the same stream.  range_log2: 0 (the library chooses: 10 up to 2^24 rows, 11 up to 2^25, 12 up to 2^26, else 14), 10, 11, 12 or 14.
  * Word ure_device_shuffle_tags_flag(n_max, n_perms) of the scratch is set to 0xdead if the resolve pass met a link it cannot follow (it
  * cannot; such a row gets tag 0xFFFF, which matches no batch; the caller clears the word when it makes the scratch).                  */
 int64_t ure_device_shuffle_tags_scratch(int64_t n_max, int32_t n_perms);

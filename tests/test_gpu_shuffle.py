@@ -46,7 +46,7 @@ def _run(cases, reps_of, seed=7, scratch_fill=0, range_log2=0):
     return L, tab_d, len(tab), n_max, scratch, words
 
 
-@pytest.mark.parametrize('fill,range_log2', [(0, 0), (-1, 0), (0x12345678, 14), (7, 12)])
+@pytest.mark.parametrize('fill,range_log2', [(0, 0), (-1, 11), (0x12345678, 14), (7, 12)])
 def test_shuffle_tags_equal_the_hosts(fill, range_log2):
     """Shards of different sizes in ONE table: 1, 2, 3 rows, around the generator's 624-output block and the eight-block pass (4,992
     outputs), around the 32,768 targets of a link workgroup and the 4,096 rows of a resolve workgroup, the sizes of BASELINE.json's

@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--skip-big', action='store_true')
     ap.add_argument('--only', default='')
+    ap.add_argument('--rl', type=int, default=0, help='range_log2 of ure_device_shuffle_tags (0: the library chooses)')
     ap.add_argument('--which', default='chain,reservations')
     a = ap.parse_args()
     L = nv.lib()
@@ -62,7 +63,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 if which == 'chain':
-                    nv.check(L.ure_device_shuffle_tags(tab.data_ptr(), len(perms), n_max, scratch.data_ptr(), words, 0, nv.stream_handle()), 'shuffle')
+                    nv.check(L.ure_device_shuffle_tags(tab.data_ptr(), len(perms), n_max, scratch.data_ptr(), words, a.rl, nv.stream_handle()), 'shuffle')
                 else:
                     nv.check(L.ure_device_randperm_tags(tab.data_ptr(), len(perms), n_max, scratch.data_ptr(), words, groups, nv.stream_handle()), 'randperm')
                 e1.record()

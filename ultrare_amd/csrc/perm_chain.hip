@@ -21,7 +21,8 @@
 //   shuffle_words_kernel    one workgroup per permutation walks MT19937, 623 new words per barrier (the recurrence substituted into itself
 //                           twice), the raw words into t[].
 //   shuffle_targets_kernel  one workgroup per (permutation, tile of 16,384 swaps): t[j] = j + temper(word) % (n - j) in place, and the
-//                           swaps counted per BUCKET = range of 2,048 targets (4,096 / 16,384 beyond 2^24 / 2^25 rows).
+//                           swaps counted per BUCKET = range of 1,024 targets (2,048 / 4,096 / 16,384 beyond 2^24 / 2^25 / 2^26 rows;
+//                           ranges of 2,048 / 4,096 targets measured 4-12 % / 35 % slower on a request's shapes).
 //   shuffle_bucket_kernel   one workgroup per (permutation, tile of 16,384 swaps): the swaps go to their bucket's stretch of `pairs` as
 //                           (j, t_j) -- the stretch from the prefix of the counts, a tile's place in it from one returning global
 //                           add per bucket it touches, the rest from LDS cursors.  The order inside a bucket is whatever the atomics
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(kResolveBlock) void shuffle_resolve_kernel(const ur
 int range_log2_of(int64_t n_max, int32_t wanted)
 {
     if (wanted) return wanted;
-    return n_max <= ((int64_t)kMaxBuckets << 11) ? 11 : n_max <= ((int64_t)kMaxBuckets << 12) ? 12 : 14;
+    return n_max <= ((int64_t)kMaxBuckets << 10) ? 10 : n_max <= ((int64_t)kMaxBuckets << 11) ? 11 : n_max <= ((int64_t)kMaxBuckets << 12) ? 12 : 14;
 }
 
 int64_t buckets_al(int64_t n_max, int rl) { return (((n_max - 1) >> rl) + 1 + 63) / 64 * 64; }
@@ -554,7 +555,7 @@ extern "C" int64_t ure_device_shuffle_tags_flag(int64_t n_max, int32_t n_perms)
 {
     if (n_max <= 0 || n_perms <= 0) return 0;
     const int64_t n_al = (n_max + 63) / 64 * 64;
-    return ure::words_per_perm(n_al, std::min<int64_t>(ure::kMaxBuckets, ure::buckets_al(n_max, 11))) * (int64_t)n_perms;       // (sized for the finest ranges)
+    return ure::words_per_perm(n_al, std::min<int64_t>(ure::kMaxBuckets, ure::buckets_al(n_max, 10))) * (int64_t)n_perms;       // (sized for the finest ranges)
 }
 
 extern "C" int64_t ure_device_shuffle_tags_scratch(int64_t n_max, int32_t n_perms)
@@ -568,7 +569,7 @@ extern "C" int ure_device_shuffle_tags(const ure_perm_t *perms, int32_t n_perms,
                                        void *stream)
 {
     using namespace ure;
-    URE_ARG(n_perms >= 0 && n_max >= 0 && (range_log2 == 0 || range_log2 == 11 || range_log2 == 12 || range_log2 == 14));
+    URE_ARG(n_perms >= 0 && n_max >= 0 && (range_log2 == 0 || range_log2 == 10 || range_log2 == 11 || range_log2 == 12 || range_log2 == 14));
     if (n_perms == 0 || n_max == 0) return 0;
     URE_ARG(perms && scratch);
     const int rl = range_log2_of(n_max, range_log2);
@@ -600,6 +601,8 @@ extern "C" int ure_device_shuffle_tags(const ure_perm_t *perms, int32_t n_perms,
     hipLaunchKernelGGL(shuffle_bucket_kernel, dim3((unsigned)(8 * slots * tiles)), dim3(kTileBlock), 0, st, perms, (int)n_perms, (int)tiles, scratch, n_al, b_al, rl);
     for (int heavy = 0; heavy < 2; ++heavy) {
         const dim3 grid((unsigned)(8 * slots * ranges)), block(kLinkBlock);
+        if (rl == 10 && !heavy) hipLaunchKernelGGL((shuffle_link_kernel<10, kStage>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
+        if (rl == 10 && heavy) hipLaunchKernelGGL((shuffle_link_kernel<10, kStageHeavy>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
         if (rl == 11 && !heavy) hipLaunchKernelGGL((shuffle_link_kernel<11, kStage>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
         if (rl == 11 && heavy) hipLaunchKernelGGL((shuffle_link_kernel<11, kStageHeavy>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
         if (rl == 12 && !heavy) hipLaunchKernelGGL((shuffle_link_kernel<12, kStage>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
