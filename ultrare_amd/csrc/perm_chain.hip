@@ -55,7 +55,8 @@ constexpr int kTileLoads = 4;                    // 16-byte loads per lane: a ti
 constexpr int kTile = kTileBlock * 4 * kTileLoads;
 constexpr int kLinkBlock = 256;
 constexpr int kLinkLoads = 8;                    // pairs a lane of the link pass has in flight
-constexpr int kStage = 6144;                     // members a link workgroup keeps in LDS (24 KB) ...
+constexpr int kStage = 6144;                     // members a link workgroup keeps in LDS: three per target of its range (24 KB at 2,048 targets) ...
+constexpr int kStage10 = 3072, kStage12 = 12288; // ... 12 KB at 1,024 targets (eight workgroups per CU), 48 KB at 4,096 and beyond
 constexpr int kStageHeavy = 16384;               // ... and one of a permutation's last kHeavyParts buckets (64 KB)
 constexpr int kHeavyParts = 8;
 constexpr int kResolveBlock = 256;
@@ -601,13 +602,13 @@ extern "C" int ure_device_shuffle_tags(const ure_perm_t *perms, int32_t n_perms,
     hipLaunchKernelGGL(shuffle_bucket_kernel, dim3((unsigned)(8 * slots * tiles)), dim3(kTileBlock), 0, st, perms, (int)n_perms, (int)tiles, scratch, n_al, b_al, rl);
     for (int heavy = 0; heavy < 2; ++heavy) {
         const dim3 grid((unsigned)(8 * slots * ranges)), block(kLinkBlock);
-        if (rl == 10 && !heavy) hipLaunchKernelGGL((shuffle_link_kernel<10, kStage>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
+        if (rl == 10 && !heavy) hipLaunchKernelGGL((shuffle_link_kernel<10, kStage10>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
         if (rl == 10 && heavy) hipLaunchKernelGGL((shuffle_link_kernel<10, kStageHeavy>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
         if (rl == 11 && !heavy) hipLaunchKernelGGL((shuffle_link_kernel<11, kStage>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
         if (rl == 11 && heavy) hipLaunchKernelGGL((shuffle_link_kernel<11, kStageHeavy>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
-        if (rl == 12 && !heavy) hipLaunchKernelGGL((shuffle_link_kernel<12, kStage>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
+        if (rl == 12 && !heavy) hipLaunchKernelGGL((shuffle_link_kernel<12, kStage12>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
         if (rl == 12 && heavy) hipLaunchKernelGGL((shuffle_link_kernel<12, kStageHeavy>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
-        if (rl == 14 && !heavy) hipLaunchKernelGGL((shuffle_link_kernel<14, kStage>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
+        if (rl == 14 && !heavy) hipLaunchKernelGGL((shuffle_link_kernel<14, kStage12>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
         if (rl == 14 && heavy) hipLaunchKernelGGL((shuffle_link_kernel<14, kStageHeavy>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
     }
     hipLaunchKernelGGL(shuffle_resolve_kernel, dim3((unsigned)(8 * slots * rows)), dim3(kResolveBlock), 0, st, perms, (int)n_perms, (int)rows, scratch, n_al, b_al, broken);
