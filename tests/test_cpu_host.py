@@ -1101,3 +1101,31 @@ def test_shard_streams_memo_returns_the_walked_states():
         torch.manual_seed(42)
         got = rng.shard_streams(3, n_user, n_item, k, epochs, total, want_seeds=True)[2]
         assert got == sequential(n_user, n_item, k, epochs, 4 if total else 3), (n_user, n_item, epochs, total)
+
+
+def test_layouts_built_on_a_native_thread_equal_the_blocking_call():
+    """ure_host_build_layouts_units_start / _wait (the request path: engine.LayoutPlan starts the builder on a thread of the library's own)
+    against ure_host_build_layouts_units: the same regions, counts and units; an id out of range comes back through _wait with the
+    blocking call's code; a handle is good for one wait."""
+    from ultrare_amd import _native as nv
+    rs = np.random.RandomState(3)
+    n_user, n_item, d = 300, 200, 32
+    triples = []
+    for n in (5000, 1, 777):
+        triples.append((rs.randint(0, n_user, n).astype(np.int64), rs.randint(0, n_item, n).astype(np.int64), rs.randint(1, 6, n) / 5.0))
+    words = [nv.layout_region_words(len(t[0]), n_user, n_item) + nv.units_capacity_words(len(t[0]), n_user, n_item, d) for t in triples]
+    a = [np.zeros(w, dtype=np.int32) for w in words]
+    b = [np.zeros(w, dtype=np.int32) for w in words]
+    want = nv.build_layouts(triples, n_user, n_item, a, threads=2, units_d=d)
+    job = nv.build_layouts_start(triples, n_user, n_item, b, threads=2, units_d=d)
+    got = job.result()
+    assert all(np.array_equal(x, y) for x, y in zip(want, got))
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert job.result() is got                      # (joined once; the counts stay)
+    bad = [(np.array([0, n_user], dtype=np.int64), np.array([0, 0], dtype=np.int64), np.array([0.2, 0.4]))]
+    region = [np.zeros(nv.layout_region_words(2, n_user, n_item) + nv.units_capacity_words(2, n_user, n_item, d), dtype=np.int32)]
+    job = nv.build_layouts_start(bad, n_user, n_item, region, threads=1, units_d=d)
+    with pytest.raises(nv.NativeError) as e:
+        job.result()
+    assert e.value.code == -2
+    assert nv.lib().ure_host_build_layouts_units_wait(12345678) != 0

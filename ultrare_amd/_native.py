@@ -87,6 +87,9 @@ _PROTOTYPES = {
                                               ctypes.POINTER(_vp), _vp, _vp, ctypes.c_int]),
     'ure_host_build_layouts_units': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i32, _i32,
                                                     ctypes.POINTER(_vp), _vp, _vp, _vp, _i32, _vp, ctypes.c_int]),
+    'ure_host_build_layouts_units_start': (_i64, [ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i32, _i32,
+                                                  ctypes.POINTER(_vp), _vp, _vp, _vp, _i32, _vp, ctypes.c_int]),
+    'ure_host_build_layouts_units_wait': (ctypes.c_int, [_i64]),
     'ure_host_build_units': (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _i64, ctypes.POINTER(_i64)]),
     'ure_score': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_int, _vp, _vp, _vp, _i64, ctypes.c_int, _vp, _vp, _vp]),
@@ -282,6 +285,54 @@ def build_layouts(triples, n_user, n_item, regions, threads=0, units_d=0):
     check(lib().ure_host_build_layouts(S, col(0, np.int64), col(1, np.int64), col(2, np.float64), n.ctypes.data, n_user, n_item, reg,
                                        n_slots.ctypes.data, n_active.ctypes.data, int(threads)), 'ure_host_build_layouts')
     return n_slots, n_active
+
+
+class LayoutBuild:
+    """ure_host_build_layouts_units under way on a thread of the library (build_layouts_start); result() joins it.  Holds every array the
+    native thread reads and writes; an object that is dropped without result() joins the thread first."""
+
+    def __init__(self, handle, keep, outs):
+        self.handle, self.keep, self.outs = handle, keep, outs
+
+    def result(self):
+        if self.handle:
+            h, self.handle = self.handle, 0
+            check(lib().ure_host_build_layouts_units_wait(h), 'ure_host_build_layouts_units')
+        return self.outs
+
+    def __del__(self):
+        try:
+            if self.handle:
+                h, self.handle = self.handle, 0
+                lib().ure_host_build_layouts_units_wait(h)
+        except Exception:
+            pass
+
+
+def build_layouts_start(triples, n_user, n_item, regions, threads=0, units_d=0):
+    """build_layouts(units_d > 0) started on a native thread by THIS call (no Python worker has to be woken first) -> LayoutBuild."""
+    S = len(triples)
+    keep = []
+    def col(c, dt):
+        arr = [np.ascontiguousarray(t[c], dtype=dt) for t in triples]
+        keep.append(arr)
+        ptrs = (_vp * S)(*[a.ctypes.data for a in arr])
+        keep.append(ptrs)
+        return ptrs
+    n = np.array([len(t[0]) for t in triples], dtype=np.int64)
+    for t, r in zip(triples, regions):
+        assert len(t[0]) == len(t[1]) == len(t[2]) and r.dtype == np.int32 and r.flags['C_CONTIGUOUS']
+        assert len(r) >= layout_region_words(len(t[0]), n_user, n_item)
+    reg = (_vp * S)(*[r.ctypes.data for r in regions])
+    words = np.array([len(r) for r in regions], dtype=np.int64)
+    n_slots, n_active, n_units = np.zeros(S, dtype=np.int64), np.zeros(S, dtype=np.int32), np.zeros(S, dtype=np.int64)
+    keep += [n, reg, words, list(regions), n_slots, n_active, n_units]
+    handle = lib().ure_host_build_layouts_units_start(S, col(0, np.int64), col(1, np.int64), col(2, np.float64), n.ctypes.data, n_user, n_item, reg,
+                                                      words.ctypes.data, n_slots.ctypes.data, n_active.ctypes.data, int(units_d), n_units.ctypes.data,
+                                                      int(threads))
+    if not handle:
+        raise NativeError('ure_host_build_layouts_units_start: ' + lib().ure_last_error().decode(errors='replace'))
+    return LayoutBuild(handle, keep, (n_slots, n_active, n_units))
 
 
 def layout_capacity(n, n_user, n_item):

@@ -167,6 +167,18 @@ class LayoutPlan:
                          (nv.units_capacity_words(len(c[0]), self.n_user, self.n_item, self.d_units) if self.d_units else 0)) for c in cols]
         self.off = np.concatenate([[0], np.cumsum(self.words)]).astype(np.int64)
         self.stage = rng.STAGING.take((int(self.off[-1]),), torch.int32)
+        # the native builder starts HERE, on a thread of the library's own (a Python worker took 0.3-0.4 ms to get going while the calling
+        # thread held the interpreter); build() joins it
+        self._async = None
+        if self.d_units:
+            host = self.stage.numpy()
+            mark('layouts native start')
+            try:
+                self._async = nv.build_layouts_start(cols, self.n_user, self.n_item, [host[self.off[s]:self.off[s + 1]] for s in range(len(cols))],
+                                                     threads=min(len(cols), rng.host_cpus()), units_d=self.d_units)
+            except BaseException:
+                rng.STAGING.give(self.stage, None)
+                raise
         self._owner = __import__('threading').current_thread()
         self._allocated = __import__('threading').Event()
         self._alloc_error = None
@@ -204,8 +216,12 @@ class LayoutPlan:
         handed_back = False
         try:
             try:
-                mark('w: layouts native start')
-                built = nv.build_layouts(cols, n_user, n_item, [host[off[s]:off[s + 1]] for s in range(S)], threads=min(S, rng.host_cpus()), units_d=d_units)
+                if self._async is not None:
+                    built = self._async.result()
+                    self._async = None
+                else:
+                    mark('w: layouts native start')
+                    built = nv.build_layouts(cols, n_user, n_item, [host[off[s]:off[s + 1]] for s in range(S)], threads=min(S, rng.host_cpus()), units_d=d_units)
             except nv.NativeError as e:
                 if getattr(e, 'code', None) == -2:             # (-3: a shard beyond 2^31 slots -- reported as it is)
                     raise ValueError(f'user or item id outside [0, n_user) x [0, n_item): {e}') from None

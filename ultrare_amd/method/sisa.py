@@ -70,10 +70,15 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
             finish.allocate()                                #  ... and the device allocations are made beside it)
         engine.mark('layouts planned')
         return fut, finish.allocate
+    # the layouts first: their native builder runs on a thread of the library's own from this call on (engine.LayoutPlan), the worker below
+    # only joins it and queues the copy
+    allocate_layouts = None
+    if on_device:
+        layouts, allocate_layouts = start_layouts(allocate=False)
     streams = rng.shard_streams(len(ids), n_user, n_item, k, epochs, True, want_seeds=True) if on_device else None
     engine.mark('streams')
     if on_device and streams is None:
-        layouts = start_layouts()[0]
+        allocate_layouts()
     if streams is not None:
         # every shard's start state by skip-ahead; then, in the order of what the job waits for longest: the owned shards' model inits
         # (a worker each, started at once: rng.start_inits), the layouts (one native call on a worker, the device allocations beside
@@ -97,19 +102,16 @@ def prepare_owned(ids, owner, rank, train_dlist, n_user, n_item, k, epochs, on_d
                 order.append(i)
         tasks = rng.start_inits(specs)
         engine.mark('inits started')
-        # the layouts' native builder goes first (a worker); then the epochs' batch tags are put on their way (rng.draws_batch_async: made on
-        # the device from the seeds, or by host workers); the layouts' device allocations -- which the builder's worker needs only when it
-        # is done -- come last
-        layouts, allocate_layouts = start_layouts(allocate=False)
+        # (the layouts' builder is running); the epochs' batch tags are put on their way (rng.draws_batch_async: made on the device from the
+        # seeds, or by host workers); the layouts' device allocations -- which the builder's worker needs only when it is done -- come last
         # few workers, several shards each (rng.draws_batch_async): the expansion threads of a worker's native calls share
         # the rank's CPUs
         W = max(1, min(len(specs), max(2, rng.host_cpus() // 2)))
         for sp in specs:
             sp['threads'] = max(2, PERM_THREADS // W)
-        try:
-            futures = dict(zip(order, rng.draws_batch_async(specs, W, tasks=tasks)))
-        finally:
-            allocate_layouts()                           # (whatever happened: the builder's worker waits for it)
+        allocate_layouts()                               # (the builder's worker queues the layouts' copy as soon as both are done)
+        engine.mark('layouts allocated')
+        futures = dict(zip(order, rng.draws_batch_async(specs, W, tasks=tasks)))
         engine.mark('draws submitted')
         shards = dict(zip(own_ids, layouts.result()))
         engine.mark('layouts')

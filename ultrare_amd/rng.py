@@ -857,6 +857,8 @@ def device_tags(tasks, bounds=None, defer=False, method=None):
     for _, e, n_rows in plans:
         offs.append(at)
         at += al(e * n_rows)
+    from .engine import mark
+    mark('tags: start')
     main = torch.cuda.current_stream(dev)
     dev_all = torch.empty(at, dtype=torch.int16, device=dev)
     S = len(tasks)
@@ -878,6 +880,7 @@ def device_tags(tasks, bounds=None, defer=False, method=None):
         n_p = S * (c1 - c0)
         launches.append((c1, at_row, at_row + n_p, shuffle_method(n_max, n_p, method), c & 1))      # (chunks alternate between the two side streams)
         at_row += n_p
+    mark('tags: table')
     L = nv.lib()
     sides = _PERM_STREAMS.get(str(dev))
     if sides is None:
@@ -905,6 +908,7 @@ def device_tags(tasks, bounds=None, defer=False, method=None):
         flags.append(f)
         keep.append(block)
         scratch[(side, how)] = (block, words, n_p)
+    mark('tags: scratch')
     table_dev = upload_many([table.view(np.uint8)], dev)[0]
     keep.append(table_dev)
     # (the blocks are made on the caller's stream and worked on by the side streams: the allocator must not hand them to anybody
@@ -930,9 +934,11 @@ def device_tags(tasks, bounds=None, defer=False, method=None):
         ev.record(sides[side])
         chunks[c][2][0] = ev
         chunks[c][1].set()
+    mark('tags: uploaded')
     if not defer:
         for c in range(len(launches)):
             fire(c)
+    mark('tags: launched')
     for t, (_, e, n_rows), o in zip(tasks, plans, offs):
         on_dev = dev_all[o:o + e * n_rows].view(e, n_rows)
         t.host, t.on_dev, t.ready = None, on_dev, ready
