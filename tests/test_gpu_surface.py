@@ -330,6 +330,35 @@ def test_tags_made_on_the_device_train_like_the_hosts(monkeypatch):
     assert out[0][2] == out[1][2] and out[0][3] == out[1][3]
 
 
+@pytest.mark.parametrize('shuffle', ['auto', 'chain', 'reservations'])
+def test_every_device_shuffle_trains_like_the_hosts(monkeypatch, shuffle):
+    """The same with the kernel family forced (URE_SHUFFLE: csrc/perm_chain.hip for every chunk, csrc/perm_tags.hip for every chunk, the
+    product's choice per chunk) -- and for Scratch.train (config.py:182-188's full-MF stage), whose tags are made on the device since round 5
+    (rng.epoch_tags_device), epoch by epoch (verbose 1) and queued (verbose 0)."""
+    from ultrare_amd.method.scratch import Scratch
+    from ultrare_amd.method.sisa import Sisa
+    S, E = 3, 5
+    idx, trd, ted, tot = _sisa_inputs(S)
+    runs = []
+    for tags, how in (('1', shuffle), ('0', 'auto')):
+        monkeypatch.setenv('URE_DEVICE_TAGS', tags)
+        monkeypatch.setenv('URE_SHUFFLE', how)
+        sisa = Sisa(Param(E, parallel=True), 'mf', S, idx)
+        torch.manual_seed(42)
+        ml = sisa.learn(trd, ted, tot, 0, '')
+        got = [[m.item_mat.weight.detach().clone() for m in ml] + [ml[0].user_mat.weight.detach().clone()], dict(sisa.log)]
+        for verbose in (0, 1):
+            sc = Scratch(Param(E), 'mf')
+            torch.manual_seed(42)
+            m = sc.train(trd[0], ted[0], tot, verbose, '')
+            got[0] += [m.user_mat.weight.detach().clone(), m.item_mat.weight.detach().clone()]
+            got.append({k: v for k, v in sc.log.items() if k != 'time'})
+        runs.append(got)
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b)
+    assert runs[0][1:] == runs[1][1:]
+
+
 def test_cli_default_trains_shards_side_by_side_and_prints_the_same_lines(tmp_path, capsys):
     """main.py:60-70.  `python main.py --group 3` takes the shard-parallel path by default: models, logs, log0 and
     the per-epoch lines of scratch.py:99-118 equal those of `--parallel 0`, which trains shard after shard as the reference does."""
