@@ -114,6 +114,15 @@ __global__ __launch_bounds__(kJumpLanes) void mt_jump_kernel(unsigned *__restric
     }
 }
 
+// A barrier that orders LDS traffic only (as csrc/perm_chain.hip's): __syncthreads() also waits for the wave's global stores -- the tables'
+// elements of the chunk before --, an L2 round trip per chunk that nothing here depends on.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __global__ __launch_bounds__(kFillBlock) void mf_init_fill_kernel(const init_shard *__restrict__ shards, const unsigned *__restrict__ states, int J)
 {
     __shared__ unsigned w[(kChunkBlocks + 1) * kMtN];
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(kFillBlock) void mf_init_fill_kernel(const init_sha
     if (seg_lo >= n_out) return;
     const unsigned *st = states + ((size_t)shard * J + seg) * kMtN;
     for (int k = tid; k < kMtN; k += kFillBlock) w[k] = st[k];
-    __syncthreads();
+    lds_barrier();
     const int64_t q0 = S->q0;
     for (int chunk = 0; chunk < kSegBlocks / kChunkBlocks; ++chunk) {
         const int64_t lo = seg_lo + (int64_t)chunk * kChunkBlocks * kMtN;
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(kFillBlock) void mf_init_fill_kernel(const init_sha
         for (int pos = kMtN; pos < (kChunkBlocks + 1) * kMtN; pos += kMtLag) {
             const int p = pos + tid;
             if (tid < kMtLag && p < (kChunkBlocks + 1) * kMtN) w[p] = mt_twist(w[p - kMtN], w[p - kMtN + 1], w[p - kMtLag]);
-            __syncthreads();
+            lds_barrier();
         }
 #pragma unroll 1
         for (int pi = 0; pi < 4; ++pi) {
@@ -158,9 +167,9 @@ __global__ __launch_bounds__(kFillBlock) void mf_init_fill_kernel(const init_sha
                 if (e + 8 < limit) dest[e + 8] = b;
             }
         }
-        __syncthreads();
+        lds_barrier();
         for (int k = tid; k < kMtN; k += kFillBlock) w[k] = w[kChunkBlocks * kMtN + k];
-        __syncthreads();
+        lds_barrier();
     }
 }
 
