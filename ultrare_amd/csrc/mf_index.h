@@ -346,6 +346,10 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_kernel(const ure_shard_t *
 // one run of ~600 bytes instead of 38 scattered 16-byte stores (partial-line stores run at ~34 G/s: 1.3 ms per epoch for the 45 M
 // sorted slots of configs[3]'s shape, whatever the row width).  Every slot lands exactly where idx_scatter_kernel puts it.
 constexpr int kIdxStage = 1024;                 // slots a wavefront sorts in LDS at a time
+#ifndef URE_INDEX_STAGED_WAVES
+#define URE_INDEX_STAGED_WAVES 16
+#endif
+constexpr int kIdxStagedWaves = URE_INDEX_STAGED_WAVES;   // wavefronts that sort a chunk of an epoch of 64+ steps together (idx_scatter_staged_kernel)
 
 __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
 {
@@ -453,6 +457,144 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_sha
             }
         }
         flush();
+    }
+}
+
+// ---- epoch start 5, epochs of 64 .. 1,008 steps: the same idea with a WORKGROUP per chunk.  A chunk's slots of one step are few -- 4,096
+// slots / 750 steps = 5.5 -- but they are neighbours in the sorted array, and idx_scatter_kernel stores them one 16-byte record at a time,
+// minutes of the wave's life apart: every record leaves its L2 as a partial-line write of its own (45 M of them per epoch at the 25 M
+// shape: ~34 G/s, 1.31 ms whatever else the kernel does).  Here the four wavefronts of a workgroup sort ONE chunk in LDS -- count per (wave,
+// step), prefix over (step, wave), every wave places its quarter in slot order (the ranks of idx_scatter_kernel: ballots inside a batch of 64,
+// running counters) -- and the chunk leaves in sorted order: a step's 5.5 records are one stretch of 88 bytes, stored by neighbouring lanes.
+// Every slot lands exactly where idx_scatter_kernel puts it.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+{
+    __shared__ uint4 stage[kIdxChunk];                                  // 64 KB
+    __shared__ unsigned fill[WAVES][kIdxMaxSteps];              // per (wave, step): count, then where the wave's next record of the step goes
+    __shared__ unsigned lstart[kIdxMaxSteps + 1], goff[kIdxMaxSteps];    // a step's first record in the stage / in the sorted array
+    __shared__ unsigned wave_tot[WAVES];
+    constexpr int kThreads = WAVES * kWave, kPer = (kIdxMaxSteps + kThreads - 1) / kThreads;      // steps a thread takes of the prefix
+    const ure_shard_t &S = shards[blockIdx.y];
+    const shard_aux &A = aux[blockIdx.y];
+    const int epoch = idx_epoch_start(S, A, tick);
+    const int c = (int)blockIdx.x;
+    if (epoch < 0 || c >= A.idx_chunks) return;                         // (workgroup-uniform)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int steps = A.steps;
+    for (int s = tid; s < steps; s += kThreads) {
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) fill[w][s] = 0u;
+        goff[s] = ldg(A.hist + (size_t)c * (steps + 1) + s);
+    }
+    __syncthreads();
+    const uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, epoch);
+    const int64_t lo = (int64_t)c * kIdxChunk, hi = min(lo + kIdxChunk, S.n_slots);
+    const int64_t w_lo = lo + (int64_t)wave * (kIdxChunk / WAVES), w_hi = min(w_lo + kIdxChunk / WAVES, hi);
+    // ---- the wave's slots per step
+    unsigned *mine = fill[wave];
+    for (int64_t p = w_lo + lane * 8; p < w_hi; p += kWave * 8) {
+        const uint4 t4 = ldg_u4(ent_tag + p);
+        const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned t = (tw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            if (t < (unsigned)steps) atomicAdd(&mine[t], 1u);
+        }
+    }
+    __syncthreads();
+    // ---- exclusive prefix over (step, wave): thread t takes the steps [kPer t, kPer t + kPer)
+    {
+        unsigned own = 0u;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int s = kPer * tid + k;
+            if (s < steps)
+                for (int w = 0; w < WAVES; ++w) own += fill[w][s];
+        }
+        unsigned incl = own;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const unsigned v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == kWave - 1) wave_tot[wave] = incl;
+        __syncthreads();
+        unsigned run = incl - own;
+        for (int w = 0; w < wave; ++w) run += wave_tot[w];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int s = kPer * tid + k;
+            if (s < steps) {
+                lstart[s] = run;
+                for (int w = 0; w < WAVES; ++w) {
+                    const unsigned n_ws = fill[w][s];
+                    fill[w][s] = run;
+                    run += n_ws;
+                }
+            }
+        }
+        if (tid == kThreads - 1) lstart[kIdxMaxSteps] = run;           // the chunk's valid slots
+    }
+    __syncthreads();
+    // ---- every wave places its quarter, in slot order
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int n_all = S.n_user + S.n_item;
+    struct Batch { unsigned tag; int oid, idx, row; float r; };
+    auto fetch = [&](int64_t p) {
+        Batch b{0xFFFFu, 0, 0, 0, 0.f};
+        if (p < w_hi) {
+            b.tag = ldg(ent_tag + p);
+            b.oid = ldg(S.ent_oid + p);
+            b.r = ldg(S.ent_r + p);
+            const ure_i2 g = *(const ure_i2 URE_AS1 *)(A.grp_row + 2 * (p >> 3));
+            const int gi = g.x, gr = g.y;
+            b.idx = gi; b.row = gr;
+        }
+        return b;
+    };
+    auto word_of = [&](const Batch &b) {
+        if (b.tag >= (unsigned)steps) return 0ull;
+        const int other = b.row >= S.n_user ? b.oid : S.n_user + b.oid;
+        return ldg(A.W + (size_t)(b.tag / kIdxWin) * n_all + other);
+    };
+    constexpr int kRound = 8;
+    for (int64_t r0 = w_lo; r0 < w_hi; r0 += kRound * kWave) {
+        Batch bt[kRound];
+        unsigned long long wd[kRound];
+#pragma unroll
+        for (int k = 0; k < kRound; ++k) bt[k] = fetch(r0 + k * kWave + lane);
+#pragma unroll
+        for (int k = 0; k < kRound; ++k) wd[k] = word_of(bt[k]);
+#pragma unroll
+        for (int k = 0; k < kRound; ++k) {
+            const unsigned tag = bt[k].tag;
+            const bool valid = tag < (unsigned)steps;
+            const int oid = bt[k].oid | (valid ? idx_buffer_at(wd[k], (int)(tag % kIdxWin)) << 31 : 0);
+            const int cls = bt[k].idx < S.n_split ? kIdxSplit : bt[k].idx < S.n_multi ? kIdxHeavy : kIdxLight;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 10; ++b) {
+                const bool bit = (tag >> b) & 1u;
+                const unsigned long long m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
+            if (valid) {
+                const unsigned base = mine[tag];                        // (all peers read before their first lane writes: LDS runs a wave's accesses in order)
+                const int rank = __popcll(peers & below);
+                if (rank == 0) mine[tag] = base + (unsigned)__popcll(peers);
+                stage[base + rank] = make_uint4((unsigned)oid, __float_as_uint(bt[k].r), (unsigned)bt[k].row, tag | ((unsigned)cls << 16));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    // ---- the chunk leaves in sorted order
+    const unsigned total = lstart[kIdxMaxSteps];
+    for (unsigned i = tid; i < total; i += kThreads) {
+        const uint4 rec = stage[i];
+        const unsigned tag = rec.w & 0xFFFFu;
+        stg_u4(A.sslot + (size_t)(goff[tag] + (i - lstart[tag])), rec);
     }
 }
 

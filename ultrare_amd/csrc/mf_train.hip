@@ -651,6 +651,8 @@ static void launch_index_epoch_start(const ure_job *job, int64_t tick, hipStream
     constexpr bool staged_ok = true;
     if (steps <= kIdxWin && staged_ok)
         hipLaunchKernelGGL(idx_scatter_short_kernel, dim3(wave_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+    else if (job->scatter_staged)
+        hipLaunchKernelGGL(idx_scatter_staged_kernel<kIdxStagedWaves>, dim3((unsigned)chunks, n_sh), dim3(kIdxStagedWaves * kWave), 0, st, job->dev, job->dev_aux, tick);
     else
         hipLaunchKernelGGL(idx_scatter_kernel, dim3(wave_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
     hipLaunchKernelGGL(idx_mark_kernel, dim3(flag_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
@@ -746,6 +748,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
     }
     job->d = shards[0].d;
     if (const char *e = std::getenv("URE_SHARD_FAST")) { job->shard_fast = e[0] != '0'; job->shard_sliced = e[0] == '2'; }
+    if (const char *e = std::getenv("URE_INDEX_STAGED")) job->scatter_staged = e[0] != '0';
     for (int k = 0; k < n_shards; ++k) {
         const ure_shard_t &S = shards[k];
         job->lr_host.emplace_back(S.lr_host ? std::vector<float>(S.lr_host, S.lr_host + S.epochs) : std::vector<float>());

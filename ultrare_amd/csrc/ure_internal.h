@@ -66,6 +66,7 @@ struct ure_job {
     bool ahead = false;                                // touch_mode 2 (masks one epoch ahead): all shards of the job or none
     bool index = false;                                // touch_mode 3 (per-step slot index, mf_index.h): all shards of the job or none
     bool index_split = false;                          // ... and some shard has rows split over several workgroups (a combine launch per step)
+    bool scatter_staged = true;                        // ... its epochs of 64+ steps sorted a chunk at a time in LDS (idx_scatter_staged_kernel; URE_INDEX_STAGED=0: record by record)
     bool all_file_tags = true;                         // every shard's batch tags come from the host: no partition / collect / scatter launches
     std::vector<void *> touch_mem;                     // library-owned device memory of touch mode (masks, tables)
     int max_units = 0;                                 // work units of the largest shard
