@@ -347,9 +347,12 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_kernel(const ure_shard_t *
 // sorted slots of configs[3]'s shape, whatever the row width).  Every slot lands exactly where idx_scatter_kernel puts it.
 constexpr int kIdxStage = 1024;                 // slots a wavefront sorts in LDS at a time
 #ifndef URE_INDEX_STAGED_WAVES
-#define URE_INDEX_STAGED_WAVES 16
+#define URE_INDEX_STAGED_WAVES 8
 #endif
 constexpr int kIdxStagedWaves = URE_INDEX_STAGED_WAVES;   // wavefronts that sort a chunk of an epoch of 64+ steps together (idx_scatter_staged_kernel)
+#ifndef URE_INDEX_STAGED_COMPACT
+#define URE_INDEX_STAGED_COMPACT 1
+#endif
 
 __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
 {
@@ -467,10 +470,13 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_sha
 // step), prefix over (step, wave), every wave places its quarter in slot order (the ranks of idx_scatter_kernel: ballots inside a batch of 64,
 // running counters) -- and the chunk leaves in sorted order: a step's 5.5 records are one stretch of 88 bytes, stored by neighbouring lanes.
 // Every slot lands exactly where idx_scatter_kernel puts it.
-template <int WAVES>
+template <int WAVES, bool COMPACT>
 __global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
 {
-    __shared__ uint4 stage[kIdxChunk];                                  // 64 KB
+    // COMPACT: the stage holds a word per slot -- where the slot is in the chunk, its step, the buffer bit of its opposite row -- and the record is
+    // put together when the chunk leaves (three loads of lines this workgroup has just read): 16 KB instead of 64, two workgroups per CU
+    __shared__ uint4 stage[COMPACT ? 1 : kIdxChunk];
+    __shared__ unsigned stage_c[COMPACT ? kIdxChunk : 1];
     __shared__ unsigned fill[WAVES][kIdxMaxSteps];              // per (wave, step): count, then where the wave's next record of the step goes
     __shared__ unsigned lstart[kIdxMaxSteps + 1], goff[kIdxMaxSteps];    // a step's first record in the stage / in the sorted array
     __shared__ unsigned wave_tot[WAVES];
@@ -583,7 +589,10 @@ __global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const
                 const unsigned base = mine[tag];                        // (all peers read before their first lane writes: LDS runs a wave's accesses in order)
                 const int rank = __popcll(peers & below);
                 if (rank == 0) mine[tag] = base + (unsigned)__popcll(peers);
-                stage[base + rank] = make_uint4((unsigned)oid, __float_as_uint(bt[k].r), (unsigned)bt[k].row, tag | ((unsigned)cls << 16));
+                if (COMPACT)
+                    stage_c[base + rank] = (unsigned)(r0 + k * kWave + lane - lo) | ((unsigned)oid & 0x80000000u) >> 19 | tag << 13;
+                else
+                    stage[base + rank] = make_uint4((unsigned)oid, __float_as_uint(bt[k].r), (unsigned)bt[k].row, tag | ((unsigned)cls << 16));
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -592,7 +601,18 @@ __global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const
     // ---- the chunk leaves in sorted order
     const unsigned total = lstart[kIdxMaxSteps];
     for (unsigned i = tid; i < total; i += kThreads) {
-        const uint4 rec = stage[i];
+        uint4 rec;
+        if (COMPACT) {
+            const unsigned v = stage_c[i];
+            const int64_t p = lo + (int64_t)(v & 4095u);
+            const unsigned tag = v >> 13;
+            const ure_i2 g = *(const ure_i2 URE_AS1 *)(A.grp_row + 2 * (p >> 3));
+            const int gi = g.x, gr = g.y;
+            const int cls = gi < S.n_split ? kIdxSplit : gi < S.n_multi ? kIdxHeavy : kIdxLight;
+            rec = make_uint4((unsigned)ldg(S.ent_oid + p) | ((v >> 12) & 1u) << 31, __float_as_uint(ldg(S.ent_r + p)), (unsigned)gr, tag | ((unsigned)cls << 16));
+        } else {
+            rec = stage[i];
+        }
         const unsigned tag = rec.w & 0xFFFFu;
         stg_u4(A.sslot + (size_t)(goff[tag] + (i - lstart[tag])), rec);
     }

@@ -652,7 +652,7 @@ static void launch_index_epoch_start(const ure_job *job, int64_t tick, hipStream
     if (steps <= kIdxWin && staged_ok)
         hipLaunchKernelGGL(idx_scatter_short_kernel, dim3(wave_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
     else if (job->scatter_staged)
-        hipLaunchKernelGGL(idx_scatter_staged_kernel<kIdxStagedWaves>, dim3((unsigned)chunks, n_sh), dim3(kIdxStagedWaves * kWave), 0, st, job->dev, job->dev_aux, tick);
+        hipLaunchKernelGGL((idx_scatter_staged_kernel<kIdxStagedWaves, URE_INDEX_STAGED_COMPACT != 0>), dim3((unsigned)chunks, n_sh), dim3(kIdxStagedWaves * kWave), 0, st, job->dev, job->dev_aux, tick);
     else
         hipLaunchKernelGGL(idx_scatter_kernel, dim3(wave_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
     hipLaunchKernelGGL(idx_mark_kernel, dim3(flag_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
