@@ -66,6 +66,7 @@ def parse():
     ap.add_argument('--extras-budget', type=float, default=240.0, help='N = 1: seconds after which no further optional leg is started')
     ap.add_argument('--cpu-budget', type=float, default=15.0, help='seconds of CPU baseline work')
     ap.add_argument('--roofline-steps', type=int, default=3)
+    ap.add_argument('--no-resident', action='store_true', help='skip the second timed region (every tag resident): the process then launches the step kernel in the inclusive region, the warm-up and the event-pair pass only (profiles/rNN/bench_headline_kernel_stats.csv)')
     ap.add_argument('--extras-timeout', type=float, default=420.0, help='N > 1: seconds allowed for the exchange / split legs')
     ap.add_argument('--backend', default='nccl', help='process-group backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)')
     ap.add_argument('--force-device', type=int, default=None, help='rehearsal only: put every rank on this device')
@@ -179,6 +180,9 @@ class Dist:
         return int(t.item())
 
 
+NO_RESIDENT = False
+
+
 def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_steps=0, keep_job=False, data=None):
     """Make the workload resident, run W warm-up and K timed bench steps of the rank's shards, return the
     measurements.  split: ONE job (same data on every rank), shards placed by assign_shards; otherwise
@@ -201,7 +205,7 @@ def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_st
     # launched AFTER the clock has started.  A second timed region of K steps with every tag resident gives `value_resident_tags`
     # (round 4's headline).  Shards beyond 2^20 rows / URE_DEVICE_TAGS=0: host-made tags, resident, one region.
     dev_tags = bool(mine) and rng.device_tags_wanted() and all(all_sizes[s] <= rng.DEVICE_TAGS_MAX_ROWS and -(-all_sizes[s] // batch) <= 65535 for s in mine)
-    resident_steps = steps if dev_tags else 0
+    resident_steps = steps if dev_tags and not NO_RESIDENT else 0
     n_bench_steps = warmup + steps + resident_steps + roofline_steps
     min_steps = min(steps_per_epoch)
     epochs = int(np.ceil(n_bench_steps * tps / min_steps)) + 2
@@ -651,6 +655,8 @@ def split_legs(a, D, which):
 def main():
     t_start = time.perf_counter()
     a = parse()
+    global NO_RESIDENT
+    NO_RESIDENT = bool(a.no_resident)
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(a.gpus))
     if not torch.cuda.is_available():

@@ -27,6 +27,11 @@ if has bench; then
   python3 "$ROOT/bench.py" --gpus 1 --force-dist --no-cpu-baseline > "$OUT/bench_1rank_rccl.json" 2> "$OUT/bench_1rank_rccl.err"; echo "bench rccl rc=$?"
 fi
 if has stats; then
+  # the headline region alone: the process launches mf_step_kernel in the warm-up (21), the inclusive region (350) and the event-pair pass (7) only, so
+  # the kernel's average here is what roofline.avg_launch_us must agree with; its stdout (the bench line of that run) is kept beside it
+  rm -rf "$OUT/trace_headline"
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_headline" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-hbm-leg --no-cold --no-unlearn --no-ot --no-resident --roofline-steps 1 > "$OUT/bench_headline.json" 2> /dev/null; echo "headline rc=$?"
+  f=$(find "$OUT/trace_headline" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/bench_headline_kernel_stats.csv"; rm -rf "$OUT/trace_headline"
   stats bench "$ROOT/bench.py" --no-cpu-baseline --no-hbm-leg --no-cold
   stats bench_ml25m "$ROOT/bench.py" --workload ml25m --no-cpu-baseline --no-unlearn --no-hbm-leg --steps 5 --warmup 1
   stats e2e_sisa "$ROOT/tools/e2e_sisa.py"
