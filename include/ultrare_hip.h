@@ -327,12 +327,15 @@ int ure_host_build_layouts(int n_shards, const int64_t *const *uid, const int64_
 int ure_host_build_layouts_units(int n_shards, const int64_t *const *uid, const int64_t *const *iid, const double *const *rating, const int64_t *n,
                                  int32_t n_user, int32_t n_item, int32_t *const *region, const int64_t *region_words, int64_t *n_slots,
                                  int32_t *n_active, int32_t units_d, int64_t *n_units, int n_threads);
-/* ABI 9.  The same on a thread of the library's own: _start returns at once with a handle (0: no thread could be started), _wait joins and
- * returns what ure_host_build_layouts_units returned (its message in this thread's ure_last_error()).  Every argument of _start must stay
- * alive and unchanged until _wait has returned; every handle must be waited for exactly once. */
+/* ABI 9.  The same on a thread of the library's own: _start returns at once with a handle (0: bad arguments / no thread could be started),
+ * _wait joins and returns what ure_host_build_layouts_units returned (its message in this thread's ure_last_error()).  dev_region != NULL:
+ * every shard's region (layout + units, the words used) is copied to dev_region[s] -- DEVICE memory of `device` -- on `stream` as soon as
+ * the shard is built, while the others are still being built; _wait returns when every copy has been queued.  Every argument of _start
+ * must stay alive and unchanged until _wait has returned; every handle must be waited for exactly once. */
 int64_t ure_host_build_layouts_units_start(int n_shards, const int64_t *const *uid, const int64_t *const *iid, const double *const *rating,
                                            const int64_t *n, int32_t n_user, int32_t n_item, int32_t *const *region, const int64_t *region_words,
-                                           int64_t *n_slots, int32_t *n_active, int32_t units_d, int64_t *n_units, int n_threads);
+                                           int64_t *n_slots, int32_t *n_active, int32_t units_d, int64_t *n_units, int n_threads,
+                                           int32_t *const *dev_region, int32_t device, void *stream);
 int ure_host_build_layouts_units_wait(int64_t handle);
 /* Cuts the active rows of a schedule into the work units of struct ure_shard for row width d and
  * packs them into workgroups.  unit_passes = scan passes of one lane group per unit: 1 everywhere, except touch

@@ -88,7 +88,7 @@ _PROTOTYPES = {
     'ure_host_build_layouts_units': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i32, _i32,
                                                     ctypes.POINTER(_vp), _vp, _vp, _vp, _i32, _vp, ctypes.c_int]),
     'ure_host_build_layouts_units_start': (_i64, [ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _i32, _i32,
-                                                  ctypes.POINTER(_vp), _vp, _vp, _vp, _i32, _vp, ctypes.c_int]),
+                                                  ctypes.POINTER(_vp), _vp, _vp, _vp, _i32, _vp, ctypes.c_int, ctypes.POINTER(_vp), _i32, _vp]),
     'ure_host_build_layouts_units_wait': (ctypes.c_int, [_i64]),
     'ure_host_build_units': (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _i64, ctypes.POINTER(_i64)]),
     'ure_score': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -309,8 +309,9 @@ class LayoutBuild:
             pass
 
 
-def build_layouts_start(triples, n_user, n_item, regions, threads=0, units_d=0):
-    """build_layouts(units_d > 0) started on a native thread by THIS call (no Python worker has to be woken first) -> LayoutBuild."""
+def build_layouts_start(triples, n_user, n_item, regions, threads=0, units_d=0, dev_regions=None, device=-1, stream=None):
+    """build_layouts(units_d > 0) started on a native thread by THIS call (no Python worker has to be woken first) -> LayoutBuild.
+    dev_regions: device addresses, one per shard -- every shard's region is copied there on `stream` as soon as it is built."""
     S = len(triples)
     keep = []
     def col(c, dt):
@@ -326,10 +327,11 @@ def build_layouts_start(triples, n_user, n_item, regions, threads=0, units_d=0):
     reg = (_vp * S)(*[r.ctypes.data for r in regions])
     words = np.array([len(r) for r in regions], dtype=np.int64)
     n_slots, n_active, n_units = np.zeros(S, dtype=np.int64), np.zeros(S, dtype=np.int32), np.zeros(S, dtype=np.int64)
-    keep += [n, reg, words, list(regions), n_slots, n_active, n_units]
+    dreg = (_vp * S)(*[int(a) for a in dev_regions]) if dev_regions is not None else None
+    keep += [n, reg, words, list(regions), n_slots, n_active, n_units, dreg]
     handle = lib().ure_host_build_layouts_units_start(S, col(0, np.int64), col(1, np.int64), col(2, np.float64), n.ctypes.data, n_user, n_item, reg,
                                                       words.ctypes.data, n_slots.ctypes.data, n_active.ctypes.data, int(units_d), n_units.ctypes.data,
-                                                      int(threads))
+                                                      int(threads), dreg, int(device), stream_handle(stream) if dreg is not None else None)
     if not handle:
         raise NativeError('ure_host_build_layouts_units_start: ' + lib().ure_last_error().decode(errors='replace'))
     return LayoutBuild(handle, keep, (n_slots, n_active, n_units))

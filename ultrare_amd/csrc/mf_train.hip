@@ -39,6 +39,8 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <vector>
 
 // Tuning knobs (defaults = the swept optimum; -D overrides are for sweeps only)
@@ -716,6 +718,79 @@ extern "C" int ure_debug_timeline(void *buf) { return (int)hipMemcpyToSymbol(HIP
 
 extern "C" {
 
+// Library-owned device memory of touch mode (masks, tables, the slot index) comes from a small cache of blocks instead of hipMalloc / hipFree
+// per job: a 32-shard job makes 32-128 allocations, each a driver call and a synchronous fill -- 24 ms of a 110 ms request at configs[3]'s
+// shape (k = 16), 28 ms at k = 128 --, and every request of a process asks for the same sizes again.  Blocks go back when their job is destroyed
+// (after the device has been waited for); up to kBlockCacheBytes are kept per device, the rest is freed.
+namespace ure {
+namespace {
+struct BlockCache {
+    std::multimap<size_t, void *> idle;
+    std::map<void *, size_t> size_of;
+    size_t held = 0;
+};
+std::mutex g_block_lock;
+std::map<int, BlockCache> g_block_cache;
+constexpr size_t kBlockCacheBytes = (size_t)8 << 30;
+
+hipError_t block_malloc(void **out, size_t bytes)
+{
+    bytes = (std::max<size_t>(bytes, 1) + ((size_t)256 << 10) - 1) / ((size_t)256 << 10) * ((size_t)256 << 10);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> hold(g_block_lock);
+        BlockCache &C = g_block_cache[dev];
+        auto it = C.idle.lower_bound(bytes);
+        if (it != C.idle.end() && it->first <= bytes + bytes / 4 + ((size_t)1 << 20)) {
+            *out = it->second;
+            C.held -= it->first;
+            C.idle.erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {                                   // (out of memory with idle blocks held: give them back and ask once more)
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> hold(g_block_lock);
+            BlockCache &C = g_block_cache[dev];
+            for (auto &kv : C.idle) { drop.push_back(kv.second); C.size_of.erase(kv.second); }
+            C.idle.clear();
+            C.held = 0;
+        }
+        for (void *p : drop) (void)hipFree(p);
+        (void)hipGetLastError();
+        e = hipMalloc(out, bytes);
+    }
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> hold(g_block_lock);
+        g_block_cache[dev].size_of[*out] = bytes;
+    }
+    return e;
+}
+
+void block_free(void *p)
+{
+    if (!p) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> hold(g_block_lock);
+        BlockCache &C = g_block_cache[dev];
+        auto it = C.size_of.find(p);
+        if (it != C.size_of.end() && C.held + it->second <= kBlockCacheBytes) {
+            C.idle.emplace(it->second, p);
+            C.held += it->second;
+            return;
+        }
+        if (it != C.size_of.end()) C.size_of.erase(it);
+    }
+    (void)hipFree(p);
+}
+}  // namespace
+}  // namespace ure
+
 int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
 {
     URE_ARG(shards && out && n_shards > 0 && n_shards <= 65535);
@@ -816,7 +891,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             }
         }
         void *ptab = nullptr;
-        e = hipMalloc(&ptab, tab.size() * sizeof(float));
+        e = block_malloc(&ptab, tab.size() * sizeof(float));
         if (e == hipSuccess) { job->touch_mem.push_back(ptab); e = hipMemcpy(ptab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice); }
         for (int k = 0; k < n_shards && e == hipSuccess && job->index; ++k) {
             // touch_mode 3: the slot index of the current epoch (mf_index.h), one allocation per shard
@@ -838,7 +913,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             const size_t o_cum = take(steps * (kIdxHeavyMax + 1) * 4), o_pa = take((size_t)A.idx_hw * (S.d + 4) * 4);
             const size_t o_map = take(steps * (size_t)A.idx_hw * 4), o_wg = take(steps * 4), o_sd = take(steps * 16);
             void *mem = nullptr;
-            e = hipMalloc(&mem, at);
+            e = block_malloc(&mem, at);
             if (e != hipSuccess) break;
             job->touch_mem.push_back(mem);
             char *b = static_cast<char *>(mem);
@@ -869,7 +944,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         for (int k = 0; k < n_shards && e == hipSuccess && !job->index; ++k) {
             const size_t bytes = (size_t)(shards[k].n_user + shards[k].n_item) * sizeof(unsigned long long);
             void *mk = nullptr;
-            e = hipMalloc(&mk, 2 * bytes);
+            e = block_malloc(&mk, 2 * bytes);
             if (e != hipSuccess) break;
             job->touch_mem.push_back(mk);
             e = hipMemset(mk, 0, 2 * bytes);
@@ -879,7 +954,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             // the masks once more in work order: per work unit (multi-pass rows) and per single-pass row of the schedule
             const size_t n_um = (size_t)std::max(shards[k].n_units, 1), n_sm = (size_t)std::max(shards[k].n_active - shards[k].n_multi, 1);
             void *wm = nullptr;
-            e = hipMalloc(&wm, (2 * n_um + n_sm) * sizeof(unsigned long long));
+            e = block_malloc(&wm, (2 * n_um + n_sm) * sizeof(unsigned long long));
             if (e != hipSuccess) break;
             job->touch_mem.push_back(wm);
             e = hipMemset(wm, 0, (2 * n_um + n_sm) * sizeof(unsigned long long));
@@ -892,7 +967,7 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
                 // epochs of several windows: the steps of every scan pass of the multi-pass units (mf_touch.h: pass skipping)
                 void *pm = nullptr;
                 const size_t bytes = ((size_t)shards[k].n_slots / 8 + 1) * sizeof(unsigned long long);
-                e = hipMalloc(&pm, bytes);
+                e = block_malloc(&pm, bytes);
                 if (e != hipSuccess) break;
                 job->touch_mem.push_back(pm);
                 e = hipMemset(pm, 0, bytes);
@@ -902,12 +977,12 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             if (job->ahead) {
                 // touch_mode 2: the work-order masks once per epoch parity (the first set is the one above), and the owners' hand-over
                 void *wm2 = nullptr, *nf = nullptr;
-                e = hipMalloc(&wm2, (2 * n_um + n_sm) * sizeof(unsigned long long));
+                e = block_malloc(&wm2, (2 * n_um + n_sm) * sizeof(unsigned long long));
                 if (e != hipSuccess) break;
                 job->touch_mem.push_back(wm2);
                 e = hipMemset(wm2, 0, (2 * n_um + n_sm) * sizeof(unsigned long long));
                 if (e != hipSuccess) break;
-                e = hipMalloc(&nf, n_um + n_sm);
+                e = block_malloc(&nf, n_um + n_sm);
                 if (e != hipSuccess) break;
                 job->touch_mem.push_back(nf);
                 e = hipMemset(nf, 0xFF, n_um + n_sm);
@@ -932,7 +1007,7 @@ int ure_job_destroy(ure_job_t *j)
     if (job->dev) (void)hipFree(job->dev);
     if (job->dev_ab) (void)hipFree(job->dev_ab);
     if (job->dev_aux) (void)hipFree(job->dev_aux);
-    for (void *p : job->touch_mem) (void)hipFree(p);
+    for (void *p : job->touch_mem) ure::block_free(p);          // (the three frees above have waited for the device)
     delete job;
     return 0;
 }

@@ -169,13 +169,27 @@ class LayoutPlan:
         self.stage = rng.STAGING.take((int(self.off[-1]),), torch.int32)
         # the native builder starts HERE, on a thread of the library's own (a Python worker took 0.3-0.4 ms to get going while the calling
         # thread held the interpreter); build() joins it
+        # ... and sends every shard's layout to the device as soon as it is built (the blob is allocated here for that; as ONE copy behind the
+        # last shard, the 1.1 GB of a 32-shard request at the 25 M shape stood between the build and the job for 28 ms)
         self._async = None
+        self.blob = None
+        self._uploaded = False
+        self._stream = None
         if self.d_units:
             host = self.stage.numpy()
-            mark('layouts native start')
             try:
+                dev_regions, dev_id, stream = None, -1, None
+                if self.on_gpu:
+                    with torch.cuda.device(dev):
+                        self.blob = torch.empty(int(self.off[-1]), dtype=torch.int32, device=dev)
+                        stream = torch.cuda.current_stream(dev)
+                    dev_regions = [self.blob.data_ptr() + 4 * int(self.off[s]) for s in range(len(cols))]
+                    dev_id = self.blob.device.index
+                    self._uploaded, self._stream = True, stream
+                mark('layouts native start')
                 self._async = nv.build_layouts_start(cols, self.n_user, self.n_item, [host[self.off[s]:self.off[s + 1]] for s in range(len(cols))],
-                                                     threads=min(len(cols), rng.host_cpus()), units_d=self.d_units)
+                                                     threads=min(len(cols), rng.host_cpus()), units_d=self.d_units, dev_regions=dev_regions, device=dev_id,
+                                                     stream=stream)
             except BaseException:
                 rng.STAGING.give(self.stage, None)
                 raise
@@ -187,7 +201,8 @@ class LayoutPlan:
         from . import rng
         cols, dev, al = self.cols, self.dev, (lambda x: (x + 7) // 8 * 8)
         try:
-            self.blob = torch.empty(int(self.off[-1]), dtype=torch.int32, device=dev)
+            if self.blob is None:
+                self.blob = torch.empty(int(self.off[-1]), dtype=torch.int32, device=dev)
             # engine-side scratch: batch tags (0xFFFF matches no batch; three buffers: touch_mode 2 prepares two epochs ahead) and
             # the stages of the inverse permutation.  Sized for the most slots a shard of n interactions can have.
             self.t_words = [(al(3 * nv.layout_capacity(len(c[0]), self.n_user, self.n_item)), al(len(c[0]))) for c in cols]
@@ -243,11 +258,12 @@ class LayoutPlan:
                 if self.on_gpu:
                     # (the allocations and fills were queued on the planner's stream, which need not be this thread's)
                     torch.cuda.current_stream(dev).wait_event(self.allocated)
-                self.blob[:end].copy_(self.stage[:end], non_blocking=pinned)          # ONE copy (the slack between the regions travels along)
+                if not self._uploaded:
+                    self.blob[:end].copy_(self.stage[:end], non_blocking=pinned)      # ONE copy (the slack between the regions travels along)
                 if self.on_gpu:
                     # whoever trains on a layout from another stream waits for this event first: TrainJob does
                     ready = torch.cuda.Event()
-                    ready.record(torch.cuda.current_stream(dev))
+                    ready.record(self._stream if self._uploaded else torch.cuda.current_stream(dev))     # (the stream the copies went to)
             mark('w: layouts copy queued')
             out, t_at, z_at = [], 0, 0
             for s, (uid, iid, rating) in enumerate(cols):
@@ -267,8 +283,10 @@ class LayoutPlan:
                 t_at += ta + tb
                 z_at += za + zb
                 sh._blob = self.blob
-                sh._sched_host = host[o + 3 * k:o + 3 * k + 4 * rows].reshape(rows, 4).copy()
-                sh.max_row = int(sh._sched_host[0, 3])
+                # (the schedule's head stays on the host -- what a job reads of it --; the whole of it, 3.5 MB per shard at the 25 M shape and 6 ms of
+                # copying for a 32-shard request, comes back from the device when somebody asks: units of another table width)
+                sh._sched_head = host[o + 3 * k:o + 3 * k + 4 * min(rows, INDEX_HEAVY_MAX)].reshape(-1, 4).copy()
+                sh.max_row = int(sh._sched_head[0, 3])
                 sh.u_pos = sh.i_pos = None
                 if keep_positions:                                        # host copies of every interaction's two slots (tests, tools)
                     lay = nv.build_layout(np.ascontiguousarray(uid, dtype=np.int32), np.ascontiguousarray(iid, dtype=np.int32),
@@ -309,6 +327,10 @@ class ShardData:
     def __getattr__(self, name):
         # the layout's arrays as tensors (ent_oid, ent_r, ent_src, sched, ent_tag, file_tag, inv_stage, inv_off, _row_slot): views made on first use
         where = self.__dict__.get('_where')
+        if name == '_sched_host' and where is not None:
+            got = self.sched.cpu().numpy()                   # (synchronises; rare)
+            self.__dict__[name] = got
+            return got
         if where is None or name not in where:
             raise AttributeError(name)
         base, first, count, dtype, shape = where[name]
@@ -524,7 +546,7 @@ class TrainJob:
                 setattr(D, name, sh.ptr(name))
             if self.index:
                 # no work units: the step's items come from the epoch's index.  Rows by weight class (slots per step on average)
-                nnz, st_s = sh._sched_host[:min(sh.n_active, INDEX_HEAVY_MAX), 3], steps_all[s]
+                nnz, st_s = sh._sched_head[:min(sh.n_active, INDEX_HEAVY_MAX), 3], steps_all[s]
                 D.n_multi = int(np.count_nonzero(nnz >= INDEX_HEAVY_SLOTS * st_s))
                 D.n_split = min(D.n_multi, int(np.count_nonzero(nnz >= INDEX_SPLIT_SLOTS * st_s)))
                 units, n_units = sh.ptr('sched'), 0
