@@ -324,3 +324,16 @@ def test_cold_request_rebuilds_everything():
     assert r['learn']['layouts_built'] == 4 and r['unlearn']['layouts_built'] == r['retrained'] >= 1
     assert r['unlearn']['total_s'] >= r['unlearn']['train_merge_test_s'] > 0
     assert np.isfinite(list(r['unlearn_log0'].values())).all()
+
+
+def test_full_mf_request_and_ot_leg_of_the_bench_line():
+    """What bench.py's `unlearn.run_full` and `ot` objects call (ultrare_amd.measure), at small sizes: the full-MF stage as a request
+    (config.py:182-188; a new request per repetition, its layout built inside the timed call, its epochs' tags made on the device) and the
+    OT leg (utils.py:628-656: labels of balanced sizes, the parts of a round, the cost kernel's bytes)."""
+    from ultrare_amd import measure, synth
+    data = synth.make_dataset(n_user=1200, n_item=900, n_train=90000, n_test=10000, seed=5)
+    r = measure.full_request(k=8, epochs=3, data=data, reps=2)
+    assert r['layouts_built_in_timed_call'] == 1 and r['finite_tables'] and r['batch_tags'] == 'device'
+    assert r['wall_s'] > 0 and np.isfinite(list(r['last_epoch'].values())).all()
+    o = measure.ot_request(600, 8, 4, 3, max_iters=3)
+    assert sorted(o['group_sizes']) == [150] * 4 and o['rounds'] >= 1 and o['cost_kernel']['alg_bytes'] == 600 * 8 * 4 + 4 * 8 * 4 + 4 * 600 * 4
