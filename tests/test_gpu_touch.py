@@ -455,6 +455,38 @@ def test_touch_index_mode_heavy_and_split_rows(B, heavy, split, monkeypatch):
     job.close()
 
 
+@pytest.mark.parametrize('B,k', [(437, 16), (37, 16), (219, 128)])
+def test_touch_index_staged_scatter_equals_the_direct_one(B, k, monkeypatch):
+    """Epochs of 65 / 130 / 750 steps in touch_mode 3: the scatter that sorts a chunk of 4,096 slots in LDS and stores a step's stretch at a
+    time (idx_scatter_staged_kernel, the default since round 5) puts every slot exactly where the record-by-record scatter
+    (idx_scatter_kernel, URE_INDEX_STAGED=0) puts it: the same index (ure_job_index_read), and tables, losses bit for bit."""
+    from ultrare_amd import engine, rng
+    monkeypatch.setenv('URE_TOUCH_INDEX', '1')
+    raw = O.load_csv(TRAIN)
+    part = O.partition(*raw, O.uniform_groups(N_USER, 1))[0]
+    if B == 37:
+        part = _truncate(part, 27714)
+    E = 2
+    torch.manual_seed(11)
+    init = tuple(t * (0.3 if k > 64 else 1.0) for t in rng.mf_init(N_USER, N_ITEM, k))
+    perms = rng.epoch_perms(rng.epoch_seeds(E, True), len(part[0]))
+    got = []
+    for staged in ('1', '0'):
+        monkeypatch.setenv('URE_INDEX_STAGED', staged)
+        job = engine.TrainJob([engine.ShardData(*part, N_USER, N_ITEM)], [init], [perms], k, B, E, 1e-3, 0.1, 0.9, 0.95, touch=True)
+        assert job.index and job.steps_per_epoch(0) > 63
+        job.run_epochs(1)
+        sb = job.index_array(0, 'step_begin')
+        index = (sb, job.index_array(0, 'sslot')[:int(sb[job.steps_per_epoch(0)])], job.index_array(0, 'items'), job.index_array(0, 'step_item'))
+        job.run()
+        U, V = job.tables(0)
+        got.append((U.clone(), V.clone(), job.epoch_sse(0).copy(), index))
+        job.close()
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])
+    for a, b in zip(got[0][3], got[1][3]):
+        assert np.array_equal(a, b)
+
+
 def test_touch_index_mode_refusals():
     from ultrare_amd import engine, _native as nv
     parts, inits, perms, shards = _setup(1, 16, 20, 1)
