@@ -16,8 +16,9 @@
 // So all that is needed is every T_q in rising order -- a grouping of the n - 1 swaps by target -- and a chase along "largest member"
 // links, which is short (half a hop per row on average: a random target list has about one member).  No swap waits for another.
 //
-// SIX LAUNCHES (the link pass is two), stream ordered (no grid barrier; global atomics only to count and to reserve space, one per (tile,
-// bucket)):
+// SIX LAUNCHES (the link pass is two), stream ordered, no grid barrier.  Up to 2^20 rows (at most 1,024 buckets) no global atomic at all: the
+// targets pass leaves a (tile, bucket) count matrix, the bucket pass sums its columns -- every swap's place is fixed.  Beyond: one global add per
+// (tile, bucket) to count and one to reserve space:
 //   shuffle_words_kernel    one workgroup per permutation walks MT19937, 623 new words per barrier (the recurrence substituted into itself
 //                           twice), the raw words into t[].
 //   shuffle_targets_kernel  one workgroup per (permutation, tile of 16,384 swaps): t[j] = j + temper(word) % (n - j) in place, and the
@@ -49,6 +50,7 @@ constexpr int kDrawBlock = 640;                  // ten wavefronts: lanes 0..622
 constexpr int kDrawWide = 623;                   // words per dependent step
 constexpr int kDrawRing = 8192;                  // the generator's words kept in LDS (a step reads 1,305 back)
 constexpr int64_t kSegmentedRows = 1 << 21;      // permutations beyond this: the generator's stream in segments (mt_jump_dev.h)
+constexpr int kFewBuckets = 1024;                // ... of a launch whose permutations have at most 2^20 rows
 constexpr int kMaxBuckets = 16384;               // per permutation (LDS counters of the draw and bucket passes)
 constexpr int kTileBlock = 1024;
 constexpr int kTileLoads = 4;                    // 16-byte loads per lane: a tile of the bucket pass is 16,384 swaps
@@ -187,10 +189,11 @@ __global__ __launch_bounds__(kDrawBlock) void shuffle_words_kernel(const ure_per
 
 // One workgroup per (permutation, tile of 16,384 swaps): raw word -> target, t[j] = j + temper(word) % (n - j), in place, and the swaps
 // per BUCKET (range of 2^range_log2 targets) added to the permutation's counters -- one global add per bucket the tile touches.
+template <int CAP>
 __global__ __launch_bounds__(kTileBlock) void shuffle_targets_kernel(const ure_perm_t *__restrict__ perms, int n_perms, int parts_max, unsigned *__restrict__ scratch,
-                                                                      int64_t n_al, int64_t b_al, int range_log2)
+                                                                      int64_t n_al, int64_t b_al, int range_log2, unsigned *__restrict__ mat)
 {
-    __shared__ unsigned cnt[kMaxBuckets];
+    __shared__ unsigned cnt[CAP];                               // (CAP = the launch's most buckets per permutation: 4 KB of LDS up to 2^20 rows, not 64)
     const int tid = threadIdx.x;
     const int x8 = blockIdx.x & 7, l = blockIdx.x >> 3;
     const int perm = (l / parts_max) * 8 + x8, part = l % parts_max;
@@ -229,6 +232,12 @@ __global__ __launch_bounds__(kTileBlock) void shuffle_targets_kernel(const ure_p
         }
     }
     __syncthreads();
+    if (CAP == kFewBuckets) {
+        // few buckets: the tile's counts into its row of the permutation's (tile, bucket) matrix -- the bucket pass sums the columns, no atomic
+        unsigned *row = mat + ((size_t)perm * parts_max + part) * kFewBuckets;
+        for (int b = tid; b < n_buckets; b += kTileBlock) row[b] = b >= b_lo ? cnt[b] : 0u;
+        return;
+    }
     for (int b = b_lo + tid; b < n_buckets; b += kTileBlock) {
         const unsigned c = cnt[b];
         if (c) atomicAdd(&P.totals[b], c);
@@ -272,11 +281,12 @@ __device__ __forceinline__ unsigned prefix_in_place(unsigned *v, int n, unsigned
     return *carry_word;
 }
 
+template <int CAP>
 __global__ __launch_bounds__(kTileBlock) void shuffle_bucket_kernel(const ure_perm_t *__restrict__ perms, int n_perms, int parts_max, unsigned *__restrict__ scratch,
-                                                                     int64_t n_al, int64_t b_al, int range_log2)
+                                                                     int64_t n_al, int64_t b_al, int range_log2, const unsigned *__restrict__ mat)
 {
-    __shared__ unsigned cur[kMaxBuckets];                       // the tile's count per bucket, then its cursor in the bucket's stretch
-    __shared__ unsigned base[kMaxBuckets];
+    __shared__ unsigned cur[CAP];                               // the tile's count per bucket, then its cursor in the bucket's stretch
+    __shared__ unsigned base[CAP];
     __shared__ unsigned wave_sum[kTileBlock / 64];
     __shared__ unsigned s_carry;
     const int tid = threadIdx.x;
@@ -291,11 +301,6 @@ __global__ __launch_bounds__(kTileBlock) void shuffle_bucket_kernel(const ure_pe
     const int n_buckets = (int)((((int64_t)n - 1) >> range_log2) + 1);
     const unsigned j0 = (unsigned)j0l, j_end = (unsigned)(n - 1);
     const int b_lo = (int)(j0 >> range_log2);                   // t_j >= j: the tile's swaps target buckets b_lo .. n_buckets - 1
-    for (int b = tid; b < n_buckets; b += kTileBlock) {
-        cur[b] = 0u;
-        base[b] = P.totals[b];
-    }
-    __syncthreads();
     const uint4 *t4 = reinterpret_cast<const uint4 *>(P.t);
     uint4 v[kTileLoads];
 #pragma unroll
@@ -303,22 +308,51 @@ __global__ __launch_bounds__(kTileBlock) void shuffle_bucket_kernel(const ure_pe
         const unsigned j = j0 + 4u * (unsigned)(tid + u * kTileBlock);
         v[u] = j < j_end ? t4[j >> 2] : make_uint4(0u, 0u, 0u, 0u);
     }
+    if (CAP == kFewBuckets) {
+        // few buckets: a bucket's swaps and the ones of the tiles before this one from the columns of the (tile, bucket) matrix the targets
+        // pass left -- every tile's place in every stretch is fixed, no atomic, no cursor
+        const int n_tiles = (int)(((int64_t)n - 1 + kTile - 1) / kTile);
+        const unsigned *m = mat + (size_t)perm * parts_max * kFewBuckets;
+        for (int b = tid; b < n_buckets; b += kTileBlock) {
+            unsigned all = 0u, before = 0u;
+            for (int t = 0; t < n_tiles; ++t) {
+                const unsigned c = m[(size_t)t * kFewBuckets + b];
+                before += t < part ? c : 0u;
+                all += c;
+            }
+            base[b] = all;
+            cur[b] = before;
+            if (part == 0) P.totals[b] = all;
+        }
+        prefix_in_place<kTileBlock>(base, n_buckets, wave_sum, &s_carry);
+        for (int b = tid; b < n_buckets; b += kTileBlock) {
+            if (part == 0) P.bases[b] = base[b];
+            cur[b] += base[b];
+        }
+        __syncthreads();
+    } else {
+        for (int b = tid; b < n_buckets; b += kTileBlock) {
+            cur[b] = 0u;
+            base[b] = P.totals[b];
+        }
+        __syncthreads();
 #pragma unroll
-    for (int u = 0; u < kTileLoads; ++u) {
-        const unsigned j = j0 + 4u * (unsigned)(tid + u * kTileBlock);
-        if (j < j_end) atomicAdd(&cur[v[u].x >> range_log2], 1u);
-        if (j + 1 < j_end) atomicAdd(&cur[v[u].y >> range_log2], 1u);
-        if (j + 2 < j_end) atomicAdd(&cur[v[u].z >> range_log2], 1u);
-        if (j + 3 < j_end) atomicAdd(&cur[v[u].w >> range_log2], 1u);
+        for (int u = 0; u < kTileLoads; ++u) {
+            const unsigned j = j0 + 4u * (unsigned)(tid + u * kTileBlock);
+            if (j < j_end) atomicAdd(&cur[v[u].x >> range_log2], 1u);
+            if (j + 1 < j_end) atomicAdd(&cur[v[u].y >> range_log2], 1u);
+            if (j + 2 < j_end) atomicAdd(&cur[v[u].z >> range_log2], 1u);
+            if (j + 3 < j_end) atomicAdd(&cur[v[u].w >> range_log2], 1u);
+        }
+        prefix_in_place<kTileBlock>(base, n_buckets, wave_sum, &s_carry);    // (its first barrier ends the counting)
+        if (part == 0)
+            for (int b = tid; b < n_buckets; b += kTileBlock) P.bases[b] = base[b];
+        for (int b = b_lo + tid; b < n_buckets; b += kTileBlock) {
+            const unsigned c = cur[b];
+            if (c) cur[b] = base[b] + atomicAdd(&P.cursors[b], c);  // the tile's place in the bucket's stretch (where it lies does not matter)
+        }
+        __syncthreads();
     }
-    prefix_in_place<kTileBlock>(base, n_buckets, wave_sum, &s_carry);        // (its first barrier ends the counting)
-    if (part == 0)
-        for (int b = tid; b < n_buckets; b += kTileBlock) P.bases[b] = base[b];
-    for (int b = b_lo + tid; b < n_buckets; b += kTileBlock) {
-        const unsigned c = cur[b];
-        if (c) cur[b] = base[b] + atomicAdd(&P.cursors[b], c);  // the tile's place in the bucket's stretch (where it lies does not matter)
-    }
-    __syncthreads();
     auto put = [&](unsigned j, unsigned q) { P.pairs[atomicAdd(&cur[q >> range_log2], 1u)] = make_uint2(j, q); };
 #pragma unroll
     for (int u = 0; u < kTileLoads; ++u) {
@@ -563,7 +597,9 @@ extern "C" int64_t ure_device_shuffle_tags_scratch(int64_t n_max, int32_t n_perm
 {
     if (n_max <= 0 || n_perms <= 0) return 0;
     const int64_t J = n_max > ure::kSegmentedRows ? (n_max - 1 + ure::jmp::kSegWords - 1) / ure::jmp::kSegWords : 0;
-    return ure_device_shuffle_tags_flag(n_max, n_perms) + 64 + (int64_t)n_perms * J * ure::kMtN;       // (+ the segments' start blocks)
+    const int64_t tiles = std::max<int64_t>(1, (n_max - 1 + ure::kTile - 1) / ure::kTile);
+    // (+ the segments' start blocks, + the (tile, bucket) count matrices of launches of few buckets)
+    return ure_device_shuffle_tags_flag(n_max, n_perms) + 64 + (int64_t)n_perms * J * ure::kMtN + (int64_t)n_perms * tiles * ure::kFewBuckets;
 }
 
 extern "C" int ure_device_shuffle_tags(const ure_perm_t *perms, int32_t n_perms, int64_t n_max, uint32_t *scratch, int64_t scratch_words, int32_t range_log2,
@@ -598,8 +634,17 @@ extern "C" int ure_device_shuffle_tags(const ure_perm_t *perms, int32_t n_perms,
         hipLaunchKernelGGL(shuffle_words_kernel, dim3((unsigned)n_perms), dim3(kDrawBlock), 0, st, perms, (int)n_perms, scratch, n_al, b_al, rl,
                            static_cast<const unsigned *>(nullptr), 1);
     }
-    hipLaunchKernelGGL(shuffle_targets_kernel, dim3((unsigned)(8 * slots * tiles)), dim3(kTileBlock), 0, st, perms, (int)n_perms, (int)tiles, scratch, n_al, b_al, rl);
-    hipLaunchKernelGGL(shuffle_bucket_kernel, dim3((unsigned)(8 * slots * tiles)), dim3(kTileBlock), 0, st, perms, (int)n_perms, (int)tiles, scratch, n_al, b_al, rl);
+    const bool few = ranges <= kFewBuckets;                     // (buckets per permutation: small LDS tables, a count matrix instead of global atomics)
+    const int64_t J_all = n_max > kSegmentedRows ? (n_max - 1 + jmp::kSegWords - 1) / jmp::kSegWords : 0;
+    uint32_t *mat = broken + 64 + (int64_t)n_perms * J_all * kMtN;
+    if (few)
+        hipLaunchKernelGGL(shuffle_targets_kernel<kFewBuckets>, dim3((unsigned)(8 * slots * tiles)), dim3(kTileBlock), 0, st, perms, (int)n_perms, (int)tiles, scratch, n_al, b_al, rl, mat);
+    else
+        hipLaunchKernelGGL(shuffle_targets_kernel<kMaxBuckets>, dim3((unsigned)(8 * slots * tiles)), dim3(kTileBlock), 0, st, perms, (int)n_perms, (int)tiles, scratch, n_al, b_al, rl, mat);
+    if (few)
+        hipLaunchKernelGGL(shuffle_bucket_kernel<kFewBuckets>, dim3((unsigned)(8 * slots * tiles)), dim3(kTileBlock), 0, st, perms, (int)n_perms, (int)tiles, scratch, n_al, b_al, rl, mat);
+    else
+        hipLaunchKernelGGL(shuffle_bucket_kernel<kMaxBuckets>, dim3((unsigned)(8 * slots * tiles)), dim3(kTileBlock), 0, st, perms, (int)n_perms, (int)tiles, scratch, n_al, b_al, rl, mat);
     for (int heavy = 0; heavy < 2; ++heavy) {
         const dim3 grid((unsigned)(8 * slots * ranges)), block(kLinkBlock);
         if (rl == 10 && !heavy) hipLaunchKernelGGL((shuffle_link_kernel<10, kStage10>), grid, block, 0, st, perms, (int)n_perms, (int)ranges, scratch, n_al, b_al, heavy);
