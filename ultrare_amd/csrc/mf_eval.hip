@@ -820,6 +820,29 @@ __global__ __launch_bounds__(kBlock) void eval_metrics_kernel(const int32_t *__r
 // utils.py:163-184 tail: rmse = sqrt(sse / n_rows), ndcg = mean(ndcg), hr = mean(hits / 10), reduced on
 // the device by ONE workgroup in a fixed order (reproducible) so that a caller can queue many
 // evaluations and read all results once.
+// The sums of a workgroup's 1,024 values per array in the order of the tree  for (o = 512; o > 0; o >>= 1) s[i] += s[i + o]  -- the order every
+// reduction of the user metrics has had since round 1, which results are pinned to --: the first four levels through LDS (add(i, j): s[i] += s[j]
+// for every array of the reduction, one barrier per level for all of them), the last six inside wavefront 0 with shuffles (tree_tail:
+// v + shfl_down(v, o) is s[i] + s[i + o]): six barriers fewer per reduction.
+template <class F>
+__device__ __forceinline__ void tree_head_1024(F add)
+{
+    __syncthreads();
+#pragma unroll
+    for (int o = 512; o >= 64; o >>= 1) {
+        if ((int)threadIdx.x < o) add((int)threadIdx.x, (int)threadIdx.x + o);
+        __syncthreads();
+    }
+}
+template <typename T>
+__device__ __forceinline__ T tree_tail(const T *s)              // (threads 0 .. 63; the total is thread 0's)
+{
+    T r = s[threadIdx.x & 63];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o, 64);
+    return r;
+}
+
 __global__ __launch_bounds__(1024) void eval_reduce_kernel(const int32_t *__restrict__ hits, const double *__restrict__ ndcg,
                                                            int32_t n_users, const double *__restrict__ sse, int64_t n_rows,
                                                            double *__restrict__ out3)
@@ -837,29 +860,20 @@ __global__ __launch_bounds__(1024) void eval_reduce_kernel(const int32_t *__rest
         an += ndcg[t];
         ah += hits[t];
     }
-    sn[threadIdx.x] = an;
-    sh[threadIdx.x] = ah;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            sn[threadIdx.x] += sn[threadIdx.x + o];
-            sh[threadIdx.x] += sh[threadIdx.x + o];
-        }
-        __syncthreads();
-    }
     __shared__ double ss[1024];
     double as = 0.0;
     for (int t = threadIdx.x; t < URE_SCORE_PARTIALS; t += 1024) as += sse[t];
+    sn[threadIdx.x] = an;
+    sh[threadIdx.x] = ah;
     ss[threadIdx.x] = as;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) ss[threadIdx.x] += ss[threadIdx.x + o];
-        __syncthreads();
-    }
+    tree_head_1024([&](int i, int j) { sn[i] += sn[j]; sh[i] += sh[j]; ss[i] += ss[j]; });
+    if (threadIdx.x >= 64) return;
+    const double tn = tree_tail(sn), ts = tree_tail(ss);
+    const long long th = tree_tail(sh);
     if (threadIdx.x == 0) {
-        out3[0] = sqrt(ss[0] / (double)n_rows);
-        out3[1] = n_users > 0 ? sn[0] / (double)n_users : 0.0;
-        out3[2] = n_users > 0 ? ((double)sh[0] / 10.0) / (double)n_users : 0.0;
+        out3[0] = sqrt(ts / (double)n_rows);
+        out3[1] = n_users > 0 ? tn / (double)n_users : 0.0;
+        out3[2] = n_users > 0 ? ((double)th / 10.0) / (double)n_users : 0.0;
     }
 }
 
@@ -888,32 +902,27 @@ __global__ __launch_bounds__(1024) void eval_subset_kernel(const int32_t *__rest
         ah += hits[u];
     }
     // (a thread per pair, not a thread per user walking its pairs: 50 workgroups of dependent loads took 44 us per call)
-    for (int t0 = threadIdx.x; t0 < n_pairs; t0 += 8 * 1024) {     // (eight pairs in flight per thread; added in index order)
-        float e[8];
+    constexpr int kPairs = 24;                                     // pairs in flight per thread (a fifth of ml-1m's total test set: 20 per thread, one round); added in index order
+    for (int t0 = threadIdx.x; t0 < n_pairs; t0 += kPairs * 1024) {
+        float e[kPairs];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < kPairs; ++k) {
             const int t = t0 + k * 1024;
             const int p = t < n_pairs ? sub_pairs[t] : -1;
             e[k] = p >= 0 ? pred[p] - rating[p] : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) as += (double)(e[k] * e[k]);
+        for (int k = 0; k < kPairs; ++k) as += (double)(e[k] * e[k]);
     }
     sn[threadIdx.x] = an; ss[threadIdx.x] = as; sh[threadIdx.x] = ah; sr[threadIdx.x] = ar;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            sn[threadIdx.x] += sn[threadIdx.x + o];
-            ss[threadIdx.x] += ss[threadIdx.x + o];
-            sh[threadIdx.x] += sh[threadIdx.x + o];
-            sr[threadIdx.x] += sr[threadIdx.x + o];
-        }
-        __syncthreads();
-    }
+    tree_head_1024([&](int i, int j) { sn[i] += sn[j]; ss[i] += ss[j]; sh[i] += sh[j]; sr[i] += sr[j]; });
+    if (threadIdx.x >= 64) return;
+    const double tn = tree_tail(sn), ts = tree_tail(ss);
+    const long long th = tree_tail(sh), tr = tree_tail(sr);
     if (threadIdx.x == 0) {
-        out3[0] = sr[0] > 0 ? sqrt(ss[0] / (double)sr[0]) : 0.0;
-        out3[1] = n_sub > 0 ? sn[0] / (double)n_sub : 0.0;
-        out3[2] = n_sub > 0 ? ((double)sh[0] / 10.0) / (double)n_sub : 0.0;
+        out3[0] = tr > 0 ? sqrt(ts / (double)tr) : 0.0;
+        out3[1] = n_sub > 0 ? tn / (double)n_sub : 0.0;
+        out3[2] = n_sub > 0 ? ((double)th / 10.0) / (double)n_sub : 0.0;
     }
 }
 
