@@ -37,7 +37,8 @@ constexpr int kMtN = 624, kMtM = 397, kMtLag = kMtN - kMtM;      // 227 new word
 constexpr int kDeg = 19937;
 constexpr int kSegBlocks = 1024;                // generator blocks per segment
 constexpr int kChunkBlocks = 8;                 // ... walked eight at a time
-constexpr int kFillBlock = 256;
+constexpr int kFillBlock = 640;                 // ten wavefronts: lanes 0..622 own a word of a generation step, all of them turn outputs into normals
+constexpr int kFillWide = 623;                  // words per dependent step
 constexpr int kJumpLanes = 640;                 // ten wavefronts: lanes 0..623 own a word of the new block
 constexpr int kJumpParts = 4;                   // workgroups per jump, each a quarter of the support's degree range
 constexpr int kJumpPartSpan = (kDeg + kJumpParts - 1) / kJumpParts;
@@ -63,6 +64,12 @@ __device__ __forceinline__ unsigned mt_twist(unsigned a, unsigned b, unsigned fa
 {
     const unsigned y = (a & 0x80000000u) | (b & 0x7fffffffu);
     return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__device__ __forceinline__ unsigned mt_mix(unsigned a, unsigned b)     // (the twist's linear part)
+{
+    const unsigned y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
 
 __device__ __forceinline__ unsigned mt_temper(unsigned x)
@@ -141,9 +148,20 @@ __global__ __launch_bounds__(kFillBlock) void mf_init_fill_kernel(const init_sha
         if (lo >= n_out) break;
         const int64_t hi = lo + kChunkBlocks * kMtN;
         // the chunk's blocks 1 .. 8 behind block 0 (block 8 is the next chunk's block 0 and lends its first words to a straddling 16-block)
-        for (int pos = kMtN; pos < (kChunkBlocks + 1) * kMtN; pos += kMtLag) {
-            const int p = pos + tid;
-            if (tid < kMtLag && p < (kChunkBlocks + 1) * kMtN) w[p] = mt_twist(w[p - kMtN], w[p - kMtN + 1], w[p - kMtLag]);
+        // (the recurrence x[p] = x[p - 227] ^ F(p), F(p) = f(x[p - 624], x[p - 623]), substituted into itself twice: x[p] = x[p - 681] ^ F(p - 454) ^
+        // F(p - 227) ^ F(p) -- 623 new words per barrier, the width x[p - 623] allows, instead of 227; the first 454 words behind block 0 have
+        // no x[p - 681] and take the form with one / two terms.  As csrc/perm_chain.hip's words pass.)
+        for (int g0 = 0; g0 < kChunkBlocks * kMtN; g0 += kFillWide) {
+            const int g = g0 + tid;
+            if (tid < kFillWide && g < kChunkBlocks * kMtN) {
+                const int p = kMtN + g;
+                const bool two = g >= kMtLag, three = g >= 2 * kMtLag;
+                const unsigned a0 = w[p - kMtN], a1 = w[p - kMtN + 1];
+                const unsigned b0 = two ? w[p - kMtLag - kMtN] : 0u, b1 = two ? w[p - kMtLag - kMtN + 1] : 0u;
+                const unsigned c0 = three ? w[p - 2 * kMtLag - kMtN] : 0u, c1 = three ? w[p - 2 * kMtLag - kMtN + 1] : 0u;
+                const unsigned x = w[p - (three ? 3 * kMtLag : two ? 2 * kMtLag : kMtLag)];
+                w[p] = x ^ mt_mix(a0, a1) ^ (two ? mt_mix(b0, b1) : 0u) ^ (three ? mt_mix(c0, c1) : 0u);
+            }
             lds_barrier();
         }
 #pragma unroll 1
