@@ -1133,8 +1133,8 @@ def test_layouts_built_on_a_native_thread_equal_the_blocking_call():
 
 def test_tag_chunks_and_shuffle_choice():
     """rng.default_tag_bounds / rng.shuffle_method (the chunks of epochs a call's device shuffles are launched in, the kernel family per
-    chunk): bounds start at 0, end at the epoch count and rise; a call of small shards starts with one small chunk; shards beyond 2^20
-    rows can only take csrc/perm_chain.hip; URE_SHUFFLE overrides where both apply."""
+    chunk): bounds start at 0, end at the epoch count and rise; a call of small shards starts with one small chunk; csrc/perm_chain.hip makes
+    every chunk unless URE_SHUFFLE=reservations asks for csrc/perm_tags.hip, which shards beyond 2^20 rows cannot take."""
     from ultrare_amd import rng
     for epochs in (1, 2, 3, 50, 126, 1000):
         for S in (1, 2, 5, 16, 32, 200):
@@ -1143,7 +1143,6 @@ def test_tag_chunks_and_shuffle_choice():
                 assert b[0] == 0 and b[-1] == epochs and all(x < y for x, y in zip(b[:-1], b[1:])), (epochs, S, n, b)
     assert rng.default_tag_bounds(50, 5, 180_000) == [0, 12, 50]
     assert rng.default_tag_bounds(3, 1, 22_500_000) == [0, 1, 2, 3]
-    assert rng.shuffle_method(180_000, 250, 'auto') == 'chain' and rng.shuffle_method(56_000, 800, 'auto') == 'reservations'
-    assert rng.shuffle_method(56_000, 64, 'auto') == 'chain'
+    assert rng.shuffle_method(180_000, 250, 'auto') == 'chain' and rng.shuffle_method(56_000, 800, 'auto') == 'chain'
     assert rng.shuffle_method((1 << 20) + 1, 800, 'reservations') == 'chain'
     assert rng.shuffle_method(56_000, 8, 'reservations') == 'reservations' and rng.shuffle_method(56_000, 800, 'chain') == 'chain'

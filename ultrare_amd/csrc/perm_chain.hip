@@ -55,7 +55,7 @@ constexpr int kMaxBuckets = 16384;               // per permutation (LDS counter
 constexpr int kTileBlock = 1024;
 constexpr int kTileLoads = 4;                    // 16-byte loads per lane: a tile of the bucket pass is 16,384 swaps
 constexpr int kTile = kTileBlock * 4 * kTileLoads;
-constexpr int kLinkBlock = 256;
+constexpr int kLinkBlock = 512;
 constexpr int kLinkLoads = 8;                    // pairs a lane of the link pass has in flight
 constexpr int kStage = 6144;                     // members a link workgroup keeps in LDS: three per target of its range (24 KB at 2,048 targets) ...
 constexpr int kStage10 = 3072, kStage12 = 12288; // ... 12 KB at 1,024 targets (eight workgroups per CU), 48 KB at 4,096 and beyond

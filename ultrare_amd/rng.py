@@ -784,13 +784,11 @@ PERM_DTYPE = np.dtype([('seed', '<i8'), ('tags', '<u8'), ('n', '<i4'), ('batch',
 DEVICE_TAGS_MAX_ROWS = 1 << 27      # csrc/perm_chain.hip takes 2^28 (16,384 ranges of 16,384 targets); a row index keeps a bit free here (csrc/perm_tags.hip alone stopped at 2^20)
 RESERVATIONS_MAX_ROWS = 1 << 20     # csrc/perm_tags.hip: a swap's index shares a 32-bit reservation word with the round counter
 DEVICE_TAGS_GROUPS = 256            # workgroups (= permutations at a time) per launch: 32 / 64 / 128 / 256 -> 13.4 / 11.2 / 9.8 / 9.7 ms per 5-shard request, 18.4 / 14.8 / 12.8 / 12.3 at 16 shards
-# Which of the two device shuffles makes a chunk (URE_SHUFFLE=chain / reservations overrides; profiles/r05/exp_shuffle.json):
-#   perm_chain.hip -- many workgroups per permutation, six launches -- has the latency (5 x 180 k rows 0.31 ms against 0.59, one 897 k-row
-#   epoch 0.88 against 3.41), the big shards (50 x 897 k rows 1.98 ms against 4.41; beyond 2^20 rows it is the only one) and, from
-#   ~130 k rows per shard, the throughput too (250 x 180 k rows 1.37 ms against 1.63);
-#   perm_tags.hip -- one workgroup per permutation, one launch -- keeps the many small ones (800 x 56 k rows 1.28 ms against 1.48).
-CHAIN_MIN_ROWS = 1 << 17            # shards beyond this: chain for every chunk
-CHAIN_MAX_PERMS = 128               # smaller shards: chain for chunks of up to this many permutations (the first ones of a request)
+# Which of the two device shuffles makes a chunk (profiles/r05/exp_shuffle.json): csrc/perm_chain.hip -- many workgroups per permutation, six
+# launches -- has the latency (5 x 180 k rows 0.24 ms against 0.59, one 897 k-row epoch 0.76 against 3.42), the big shards (50 x 897 k rows 1.95 ms
+# against 4.39; beyond 2^20 rows it is the only one) and the throughput (250 x 180 k rows 1.27 ms against 1.62; 800 x 56 k rows 1.27 against 1.28):
+# it makes every chunk.  csrc/perm_tags.hip -- one workgroup per permutation, rounds of reservations: round 4's -- stays behind
+# URE_SHUFFLE=reservations (shards of up to 2^20 rows) as the second implementation the first is tested against.
 _PERM_STREAMS = {}
 
 
@@ -804,11 +802,7 @@ def shuffle_method(n_max, n_perms, method=None):
     """-> 'chain' (csrc/perm_chain.hip) or 'reservations' (csrc/perm_tags.hip) for a launch of n_perms permutations of up to n_max rows."""
     import os
     method = method or os.environ.get('URE_SHUFFLE', 'auto')
-    if n_max > RESERVATIONS_MAX_ROWS or method == 'chain':
-        return 'chain'
-    if method == 'reservations':
-        return 'reservations'
-    return 'chain' if (n_max > CHAIN_MIN_ROWS or n_perms <= CHAIN_MAX_PERMS) else 'reservations'
+    return 'reservations' if method == 'reservations' and n_max <= RESERVATIONS_MAX_ROWS else 'chain'
 
 
 def default_tag_bounds(epochs, n_shards, n_max):
