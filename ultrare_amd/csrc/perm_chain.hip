@@ -61,7 +61,7 @@ constexpr int kStage = 6144;                     // members a link workgroup kee
 constexpr int kStage10 = 3072, kStage12 = 12288; // ... 12 KB at 1,024 targets (eight workgroups per CU), 48 KB at 4,096 and beyond
 constexpr int kStageHeavy = 16384;               // ... and one of a permutation's last kHeavyParts buckets (64 KB)
 constexpr int kHeavyParts = 8;
-constexpr int kResolveBlock = 256;
+constexpr int kResolveBlock = 1024;
 constexpr int kResolveRows = 4096;               // rows per workgroup of the resolve pass
 constexpr unsigned kNone = 0xffffffffu;
 constexpr unsigned kGoOn = 0x80000000u;          // H[j] = kGoOn | q: "what swap q fetched"
