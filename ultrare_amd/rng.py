@@ -785,8 +785,8 @@ DEVICE_TAGS_MAX_ROWS = 1 << 27      # csrc/perm_chain.hip takes 2^28 (16,384 ran
 RESERVATIONS_MAX_ROWS = 1 << 20     # csrc/perm_tags.hip: a swap's index shares a 32-bit reservation word with the round counter
 DEVICE_TAGS_GROUPS = 256            # workgroups (= permutations at a time) per launch: 32 / 64 / 128 / 256 -> 13.4 / 11.2 / 9.8 / 9.7 ms per 5-shard request, 18.4 / 14.8 / 12.8 / 12.3 at 16 shards
 # Which of the two device shuffles makes a chunk (profiles/r05/exp_shuffle.json): csrc/perm_chain.hip -- many workgroups per permutation, six
-# launches -- has the latency (5 x 180 k rows 0.24 ms against 0.59, one 897 k-row epoch 0.76 against 3.42), the big shards (50 x 897 k rows 1.95 ms
-# against 4.39; beyond 2^20 rows it is the only one) and the throughput (250 x 180 k rows 1.27 ms against 1.62; 800 x 56 k rows 1.27 against 1.28):
+# launches -- has the latency (5 x 180 k rows 0.23 ms against 0.59, one 897 k-row epoch 0.74 against 3.42), the big shards (50 x 897 k rows 1.89 ms
+# against 4.37; beyond 2^20 rows it is the only one) and the throughput (250 x 180 k rows 1.22 ms against 1.61; 800 x 56 k rows 1.16 against 1.27):
 # it makes every chunk.  csrc/perm_tags.hip -- one workgroup per permutation, rounds of reservations: round 4's -- stays behind
 # URE_SHUFFLE=reservations (shards of up to 2^20 rows) as the second implementation the first is tested against.
 _PERM_STREAMS = {}
