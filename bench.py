@@ -747,9 +747,20 @@ def main():
         dog.cancel()
     else:
         # ---- N = 1 extras (rank 0 is the only rank): CPU baseline and the unlearn half of the metric
+        # (an extra that fails -- a box short of memory, a guard of a measurement tripping -- costs its own object, never the line: the
+        # headline and its roofline are already in `out`)
+        def guarded(key, fn):
+            try:
+                out[key] = fn()
+            except BaseException as e:             # noqa: BLE001  (KeyboardInterrupt included: the line is what the driver reads)
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                prev = out.get(key)                # (what the leg had put into the line before it failed stays)
+                out[key] = dict(prev if isinstance(prev, dict) else {}, error=f'{type(e).__name__}: {e}'[:400])
         if not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline_of(a, leg, a.d, a.batch)
-        if a.workload == 'ml1m' and not a.no_unlearn:
+            guarded('cpu_baseline', lambda: cpu_baseline_of(a, leg, a.d, a.batch))
+        def unlearn_extras():
+            nonlocal job
             job.close()
             leg['job'] = leg['shards'] = job = None
             un, e2e = unlearn_leg(a, leg['data'], a.shards, a.d)
@@ -782,15 +793,21 @@ def main():
             if time.perf_counter() - t_start < a.extras_budget:
                 # the full-MF stage as a request (config.py:182-188; BASELINE.json configs[0]'s shape): its epochs' shuffles made on the device
                 un['run_full'] = e2e.full_request(a.d, 50, data=leg['data'], reps=4)
+            return un
+        if a.workload == 'ml1m' and not a.no_unlearn:
+            guarded('unlearn', unlearn_extras)
         if a.workload == 'ml1m' and not a.no_ot and time.perf_counter() - t_start < a.extras_budget:
-            out['ot'] = ot_leg(a)
+            guarded('ot', lambda: ot_leg(a))
         if a.workload == 'ml1m' and not a.no_hbm_leg and time.perf_counter() - t_start < a.extras_budget:
-            if job is not None:
-                job.close()
-                leg['job'] = leg['shards'] = job = None
-            leg['data'] = None
-            torch.cuda.empty_cache()
-            out['roofline_hbm'] = hbm_leg(a, D)
+            def hbm():
+                nonlocal job
+                if job is not None:
+                    job.close()
+                    leg['job'] = leg['shards'] = job = None
+                leg['data'] = None
+                torch.cuda.empty_cache()
+                return hbm_leg(a, D)
+            guarded('roofline_hbm', hbm)
     emit()
     if D.pg is not None:
         D.pg.destroy_process_group()
