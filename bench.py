@@ -736,14 +736,22 @@ def main():
         dog = threading.Timer(a.extras_timeout, expire)
         dog.daemon = True
         dog.start()
+        # (a leg that raises on this rank costs its own object, not the line; ranks left waiting in a collective are ended by their watchdog)
+        def attempt(key, fn):
+            try:
+                out[key] = fn()
+            except BaseException as e:             # noqa: BLE001
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                out[key] = {'error': f'{type(e).__name__}: {e}'[:400]}
         if not split and job is not None:
-            out['exchange'] = exchange_leg(D, leg, a.d)
+            attempt('exchange', lambda: exchange_leg(D, leg, a.d))
         job and job.close()
         leg['job'] = leg['shards'] = job = None
         torch.cuda.empty_cache()
         which = [] if a.splits == 'none' else (['config2', 'config4', 'config3'] if a.splits == 'auto' else a.splits.split(','))
         if which:
-            out['north_star_splits'] = split_legs(a, D, which)
+            attempt('north_star_splits', lambda: split_legs(a, D, which))
         dog.cancel()
     else:
         # ---- N = 1 extras (rank 0 is the only rank): CPU baseline and the unlearn half of the metric
