@@ -307,7 +307,7 @@ def train_leg(D, workload, n_shards, d, batch, steps, warmup, split, roofline_st
            't_rng': t_rng, 't_tags': t_tags, 't0_tick': r['t0_tick'], 'n_launch': r['n_launch'], 'shards': shards, 'job': job, 'waited_ms': r['waited_ms'],
            'tag_chunks': ([{'epochs': [a_, b_], 'by': m} for a_, b_, m in zip(bounds[:-1], bounds[1:], perms_methods)] if fire else None),
            'value': r['n_total'] / r['wall'] if r['wall'] > 0 else 0.0,
-           'batch_tags': ('device (rng.device_tags -> csrc/perm_chain.hip / perm_tags.hip on two side streams, in the product\'s chunks), launched inside the timed region' if dev_tags else
+           'batch_tags': ('device (rng.device_tags -> csrc/perm_chain.hip on a side stream, in the product\'s chunks), launched inside the timed region' if dev_tags else
                           'host-made, resident before the timed region'),
            'shuffles_in_timed_region': shuffles_timed, 'resident': resident}
     if not keep_job and job is not None:

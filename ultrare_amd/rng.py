@@ -828,8 +828,8 @@ def default_tag_bounds(epochs, n_shards, n_max):
 
 def device_tags(tasks, bounds=None, defer=False, method=None):
     """The batch tags of a call's shards made on the DEVICE instead of by host threads: the seeds come by skip-ahead
-    (_DrawsTask.seeds_first), every (shard, epoch) is one entry of ONE descriptor table, and the epochs go out in a few launches on two
-    side streams -- chunk c of all shards together, by ure_device_shuffle_tags (csrc/perm_chain.hip) or ure_device_randperm_tags
+    (_DrawsTask.seeds_first), every (shard, epoch) is one entry of ONE descriptor table, and the epochs go out in a few launches on a
+    side stream -- chunk c of all shards together, by ure_device_shuffle_tags (csrc/perm_chain.hip) or ure_device_randperm_tags
     (csrc/perm_tags.hip), whichever suits the chunk (shuffle_method) --, each with the event TrainJob.run waits for before the launches
     that read it.  No host buffer, no upload, no expansion threads.  -> False when a shard cannot take this path (no tags, more than 2^27
     rows, tables too small to skip ahead): the caller falls back to the host path for the whole call.
@@ -872,13 +872,14 @@ def device_tags(tasks, bounds=None, defer=False, method=None):
     launches, at_row = [], 0
     for c, (c0, c1) in enumerate(zip(bounds[:-1], bounds[1:])):
         n_p = S * (c1 - c0)
-        launches.append((c1, at_row, at_row + n_p, shuffle_method(n_max, n_p, method), c & 1))      # (chunks alternate between the two side streams)
+        launches.append((c1, at_row, at_row + n_p, shuffle_method(n_max, n_p, method), 0))          # (one side stream: chunks alternating between two ran beside each other and took
+                                                                                        # longer each -- 12.8 against 9.2 ms of shuffle kernels per six requests, the 16-shard request 11.7 against 9.3 ms)
         at_row += n_p
     mark('tags: table')
     L = nv.lib()
     sides = _PERM_STREAMS.get(str(dev))
     if sides is None:
-        sides = _PERM_STREAMS[str(dev)] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))      # (stream priorities change nothing here: measured, profiles/r05/NOTES.md)
+        sides = _PERM_STREAMS[str(dev)] = (torch.cuda.Stream(dev),)      # (stream priorities change nothing here: measured, profiles/r05/NOTES.md)
     # scratch per (side stream, method): the launches of a stream follow each other, so they share it
     scratch, flags, keep = {}, [], [dev_all]
     for _, lo, hi, how, side in launches:
