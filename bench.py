@@ -341,7 +341,7 @@ def roofline_of(a, leg, d, batch):
     b_sparse = 16 + 16 * dp
     alg20 = float((per_tick * b_sparse + dense20).sum()) / n_launch
     alg16 = float((per_tick * b_sparse + dense20 * 16 // 20).sum()) / n_launch
-    # the region holds the epochs' shuffles on the side streams and, on the launch stream, the waits for their chunks: the step kernel's
+    # the region holds the epochs' shuffles on the side stream and, on the launch stream, the waits for their chunks: the step kernel's
     # own duration is the region minus those waits (event pairs around them) over its launches -- what rocprofv3 reads for the kernel
     avg_ms = (leg['dev_ms'] - leg.get('waited_ms', 0.0)) / n_launch
     res = leg.get('resident')
@@ -559,7 +559,7 @@ def fullmf_leg(a, D, data):
     init = tuple(t * 0.3 for t in rng.mf_init(spec_u, spec_i, 128))          # (0.3: predictions of +-1 at the start, the tables stay finite)
     E = 3
     # the epochs' batch tags as Scratch.train gets them: made on the device (rng.epoch_tags_device -> csrc/perm_chain.hip; 22.5 M rows are
-    # beyond perm_tags.hip's 2^20), a launch per epoch on the side streams, inside this leg; the host's Fisher-Yates only under URE_DEVICE_TAGS=0
+    # beyond perm_tags.hip's 2^20), a launch per epoch on the side stream, inside this leg; the host's Fisher-Yates only under URE_DEVICE_TAGS=0
     seeds = rng.epoch_seeds(E, True)
     torch.cuda.synchronize()
     t_sh = time.perf_counter()
