@@ -773,8 +773,12 @@ hipError_t block_malloc(void **out, size_t bytes)
 void block_free(void *p)
 {
     if (!p) return;
+    // (the device the block lives on, not the calling thread's current one: a job is destroyed on a worker thread, whose current device is 0
+    // whatever GPU its rank trains on)
     int dev = 0;
-    (void)hipGetDevice(&dev);
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;
+    else { (void)hipGetLastError(); (void)hipGetDevice(&dev); }
     {
         std::lock_guard<std::mutex> hold(g_block_lock);
         BlockCache &C = g_block_cache[dev];
