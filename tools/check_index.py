@@ -85,13 +85,16 @@ if __name__ == '__main__':
     G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'toy', '0_train.csv')
     raw = O.load_csv(G)
     part = O.partition(*raw, O.uniform_groups(1508, 1))[0]
-    k, B, E = 16, 437, 4
-    torch.manual_seed(11)
-    init = rng.mf_init(1508, 2071, k)
-    perms = rng.epoch_perms(rng.epoch_seeds(E, True), len(part[0]))
-    job = engine.TrainJob([engine.ShardData(*part, 1508, 2071)], [init], [perms], k, B, E, 1e-3, 0.1, 0.9, 0.95, touch='index')
-    steps = job.steps_per_epoch(0)
-    for e in range(E):          # the index a shard's steps read is the one of its current epoch (two sets, by epoch parity)
-        job.run(1)
-        print('epoch', e, 'items', check(job, 0, part, perms[e].numpy(), B))
-        job.run(steps - 1)
+    k, E = 16, 4
+    for B in (437, 3000, 37):       # 65 steps per epoch (two mask words); 10 (the short-epoch sort: chunks of 1,024); 762 (thirteen words)
+        print('B', B)
+        torch.manual_seed(11)
+        init = rng.mf_init(1508, 2071, k)
+        perms = rng.epoch_perms(rng.epoch_seeds(E, True), len(part[0]))
+        job = engine.TrainJob([engine.ShardData(*part, 1508, 2071)], [init], [perms], k, B, E, 1e-3, 0.1, 0.9, 0.95, touch='index')
+        steps = job.steps_per_epoch(0)
+        for e in range(E):          # the index a shard's steps read is the one of its current epoch (two sets, by epoch parity)
+            job.run(1)
+            print('epoch', e, 'items', check(job, 0, part, perms[e].numpy(), B))
+            job.run(steps - 1)
+        job.close()

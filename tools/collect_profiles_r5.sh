@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything profiles/r05/ holds, on the GPU box:  bash tools/collect_profiles_r5.sh [part ...]   (parts: bench stats pmc e2e fullmf cfg4 big multirank shuffle; default all)
+# Everything profiles/r05/ holds, on the GPU box:  bash tools/collect_profiles_r5.sh [part ...]   (parts: bench stats pmc e2e fullmf k16 cfg4 big multirank shuffle; default all)
 # Writes gpurun_out/profiles_r05/ ; copy what should be judged into profiles/r05/.
 # rocprofv3 runs the program itself after `--` (python3 <script>), kernel-trace / stats only; the PMC passes are separate
 # runs (tools/pmc_traffic.py), never combined with another tracing domain.
@@ -7,7 +7,7 @@ TAG=r05
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
-PARTS=${*:-bench stats pmc e2e fullmf cfg4 big multirank shuffle}
+PARTS=${*:-bench stats pmc e2e fullmf k16 cfg4 big multirank shuffle}
 cd /tmp && export TMPDIR=/tmp
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 stats() {   # name, [VAR=VALUE ...] script, args...
@@ -65,6 +65,10 @@ if has fullmf; then
   timeout -k 10 500 python3 "$ROOT/bench.py" $ARGS > "$OUT/fullmf25m_d128_index.json" 2> /dev/null; echo "fullmf index rc=$?"
   URE_TOUCH_INDEX=0 timeout -k 10 500 python3 "$ROOT/bench.py" $ARGS > "$OUT/fullmf25m_d128_touch_windows.json" 2> /dev/null; echo "fullmf windows rc=$?"
   stats fullmf_index "$ROOT/tools/exp_index.py" --epochs 3
+fi
+if has k16; then
+  # BASELINE.json configs[3]'s 32 shards at k = 16 (25-27 steps per epoch: touch_mode 3 with the short-epoch scatter), per kernel
+  stats cfg3_d16_index "$ROOT/bench.py" --workload ml25m --shards 32 --d 16 --no-cpu-baseline --no-unlearn --no-hbm-leg --steps 3 --warmup 1
 fi
 if has multirank; then
   timeout -k 10 500 python3 "$ROOT/tools/multirank_timeline.py" > "$OUT/multirank_timeline_2ranks_ml25m_k128.json" 2> "$OUT/multirank.err"; echo "multirank rc=$?"

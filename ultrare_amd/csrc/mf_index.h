@@ -39,8 +39,9 @@ namespace ure {
 constexpr int kIdxWin = 63;                     // steps per mask word
 constexpr int kIdxMaxWords = 16;
 constexpr int kIdxMaxSteps = kIdxWin * kIdxMaxWords;
-constexpr int kIdxChunk = 4096;                 // slots one wavefront sorts: 64 batches of 64
+constexpr int kIdxChunk = 4096;                 // slots of a sort chunk: 64 batches of 64 (shard_aux: idx_chunk -- 1,024 in jobs of short epochs, idx_scatter_short_kernel)
 constexpr int kIdxSeg = 32;                     // segments of the scan over chunks
+constexpr int kIdxScanBatch = 16;               // counts a thread of the scan has in flight
 constexpr int kIdxFlagBlock = 2048;             // sorted slots per workgroup of the mark / emit passes
 constexpr int kIdxHeavyMax = 256;               // rows that whole workgroups take (a prefix of the schedule)
 constexpr int kIdxPart = 256;                   // slots per workgroup of a split row
@@ -67,6 +68,25 @@ __device__ __forceinline__ int idx_epoch_start(const ure_shard_t &S, const shard
 
 __device__ __forceinline__ int idx_buffer_at(unsigned long long word, int b) { return (int)(word >> 63) ^ (__popcll(word & kIdxBits & mask_below(b)) & 1); }
 
+// What a sorted slot carries of its OWN row's step, in the bits above the class of the record's last word (every slot of a (step, row) run the same;
+// idx_emit_kernel copies them into the run's item): the buffer the row's weights are in at the step, and the steps that pass until the row is trained
+// next (none left in the epoch: until it ends).  The scatter reads them where they are cheap -- its slots come row by row, a wavefront's loads fall into
+// a handful of lines -- where the items, in (step, row) order, gathered a mask word and a next_first entry each (28 M of each at the 25 M shape).
+constexpr int kIdxOwnBufBit = 18, kIdxGapShift = 19;       // (step: bits 0-9 of 16, class: 16-17, gap: at most 1,007)
+__device__ __forceinline__ unsigned idx_own_pack(unsigned long long word, int nxt, unsigned tag)
+{
+    const int b = (int)(tag % kIdxWin);
+    const unsigned long long rest = (word & kIdxBits) >> (b + 1);
+    const int gap = rest ? __ffsll((long long)rest) - 1 : nxt - (int)tag - 1;
+    return (unsigned)idx_buffer_at(word, b) << kIdxOwnBufBit | (unsigned)gap << kIdxGapShift;
+}
+__device__ __forceinline__ unsigned idx_own_bits(const shard_aux &A, int n_all, int row, unsigned tag)
+{
+    const size_t at = (size_t)(tag / kIdxWin) * n_all + row;
+    // (epochs of one mask word: no later word, the row waits until the epoch ends)
+    return idx_own_pack(ldg(A.W + at), A.idx_words > 1 ? (int)ldg(A.next_first + at) : A.steps, tag);
+}
+
 // ---- once per job: which row owns every group of 8 slots (segments lie in schedule order, 8-aligned)
 __global__ __launch_bounds__(kBlock) void idx_grp_row_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux)
 {
@@ -86,17 +106,19 @@ __global__ __launch_bounds__(kBlock) void idx_grp_row_kernel(const ure_shard_t *
     }
 }
 
-// ---- epoch start 1: the step masks of every row.  Workgroup c takes the slots [4096 c, 4096 (c + 1)).
+// ---- epoch start 1: the step masks of every row.  Workgroup c takes the slots [2048 c, 2048 (c + 1)) (at most 256 rows: 32 KB of LDS, five
+// workgroups per CU -- with the sort's chunks of 4,096 it was two, and the kernel a chain of memory latencies: 118 us per epoch at the 25 M shape).
+constexpr int kIdxMaskChunk = 2048;
 __global__ __launch_bounds__(kBlock) void idx_masks_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
 {
-    __shared__ unsigned long long bits[(kIdxChunk / 8) * kIdxMaxWords];       // [rows of the chunk][words]: 64 KB
+    __shared__ unsigned long long bits[(kIdxMaskChunk / 8) * kIdxMaxWords];   // [rows of the chunk][words]
     const ure_shard_t &S = shards[blockIdx.y];
     const shard_aux &A = aux[blockIdx.y];
     const int epoch = idx_epoch_start(S, A, tick);
-    if (epoch < 0 || (int)blockIdx.x >= A.idx_chunks) return;
-    const int words = A.idx_words, steps = A.steps;
     const int64_t n_grp = S.n_slots / 8;
-    const int64_t g_lo = (int64_t)blockIdx.x * (kIdxChunk / 8), g_hi = min(g_lo + kIdxChunk / 8, n_grp);
+    const int64_t g_lo = (int64_t)blockIdx.x * (kIdxMaskChunk / 8), g_hi = min(g_lo + kIdxMaskChunk / 8, n_grp);
+    if (epoch < 0 || g_lo >= n_grp) return;
+    const int words = A.idx_words, steps = A.steps;
     const int idx0 = ldg(A.grp_row + 2 * g_lo);
     const int n_rows = ldg(A.grp_row + 2 * (g_hi - 1)) - idx0 + 1;
     for (int t = threadIdx.x; t < n_rows * words; t += kBlock) bits[t] = 0ull;
@@ -124,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void idx_masks_kernel(const ure_shard_t *__
     }
 }
 
-// the words of the rows that straddle chunks are ORed into memory: they start from zero.  One thread per (word, chunk edge).
+// the words of the rows that straddle the masks' chunks are ORed into memory: they start from zero.  One thread per (word, chunk edge).
 __global__ __launch_bounds__(kBlock) void idx_clear_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
 {
     const ure_shard_t &S = shards[blockIdx.y];
@@ -132,15 +154,18 @@ __global__ __launch_bounds__(kBlock) void idx_clear_kernel(const ure_shard_t *__
     if (idx_epoch_start(S, A, tick) < 0) return;
     const int n_all = S.n_user + S.n_item;
     const int64_t n_grp = S.n_slots / 8;
-    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < (int64_t)A.idx_chunks * 2; t += (int64_t)gridDim.x * kBlock) {
+    const int64_t chunks = (n_grp + kIdxMaskChunk / 8 - 1) / (kIdxMaskChunk / 8);
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < chunks * 2; t += (int64_t)gridDim.x * kBlock) {
         const int64_t c = t >> 1;
-        const int64_t g = (t & 1) ? min((c + 1) * (kIdxChunk / 8), n_grp) - 1 : c * (kIdxChunk / 8);      // the chunk's first / last group
+        const int64_t g = (t & 1) ? min((c + 1) * (kIdxMaskChunk / 8), n_grp) - 1 : c * (kIdxMaskChunk / 8);      // the chunk's first / last group
         const int row_id = ldg(A.grp_row + 2 * g + 1);
         for (int w = 0; w < A.idx_words; ++w) stg(A.W + (size_t)w * n_all + row_id, 0ull);
     }
 }
 
-// ---- epoch start 2: bit 63 of every word, the first step, the buffer at the epoch's end.  One thread per active row.
+// ---- epoch start 2: bit 63 of every word, the first step, the buffer at the epoch's end.  One thread per ROW ID (rows without interactions in
+// the shard have words of zeros -- the masks' memory is cleared when the job is made and only active rows are ever written -- and get "no step"):
+// in schedule order every load and store below was a gather (126 us per epoch at the 25 M shape).
 __global__ __launch_bounds__(kBlock) void idx_parity_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
 {
     const ure_shard_t &S = shards[blockIdx.y];
@@ -148,25 +173,28 @@ __global__ __launch_bounds__(kBlock) void idx_parity_kernel(const ure_shard_t *_
     const int epoch = idx_epoch_start(S, A, tick);
     if (epoch < 0) return;
     const int n_all = S.n_user + S.n_item;
-    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < S.n_active; idx += gridDim.x * kBlock) {
-        const int row_id = ldg(S.sched + 4 * (size_t)idx);
+    for (int row_id = blockIdx.x * kBlock + threadIdx.x; row_id < n_all; row_id += gridDim.x * kBlock) {
         int par = 0, first = A.steps;
-        for (int w = 0; w < A.idx_words; ++w) {
-            unsigned long long *p = A.W + (size_t)w * n_all + row_id;
-            const unsigned long long v = ldg(p) & kIdxBits;
-            if (v && first == A.steps) first = w * kIdxWin + __ffsll((long long)v) - 1;
-            stg(p, v | ((unsigned long long)par << 63));
-            par ^= __popcll(v) & 1;
+        unsigned long long v[kIdxMaxWords];
+#pragma unroll
+        for (int w = 0; w < kIdxMaxWords; ++w) v[w] = w < A.idx_words ? ldg(A.W + (size_t)w * n_all + row_id) & kIdxBits : 0ull;
+#pragma unroll
+        for (int w = 0; w < kIdxMaxWords; ++w) {
+            if (w >= A.idx_words) break;
+            if (v[w] && first == A.steps) first = w * kIdxWin + __ffsll((long long)v[w]) - 1;
+            stg(A.W + (size_t)w * n_all + row_id, v[w] | ((unsigned long long)par << 63));
+            par ^= __popcll(v[w]) & 1;
         }
         stg(A.first_step + row_id, (uint16_t)first);
         stg(A.end_par[epoch & 1] + row_id, (uint8_t)par);
-        // next_first[w][row] = the row's first own step in the words after w (steps: none): what the item of a row's LAST step of
-        // word w needs to know how long the row then waits (idx_emit_kernel)
+        // next_first[w][row] = the row's first own step in the words after w (steps: none): what a slot of a row's LAST step of
+        // word w needs to know how long the row then waits (idx_own_bits)
         int nxt = A.steps;
-        for (int w = A.idx_words - 1; w >= 0; --w) {
+#pragma unroll
+        for (int w = kIdxMaxWords - 1; w >= 0; --w) {
+            if (w >= A.idx_words) continue;
             stg(A.next_first + (size_t)w * n_all + row_id, (uint16_t)nxt);
-            const unsigned long long v = ldg(A.W + (size_t)w * n_all + row_id) & kIdxBits;
-            if (v) nxt = w * kIdxWin + __ffsll((long long)v) - 1;
+            if (v[w]) nxt = w * kIdxWin + __ffsll((long long)v[w]) - 1;
         }
     }
 }
@@ -186,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void idx_hist_kernel(const ure_shard_t *__r
     for (int s = lane; s < steps; s += kWave) mine[s] = 0u;
     __builtin_amdgcn_wave_barrier();
     const uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, epoch);
-    const int64_t lo = (int64_t)c * kIdxChunk, hi = min(lo + kIdxChunk, S.n_slots);
+    const int64_t lo = (int64_t)c * A.idx_chunk, hi = min(lo + A.idx_chunk, S.n_slots);
     for (int64_t p = lo + lane * 8; p < hi; p += kWave * 8) {
         const uint4 t4 = ldg_u4(ent_tag + p);
         const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
@@ -217,7 +245,13 @@ __global__ __launch_bounds__(kBlock) void idx_scan1_kernel(const ure_shard_t *__
     int c0, c1;
     idx_seg_range(A, (int)blockIdx.y, &c0, &c1);
     unsigned sum = 0;
-    for (int c = c0; c < c1; ++c) sum += ldg(A.hist + (size_t)c * (A.steps + 1) + s);
+    for (int c = c0; c < c1; c += kIdxScanBatch) {               // (a batch of loads in flight per thread: the walk is a chain of memory latencies otherwise)
+        unsigned t[kIdxScanBatch];
+#pragma unroll
+        for (int k = 0; k < kIdxScanBatch; ++k) t[k] = c + k < c1 ? ldg(A.hist + (size_t)(c + k) * (A.steps + 1) + s) : 0u;
+#pragma unroll
+        for (int k = 0; k < kIdxScanBatch; ++k) sum += t[k];
+    }
     stg(A.seg + (size_t)blockIdx.y * (A.steps + 1) + s, sum);
 }
 // one workgroup per shard: step_begin = exclusive prefix of the steps' totals; seg[y][s] <- where segment y's slots of step s start
@@ -229,8 +263,12 @@ __global__ __launch_bounds__(1024) void idx_scan2_kernel(const ure_shard_t *__re
     if (idx_epoch_start(S, A, tick) < 0) return;
     const int s = threadIdx.x, steps = A.steps;
     unsigned mine = 0;
-    if (s < steps)
-        for (int y = 0; y < kIdxSeg; ++y) mine += ldg(A.seg + (size_t)y * (steps + 1) + s);
+    unsigned t[kIdxSeg];
+#pragma unroll
+    for (int y = 0; y < kIdxSeg; ++y) {
+        t[y] = s < steps ? ldg(A.seg + (size_t)y * (steps + 1) + s) : 0u;
+        mine += t[y];
+    }
     tot[s] = mine;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
@@ -243,11 +281,10 @@ __global__ __launch_bounds__(1024) void idx_scan2_kernel(const ure_shard_t *__re
     if (s < steps) {
         stg(A.step_begin + s, begin);
         unsigned run = begin;
+#pragma unroll
         for (int y = 0; y < kIdxSeg; ++y) {
-            uint32_t *p = A.seg + (size_t)y * (steps + 1) + s;
-            const unsigned t = ldg(p);
-            stg(p, run);
-            run += t;
+            stg(A.seg + (size_t)y * (steps + 1) + s, run);
+            run += t[y];
         }
     }
     if (s == steps) { stg(A.step_begin + steps, begin); stg(A.step_begin + steps + 1, begin); }      // sorted slots in all (s == steps <= 1008 < 1024)
@@ -261,11 +298,16 @@ __global__ __launch_bounds__(kBlock) void idx_scan3_kernel(const ure_shard_t *__
     int c0, c1;
     idx_seg_range(A, (int)blockIdx.y, &c0, &c1);
     unsigned run = ldg(A.seg + (size_t)blockIdx.y * (A.steps + 1) + s);
-    for (int c = c0; c < c1; ++c) {
-        uint32_t *p = A.hist + (size_t)c * (A.steps + 1) + s;
-        const unsigned t = ldg(p);
-        stg(p, run);
-        run += t;
+    // (the loads of a batch before its stores: one load, one store at a time was 343 memory latencies in a row -- 85 us per epoch at the 25 M shape)
+    for (int c = c0; c < c1; c += kIdxScanBatch) {
+        unsigned t[kIdxScanBatch];
+#pragma unroll
+        for (int k = 0; k < kIdxScanBatch; ++k) t[k] = c + k < c1 ? ldg(A.hist + (size_t)(c + k) * (A.steps + 1) + s) : 0u;
+#pragma unroll
+        for (int k = 0; k < kIdxScanBatch; ++k) {
+            if (c + k < c1) stg(A.hist + (size_t)(c + k) * (A.steps + 1) + s, run);
+            run += t[k];
+        }
     }
 }
 
@@ -286,7 +328,7 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_kernel(const ure_shard_t *
     for (int s = lane; s < steps; s += kWave) mine[s] = ldg(off + s);
     __builtin_amdgcn_wave_barrier();
     const uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, epoch);
-    const int64_t lo = (int64_t)c * kIdxChunk, hi = min(lo + kIdxChunk, S.n_slots);
+    const int64_t lo = (int64_t)c * A.idx_chunk, hi = min(lo + A.idx_chunk, S.n_slots);
     const unsigned long long below = (1ull << lane) - 1ull;
     const int n_all = S.n_user + S.n_item;
     // Two stages ahead of the running offsets (nothing of either depends on them): what a batch reads of the row-major arrays is
@@ -311,17 +353,20 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_kernel(const ure_shard_t *
         const int other = b.row >= S.n_user ? b.oid : S.n_user + b.oid;
         return ldg(A.W + (size_t)(b.tag / kIdxWin) * n_all + other);
     };
+    auto own_of = [&](const Batch &b) { return b.tag < (unsigned)steps ? idx_own_bits(A, n_all, b.row, b.tag) : 0u; };
     Batch cur = fetch(lo + lane), nxt = fetch(lo + kWave + lane);
     unsigned long long cur_word = word_of(cur);
+    unsigned cur_own = own_of(cur);
     for (int64_t p0 = lo; p0 < hi; p0 += kWave) {
         const Batch far = fetch(p0 + 2 * kWave + lane);
         const unsigned long long nxt_word = word_of(nxt);
+        const unsigned nxt_own = own_of(nxt), own = cur_own;
         const unsigned tag = cur.tag;
         const int idx = cur.idx, row = cur.row;
         const float r = cur.r;
         const bool valid = tag < (unsigned)steps;
         const int oid = cur.oid | (valid ? idx_buffer_at(cur_word, (int)(tag % kIdxWin)) << 31 : 0);
-        cur = nxt; cur_word = nxt_word; nxt = far;
+        cur = nxt; cur_word = nxt_word; cur_own = nxt_own; nxt = far;
         const int cls = idx < S.n_split ? kIdxSplit : idx < S.n_multi ? kIdxHeavy : kIdxLight;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -334,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_kernel(const ure_shard_t *
             const unsigned base = mine[tag];                            // (all peers read before their first lane writes: LDS runs a wave's accesses in order)
             const int rank = __popcll(peers & below);
             if (rank == 0) mine[tag] = base + (unsigned)__popcll(peers);
-            stg_u4(A.sslot + (size_t)(base + rank), make_uint4((unsigned)oid, __float_as_uint(r), (unsigned)row, tag | ((unsigned)cls << 16)));
+            stg_u4(A.sslot + (size_t)(base + rank), make_uint4((unsigned)oid, __float_as_uint(r), (unsigned)row, tag | ((unsigned)cls << 16) | own));
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -354,9 +399,20 @@ constexpr int kIdxStagedWaves = URE_INDEX_STAGED_WAVES;   // wavefronts that sor
 #define URE_INDEX_STAGED_COMPACT 1
 #endif
 
+#ifndef URE_INDEX_SHORT_COMPACT
+#define URE_INDEX_SHORT_COMPACT 1
+#endif
+#ifndef URE_INDEX_SHORT_ROUND
+#define URE_INDEX_SHORT_ROUND 8
+#endif
+// COMPACT: the stage holds a word per slot -- where the slot is among the 1,024, its step, the buffer bit of its opposite row, the bits of its own
+// row's step -- and the record is put together on the way out (loads of lines the wavefront has just read): 4 KB of LDS per wavefront instead of
+// 16, so that the wavefronts a CU holds are bounded by registers, not by LDS (two per SIMD before)
+template <bool COMPACT, int ROUND>
 __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
 {
-    __shared__ uint4 stage[kWavesPerBlock][kIdxStage];
+    __shared__ uint4 stage[COMPACT ? 1 : kWavesPerBlock][COMPACT ? 1 : kIdxStage];
+    __shared__ unsigned stage_c[COMPACT ? kWavesPerBlock : 1][COMPACT ? kIdxStage : 1];
     __shared__ unsigned goff[kWavesPerBlock][64], lcnt[kWavesPerBlock][64], lstart[kWavesPerBlock][64], lfill[kWavesPerBlock][64];
     const ure_shard_t &S = shards[blockIdx.y];
     const shard_aux &A = aux[blockIdx.y];
@@ -365,13 +421,14 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_sha
     const int c = (int)blockIdx.x * kWavesPerBlock + wave;
     if (epoch < 0 || c >= A.idx_chunks) return;
     const int steps = A.steps;                                      // <= 63: a step is its own lane below
-    uint4 *st = stage[wave];
+    uint4 *st = stage[COMPACT ? 0 : wave];
+    unsigned *stc = stage_c[COMPACT ? wave : 0];
     unsigned *g_off = goff[wave], *l_cnt = lcnt[wave], *l_start = lstart[wave], *l_fill = lfill[wave];
     g_off[lane] = lane < steps ? ldg(A.hist + (size_t)c * (steps + 1) + lane) : 0u;
     l_cnt[lane] = 0u;
     __builtin_amdgcn_wave_barrier();
     const uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, epoch);
-    const int64_t lo = (int64_t)c * kIdxChunk, hi = min(lo + kIdxChunk, S.n_slots);
+    const int64_t lo = (int64_t)c * A.idx_chunk, hi = min(lo + A.idx_chunk, S.n_slots);
     const unsigned long long below = (1ull << lane) - 1ull;
     const int n_all = S.n_user + S.n_item;
     struct Batch { unsigned tag; int oid, idx, row; float r; };
@@ -380,7 +437,7 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_sha
         if (p < hi) {
             b.tag = ldg(ent_tag + p);
             b.oid = ldg(S.ent_oid + p);
-            b.r = ldg(S.ent_r + p);
+            if (!COMPACT) b.r = ldg(S.ent_r + p);
             const ure_i2 g = *(const ure_i2 URE_AS1 *)(A.grp_row + 2 * (p >> 3));
             const int gi = g.x, gr = g.y;
             b.idx = gi; b.row = gr;
@@ -392,25 +449,13 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_sha
         const int other = b.row >= S.n_user ? b.oid : S.n_user + b.oid;
         return ldg(A.W + (size_t)(b.tag / kIdxWin) * n_all + other);
     };
-    // the staged slots leave in sorted order: slot i of the stage belongs to the step whose range [l_start, l_start + l_cnt) holds i
-    auto flush = [&]() {
-        const unsigned total = l_start[63] + l_cnt[63];
-        for (unsigned i = lane; i < total; i += kWave) {
-            const uint4 rec = st[i];
-            const unsigned tag = rec.w & 0xFFFFu;
-            stg_u4(A.sslot + (size_t)(g_off[tag] + (i - l_start[tag])), rec);
-        }
-        __builtin_amdgcn_wave_barrier();
-        g_off[lane] += l_cnt[lane];
-        l_cnt[lane] = 0u;
-        __builtin_amdgcn_wave_barrier();
-    };
     // Eight batches at a time: their loads of the row-major arrays go out together, then the eight gathers of the opposite rows' mask
     // words, then the batches are placed one after the other -- the two memory levels are paid once per 512 slots, not per 64.
-    constexpr int kRound = 8;
+    constexpr int kRound = ROUND;
     for (int64_t s0 = lo; s0 < hi; s0 += kIdxStage) {
+        const int64_t s1 = min(s0 + kIdxStage, hi);
         // the counts of these 1,024 slots per step (their tags once more: 2 KB, in the caches), then the exclusive prefix over the steps
-        for (int64_t p = s0 + lane * 8; p < min(s0 + kIdxStage, hi); p += kWave * 8) {
+        for (int64_t p = s0 + lane * 8; p < s1; p += kWave * 8) {
             const uint4 t4 = ldg_u4(ent_tag + p);
             const unsigned tw[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
@@ -430,19 +475,22 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_sha
         l_start[lane] = incl - mine_n;
         l_fill[lane] = incl - mine_n;
         __builtin_amdgcn_wave_barrier();
-        for (int64_t r0 = s0; r0 < min(s0 + kIdxStage, hi); r0 += kRound * kWave) {
+        for (int64_t r0 = s0; r0 < s1; r0 += kRound * kWave) {
             Batch bt[kRound];
             unsigned long long wd[kRound];
+            unsigned own[kRound];
 #pragma unroll
             for (int k = 0; k < kRound; ++k) bt[k] = fetch(r0 + k * kWave + lane);
 #pragma unroll
-            for (int k = 0; k < kRound; ++k) wd[k] = word_of(bt[k]);
+            for (int k = 0; k < kRound; ++k) {
+                wd[k] = word_of(bt[k]);
+                own[k] = bt[k].tag < (unsigned)steps ? idx_own_bits(A, n_all, bt[k].row, bt[k].tag) : 0u;
+            }
 #pragma unroll
             for (int k = 0; k < kRound; ++k) {
                 const unsigned tag = bt[k].tag;
                 const bool valid = tag < (unsigned)steps;
-                const int oid = bt[k].oid | (valid ? idx_buffer_at(wd[k], (int)(tag % kIdxWin)) << 31 : 0);
-                const int cls = bt[k].idx < S.n_split ? kIdxSplit : bt[k].idx < S.n_multi ? kIdxHeavy : kIdxLight;
+                const unsigned opp = valid ? (unsigned)idx_buffer_at(wd[k], (int)(tag % kIdxWin)) : 0u;
                 unsigned long long peers = __ballot(valid);
 #pragma unroll
                 for (int b = 0; b < 6; ++b) {                               // (tags below 64)
@@ -454,12 +502,39 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_sha
                     const unsigned base = l_fill[tag];                      // (all peers read before their first lane writes: LDS runs a wave's accesses in order)
                     const int rank = __popcll(peers & below);
                     if (rank == 0) l_fill[tag] = base + (unsigned)__popcll(peers);
-                    st[base + rank] = make_uint4((unsigned)oid, __float_as_uint(bt[k].r), (unsigned)bt[k].row, tag | ((unsigned)cls << 16));
+                    if (COMPACT) {
+                        // slot among the 1,024 | step << 10 | opposite row's buffer << 16 | own row's buffer << 17 | gap << 18 (steps, gaps below 64)
+                        stc[base + rank] = (unsigned)(r0 + k * kWave + lane - s0) | tag << 10 | opp << 16 | (own[k] >> kIdxOwnBufBit) << 17;
+                    } else {
+                        const int cls = bt[k].idx < S.n_split ? kIdxSplit : bt[k].idx < S.n_multi ? kIdxHeavy : kIdxLight;
+                        st[base + rank] = make_uint4((unsigned)bt[k].oid | opp << 31, __float_as_uint(bt[k].r), (unsigned)bt[k].row, tag | ((unsigned)cls << 16) | own[k]);
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        flush();
+        // the staged slots leave in sorted order: slot i of the stage belongs to the step whose range [l_start, l_start + l_cnt) holds i
+        const unsigned total = l_start[63] + l_cnt[63];
+        for (unsigned i = lane; i < total; i += kWave) {
+            uint4 rec;
+            if (COMPACT) {
+                const unsigned v = stc[i];
+                const int64_t p = s0 + (int64_t)(v & 1023u);
+                const ure_i2 g = *(const ure_i2 URE_AS1 *)(A.grp_row + 2 * (p >> 3));
+                const int gi = g.x, gr = g.y;
+                const int cls = gi < S.n_split ? kIdxSplit : gi < S.n_multi ? kIdxHeavy : kIdxLight;
+                rec = make_uint4((unsigned)ldg(S.ent_oid + p) | ((v >> 16) & 1u) << 31, __float_as_uint(ldg(S.ent_r + p)), (unsigned)gr,
+                                 ((v >> 10) & 63u) | ((unsigned)cls << 16) | (v >> 17) << kIdxOwnBufBit);
+            } else {
+                rec = st[i];
+            }
+            const unsigned tag = rec.w & 0xFFFFu;
+            stg_u4(A.sslot + (size_t)(g_off[tag] + (i - l_start[tag])), rec);
+        }
+        __builtin_amdgcn_wave_barrier();
+        g_off[lane] += l_cnt[lane];
+        l_cnt[lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -477,6 +552,7 @@ __global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const
     // put together when the chunk leaves (three loads of lines this workgroup has just read): 16 KB instead of 64, two workgroups per CU
     __shared__ uint4 stage[COMPACT ? 1 : kIdxChunk];
     __shared__ unsigned stage_c[COMPACT ? kIdxChunk : 1];
+    __shared__ uint16_t stage_own[COMPACT ? kIdxChunk : 1];     // ... and the bits of its own row's step (idx_own_bits >> 18), read beside the opposite row's word
     __shared__ unsigned fill[WAVES][kIdxMaxSteps];              // per (wave, step): count, then where the wave's next record of the step goes
     __shared__ unsigned lstart[kIdxMaxSteps + 1], goff[kIdxMaxSteps];    // a step's first record in the stage / in the sorted array
     __shared__ unsigned wave_tot[WAVES];
@@ -493,10 +569,11 @@ __global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const
         for (int w = 0; w < WAVES; ++w) fill[w][s] = 0u;
         goff[s] = ldg(A.hist + (size_t)c * (steps + 1) + s);
     }
-    __syncthreads();
     const uint16_t *__restrict__ ent_tag = S.ent_tag + tag_buffer(S, epoch);
     const int64_t lo = (int64_t)c * kIdxChunk, hi = min(lo + kIdxChunk, S.n_slots);
     const int64_t w_lo = lo + (int64_t)wave * (kIdxChunk / WAVES), w_hi = min(w_lo + kIdxChunk / WAVES, hi);
+    const int n_all = S.n_user + S.n_item;
+    __syncthreads();
     // ---- the wave's slots per step
     unsigned *mine = fill[wave];
     for (int64_t p = w_lo + lane * 8; p < w_hi; p += kWave * 8) {
@@ -545,7 +622,6 @@ __global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const
     __syncthreads();
     // ---- every wave places its quarter, in slot order
     const unsigned long long below = (1ull << lane) - 1ull;
-    const int n_all = S.n_user + S.n_item;
     struct Batch { unsigned tag; int oid, idx, row; float r; };
     auto fetch = [&](int64_t p) {
         Batch b{0xFFFFu, 0, 0, 0, 0.f};
@@ -568,10 +644,16 @@ __global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const
     for (int64_t r0 = w_lo; r0 < w_hi; r0 += kRound * kWave) {
         Batch bt[kRound];
         unsigned long long wd[kRound];
+        unsigned own[kRound];
 #pragma unroll
         for (int k = 0; k < kRound; ++k) bt[k] = fetch(r0 + k * kWave + lane);
 #pragma unroll
-        for (int k = 0; k < kRound; ++k) wd[k] = word_of(bt[k]);
+        for (int k = 0; k < kRound; ++k) {
+            wd[k] = word_of(bt[k]);
+            // (the slot's own row's word and next_first entry: cached lines -- a chunk holds ~20 rows -- beside the gather above.  The kernel takes
+            // 1.10 ms per epoch at the 25 M shape with them, 0.96 without, from LDS copies of the rows' words as well: NOTES 4)
+            own[k] = bt[k].tag < (unsigned)steps ? idx_own_bits(A, n_all, bt[k].row, bt[k].tag) : 0u;
+        }
 #pragma unroll
         for (int k = 0; k < kRound; ++k) {
             const unsigned tag = bt[k].tag;
@@ -589,10 +671,11 @@ __global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const
                 const unsigned base = mine[tag];                        // (all peers read before their first lane writes: LDS runs a wave's accesses in order)
                 const int rank = __popcll(peers & below);
                 if (rank == 0) mine[tag] = base + (unsigned)__popcll(peers);
-                if (COMPACT)
+                if (COMPACT) {
                     stage_c[base + rank] = (unsigned)(r0 + k * kWave + lane - lo) | ((unsigned)oid & 0x80000000u) >> 19 | tag << 13;
-                else
-                    stage[base + rank] = make_uint4((unsigned)oid, __float_as_uint(bt[k].r), (unsigned)bt[k].row, tag | ((unsigned)cls << 16));
+                    stage_own[base + rank] = (uint16_t)(own[k] >> kIdxOwnBufBit);
+                } else
+                    stage[base + rank] = make_uint4((unsigned)oid, __float_as_uint(bt[k].r), (unsigned)bt[k].row, tag | ((unsigned)cls << 16) | own[k]);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -609,7 +692,7 @@ __global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const
             const ure_i2 g = *(const ure_i2 URE_AS1 *)(A.grp_row + 2 * (p >> 3));
             const int gi = g.x, gr = g.y;
             const int cls = gi < S.n_split ? kIdxSplit : gi < S.n_multi ? kIdxHeavy : kIdxLight;
-            rec = make_uint4((unsigned)ldg(S.ent_oid + p) | ((v >> 12) & 1u) << 31, __float_as_uint(ldg(S.ent_r + p)), (unsigned)gr, tag | ((unsigned)cls << 16));
+            rec = make_uint4((unsigned)ldg(S.ent_oid + p) | ((v >> 12) & 1u) << 31, __float_as_uint(ldg(S.ent_r + p)), (unsigned)gr, tag | ((unsigned)cls << 16) | (unsigned)stage_own[i] << kIdxOwnBufBit);
         } else {
             rec = stage[i];
         }
@@ -706,7 +789,6 @@ __global__ __launch_bounds__(kBlock) void idx_emit_kernel(const ure_shard_t *__r
     const int64_t total = ldg(A.step_begin + A.steps);
     const int64_t q_lo = (int64_t)blockIdx.x * kIdxFlagBlock;
     if (q_lo >= total) return;
-    const int n_all = S.n_user + S.n_item;
     const int lane = threadIdx.x & 63;
     const int64_t n_words = (total + 63) >> 6;
     if (threadIdx.x == 0) {
@@ -726,10 +808,7 @@ __global__ __launch_bounds__(kBlock) void idx_emit_kernel(const ure_shard_t *__r
         if (!((flags >> lane) & 1ull)) continue;
         const unsigned i = before[(int)(wi - (q_lo >> 6))] + (unsigned)__popcll(flags & mask_below(lane));
         const uint4 rec = ldg_u4(A.sslot + q);
-        const int row_id = (int)rec.z, st = (int)(rec.w & 0xFFFFu), cls = (int)(rec.w >> 16);
-        const int w = st / kIdxWin, b = st % kIdxWin;
-        const unsigned long long word = ldg(A.W + (size_t)w * n_all + row_id);
-        const int nxt = (int)ldg(A.next_first + (size_t)w * n_all + row_id);
+        const int row_id = (int)rec.z, cls = (int)(rec.w >> 16) & 3;
         // where the run ends: the next run start (a few words on for the runs of the heaviest rows)
         unsigned long long later = lane < 63 ? flags >> (lane + 1) : 0ull;
         int64_t end = later ? q + 1 + (__ffsll((long long)later) - 1) : -1;
@@ -738,10 +817,8 @@ __global__ __launch_bounds__(kBlock) void idx_emit_kernel(const ure_shard_t *__r
             const unsigned long long f2 = ldg(A.runflag + w2);
             if (f2) end = (w2 << 6) + (__ffsll((long long)f2) - 1);
         }
-        const int buf = idx_buffer_at(word, b);
-        // steps that pass between this step and the row's next own step (none: until the epoch ends)
-        const unsigned long long rest = (word & kIdxBits) >> (b + 1);
-        const int gap = rest ? __ffsll((long long)rest) - 1 : nxt - st - 1;
+        // the buffer of the row at this step and the steps that pass until its next own step came with the slot (idx_own_bits)
+        const int buf = (int)(rec.w >> kIdxOwnBufBit) & 1, gap = (int)(rec.w >> kIdxGapShift) & 0x3FF;
         stg_i4(A.items + i, make_int4(row_id | (buf << 31), (int)q, (int)min(end, total), gap | (cls << 16)));
         // the run's first two slots travel with the item (items2): most runs are one or two slots long (1.6 on average at the 25 M shape),
         // and their gathers then start with the row's own loads instead of one memory level later

@@ -642,8 +642,9 @@ static void launch_index_epoch_start(const ure_job *job, int64_t tick, hipStream
     const unsigned row_blocks = (unsigned)std::max(1, std::min((job->max_rows + kBlock - 1) / kBlock, 4096));
     const unsigned adv_b = (unsigned)std::max<int64_t>(1, std::min<int64_t>((job->max_active4 + kBlock - 1) / kBlock, 8192));
     if (tick == 0) hipLaunchKernelGGL(idx_grp_row_kernel, dim3(std::min<unsigned>((unsigned)((slots / 8 + kBlock - 1) / kBlock), 8192u), n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux);
-    hipLaunchKernelGGL(idx_clear_kernel, dim3(std::min<unsigned>((unsigned)((2 * chunks + kBlock - 1) / kBlock), 1024u), n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
-    hipLaunchKernelGGL(idx_masks_kernel, dim3((unsigned)chunks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+    const unsigned mask_chunks = (unsigned)((slots + kIdxMaskChunk - 1) / kIdxMaskChunk);
+    hipLaunchKernelGGL(idx_clear_kernel, dim3(std::min<unsigned>((2 * mask_chunks + kBlock - 1) / kBlock, 1024u), n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+    hipLaunchKernelGGL(idx_masks_kernel, dim3(mask_chunks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
     hipLaunchKernelGGL(idx_parity_kernel, dim3(row_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
     hipLaunchKernelGGL(idx_hist_kernel, dim3(wave_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
     hipLaunchKernelGGL(idx_scan1_kernel, dim3(step_blocks, kIdxSeg, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
@@ -652,7 +653,7 @@ static void launch_index_epoch_start(const ure_job *job, int64_t tick, hipStream
     // (epochs of at most 63 steps: a step's share of 1,024 slots is a run worth sorting in LDS first)
     constexpr bool staged_ok = true;
     if (steps <= kIdxWin && staged_ok)
-        hipLaunchKernelGGL(idx_scatter_short_kernel, dim3(wave_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+        hipLaunchKernelGGL((idx_scatter_short_kernel<URE_INDEX_SHORT_COMPACT != 0, URE_INDEX_SHORT_ROUND>), dim3(wave_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
     else if (job->scatter_staged)
         hipLaunchKernelGGL((idx_scatter_staged_kernel<kIdxStagedWaves, URE_INDEX_STAGED_COMPACT != 0>), dim3((unsigned)chunks, n_sh), dim3(kIdxStagedWaves * kWave), 0, st, job->dev, job->dev_aux, tick);
     else
@@ -897,6 +898,11 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
         void *ptab = nullptr;
         e = block_malloc(&ptab, tab.size() * sizeof(float));
         if (e == hipSuccess) { job->touch_mem.push_back(ptab); e = hipMemcpy(ptab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice); }
+        // (epochs of at most 63 steps in every shard: idx_scatter_short_kernel sorts 1,024 slots at a time in LDS, and with a chunk of that size a
+        // wavefront per 1,024 slots instead of 4,096 -- the shards of such a job start their epochs at different ticks, 25 / 26 / 27 steps apart, and a
+        // single shard's 340 chunks of 4,096 left three quarters of the chip idle: 100 us per shard and epoch against 26 with all 32 at once)
+        bool index_short = true;
+        for (int k = 0; k < n_shards; ++k) index_short = index_short && job->aux_host[k].steps <= kIdxWin;
         for (int k = 0; k < n_shards && e == hipSuccess && job->index; ++k) {
             // touch_mode 3: the slot index of the current epoch (mf_index.h), one allocation per shard
             const ure_shard_t &S = shards[k];
@@ -904,7 +910,8 @@ int ure_job_create(const ure_shard_t *shards, int n_shards, ure_job_t **out)
             A.ptab = static_cast<const float4 *>(ptab);
             const size_t n_all = (size_t)S.n_user + S.n_item, steps = (size_t)A.steps, slots = (size_t)S.n_slots;
             A.idx_words = (int32_t)((steps + kIdxWin - 1) / kIdxWin);
-            A.idx_chunks = (int32_t)((slots + kIdxChunk - 1) / kIdxChunk);
+            A.idx_chunk = index_short ? kIdxStage : kIdxChunk;
+            A.idx_chunks = (int32_t)((slots + A.idx_chunk - 1) / A.idx_chunk);
             A.idx_hw = S.n_multi + 2 * S.batch / kIdxPart + 2;
             A.idx_light = (int32_t)std::min<int64_t>(2 * (int64_t)S.batch, S.n_active);
             size_t at = 0;

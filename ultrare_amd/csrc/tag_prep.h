@@ -209,7 +209,8 @@ struct shard_aux {
     // touch_mode 3 ("indexed", mf_index.h): the per-step slot index of the current epoch, rebuilt at every epoch start
     int32_t ptab_stride;           // entries of ptab per epoch (65; touch_mode 3: steps + 1)
     int32_t idx_words;             // mask words per row and epoch = ceil(steps / 63)
-    int32_t idx_chunks;            // ceil(n_slots / 4096): one wavefront sorts one chunk
+    int32_t idx_chunks;            // ceil(n_slots / idx_chunk): the chunks of the sort by step
+    int32_t idx_chunk;             // slots per chunk: 4,096, or 1,024 when no shard of the job has more than 63 steps per epoch
     int32_t idx_hw;                // workgroups of a step launch reserved for heavy rows (upper bound)
     int32_t idx_light;             // upper bound of a step's light items = min(2 B, n_active)
     int32_t *grp_row;              // [n_slots / 8][2] {schedule index, row id} of the row that owns the group of 8 slots (static)
@@ -221,7 +222,8 @@ struct shard_aux {
     uint32_t *hist;                // [idx_chunks][steps + 1] slots per (chunk, step) -> after the scan: where the chunk's run of the step starts
     uint32_t *seg;                 // [32][steps + 1] scan scratch
     uint32_t *step_begin;          // [steps + 2] first sorted slot of each step; [steps] = sorted slots in all
-    uint4 *sslot;                  // [n_slots] slots sorted by (step, row, file order): {opposite id | buffer << 31, rating, row id, step | class << 16}
+    uint4 *sslot;                  // [n_slots] slots sorted by (step, row, file order): {opposite id | buffer << 31, rating, row id, step | class << 16 |
+                                   // the row's own buffer at the step << 18 | steps until its next own step << 19 (mf_index.h: idx_own_bits)}
     unsigned long long *runflag;   // [n_slots / 64 + 1] bit = the sorted slot starts a (step, row) run
     uint32_t *blk_cnt;             // [n_slots / 2048 + 2] runs that start in each block of 2048 sorted slots -> exclusive prefix
     int4 *items;                   // [2 N + 1] one per (step, row) run, steps ascending: {row id | buffer << 31, first sorted slot, end, gap | class << 16}
