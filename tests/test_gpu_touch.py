@@ -487,6 +487,32 @@ def test_touch_index_staged_scatter_equals_the_direct_one(B, k, monkeypatch):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('B', [437, 3000, 37])
+def test_touch_index_arrays_equal_the_numpy_restatement(B):
+    """The device-built index of every epoch -- sorted slots (steps, opposite ids, ratings, rows, the opposite rows' buffers), runs, items with
+    their buffers and gaps (carried by the sorted slots since round 5: idx_own_bits), step_item -- against tools/check_index.py's numpy sort:
+    65 steps per epoch (two mask words, the staged scatter), 10 (one word, chunks of 1,024 slots, the compact short scatter), 750 (twelve words)."""
+    import importlib.util
+    from ultrare_amd import engine, rng
+    spec = importlib.util.spec_from_file_location('check_index', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'check_index.py'))
+    CI = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(CI)
+    raw = O.load_csv(TRAIN)
+    part = O.partition(*raw, O.uniform_groups(N_USER, 1))[0]
+    k, E = 16, 3
+    torch.manual_seed(11)
+    init = rng.mf_init(N_USER, N_ITEM, k)
+    perms = rng.epoch_perms(rng.epoch_seeds(E, True), len(part[0]))
+    job = engine.TrainJob([engine.ShardData(*part, N_USER, N_ITEM)], [init], [perms], k, B, E, 1e-3, 0.1, 0.9, 0.95, touch='index')
+    assert job.index
+    steps = job.steps_per_epoch(0)
+    for e in range(E):
+        job.run(1)
+        assert CI.check(job, 0, part, perms[e].numpy(), B) > 0
+        job.run(steps - 1)
+    job.close()
+
+
 def test_touch_index_mode_refusals():
     from ultrare_amd import engine, _native as nv
     parts, inits, perms, shards = _setup(1, 16, 20, 1)

@@ -1013,15 +1013,17 @@ __device__ __forceinline__ void idx_gather(const ure_shard_t &S, const shard_aux
 }
 
 template <int LPR, int V4>
-__device__ __forceinline__ void mf_index_step(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+__device__ __forceinline__ void mf_index_step(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, unsigned n_sh, unsigned per)
 {
     constexpr int G = kWave / LPR;
     constexpr int UPB = kBlock / LPR;
     constexpr int D = LPR * V4 * 4;
     __shared__ float4 part_acc[UPB][V4][LPR];
     __shared__ float part_sse[UPB];
-    const ure_shard_t &S = shards[blockIdx.y];
-    const shard_aux &A = aux[blockIdx.y];
+    const WgMap wm = xcd_shard_map(blockIdx.x, n_sh, per);          // (a shard's gathers of its popular rows from one L2)
+    const unsigned wg = (unsigned)wm.wg;
+    const ure_shard_t &S = shards[wm.shard];
+    const shard_aux &A = aux[wm.shard];
     const int steps = A.steps;
     if (tick >= (int64_t)steps * S.epochs) return;
     const int epoch = (int)epoch_of(A, tick);
@@ -1033,9 +1035,9 @@ __device__ __forceinline__ void mf_index_step(const ure_shard_t *__restrict__ sh
     const uint4 sd = ldg_u4(A.step_desc + s);              // {first item, end, heavy items, workgroups of the heavy items}
     const unsigned i0 = sd.x, i1 = sd.y, n_heavy = sd.z;
     const int4 *__restrict__ items = A.items;
-    if ((int)blockIdx.x < A.idx_hw) {
+    if ((int)wg < A.idx_hw) {
         // ---- a heavy item (or one part of a split one): the workgroup's lane groups take its slots round robin
-        const unsigned b = blockIdx.x;
+        const unsigned b = wg;
         if (b >= sd.w) return;
         const unsigned hm = ldg(A.heavy_map + (size_t)s * A.idx_hw + b);     // item of the heavy prefix | part << 9 | parts << 20
         const unsigned k = hm & 0x1FFu;
@@ -1079,7 +1081,7 @@ __device__ __forceinline__ void mf_index_step(const ure_shard_t *__restrict__ sh
         return;
     }
     // ---- light items: a lane group each
-    const unsigned i = i0 + n_heavy + ((unsigned)blockIdx.x - (unsigned)A.idx_hw) * UPB + (unsigned)local;
+    const unsigned i = i0 + n_heavy + (wg - (unsigned)A.idx_hw) * UPB + (unsigned)local;
     const bool have = i < i1;
     if (!__any(have)) return;
     int4 e = make_int4(0, 0, 0, 0);
@@ -1122,9 +1124,9 @@ __device__ __forceinline__ void mf_index_step(const ure_shard_t *__restrict__ sh
 }
 
 template <int LPR, int V4>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(URE_INDEX_WAVES))) void mf_index_step_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(URE_INDEX_WAVES))) void mf_index_step_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick, unsigned n_sh, unsigned per)
 {
-    mf_index_step<LPR, V4>(shards, aux, tick);
+    mf_index_step<LPR, V4>(shards, aux, tick, n_sh, per);
 }
 
 // the rows split over several workgroups: their parts' sums in part order, then the update.  One wavefront per split item.

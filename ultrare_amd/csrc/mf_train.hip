@@ -677,7 +677,8 @@ static void launch_index_step(const ure_job *job, int64_t tick, hipStream_t st)
         blocks = std::max(blocks, A.idx_hw + (A.idx_light + UPB - 1) / UPB);
         split = std::max(split, job->host[k].n_split);
     }
-    hipLaunchKernelGGL((mf_index_step_kernel<LPR, V4>), dim3((unsigned)blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+    const unsigned per = ((unsigned)blocks + 7u) / 8u;
+    hipLaunchKernelGGL((mf_index_step_kernel<LPR, V4>), dim3(8u * n_sh * per), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick, n_sh, per);
     if (split > 0) hipLaunchKernelGGL((idx_combine_kernel<LPR, V4>), dim3((unsigned)split, n_sh), dim3(kWave), 0, st, job->dev, job->dev_aux, tick);
 }
 

@@ -160,6 +160,21 @@ __host__ __device__ inline int tag_ahead(const ure_shard_t &S) { return S.touch_
 __host__ __device__ inline size_t tag_buffer(const ure_shard_t &S, int epoch) { return (size_t)(S.touch_mode == 2 ? epoch % 3 : (epoch & 1)) * (size_t)S.n_slots; }
 
 // Phase C, workgroup `blk` of `n_blk` (256 threads, eight slots per thread).
+// Workgroup -> (shard, workgroup of the shard) on a 1-D grid of 8 n_sh `per` workgroups (per = ceil(workgroups per shard / 8)).  The dispatcher deals
+// consecutive workgroup ids out to the 8 XCDs round robin and every XCD has its own L2: XCD x takes the slices [n_sh x, n_sh (x + 1)) of the 8 n_sh
+// slices (slice r of shard k = its workgroups = r mod 8) ONE AFTER THE OTHER, so that with 8 m shards an XCD works through m whole shards in turn and what
+// a shard's workgroups gather again and again -- its popular rows -- stays in one L2.  One shard: the identity.  For launches in which EVERY shard has
+// work (the step kernel: 99.8 -> 96.8 us at configs[3]'s shape, k = 16); the epoch-start passes of touch_mode 3 lose by it -- the shards of such a job
+// start their epochs at different ticks, and a shard alone on one XCD has an eighth of the chip (its scatter 57 -> 158 us; all 32 at once 793 -> 728).
+struct WgMap { int shard, wg; };
+__device__ __forceinline__ WgMap xcd_shard_map(unsigned id, unsigned n_sh, unsigned per)
+{
+    const unsigned x = id & 7u, j = id >> 3;
+    const unsigned jq = j / per;
+    const unsigned slice = n_sh * x + jq;
+    return WgMap{(int)(slice >> 3), (int)((j - jq * per) * 8u + (slice & 7u))};
+}
+
 __device__ inline void tag_derive(const ure_shard_t &S, int epoch, int blk, int n_blk)
 {
     const int32_t *__restrict__ ent_src = S.ent_src;
