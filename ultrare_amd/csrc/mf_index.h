@@ -18,15 +18,17 @@
 // bitwise reproducible.
 //
 // The epoch start (standalone launches, mf_index launch list in index_epoch_start):
-//   masks    W[w][row]: bit b = the row is trained in step 63 w + b.  A workgroup takes 4,096 consecutive slots (at most 512 rows),
+//   masks    W[w][row]: bit b = the row is trained in step 63 w + b.  A workgroup takes 2,048 consecutive slots (at most 256 rows),
 //            ORs the tags into an LDS bitmap and stores a row's words whole; rows that straddle chunks are ORed into memory.
 //   parity   bit 63 of every word = the buffer the row's weights are in at the word's first step (a row alternates between the two
-//            weight buffers with each of its own steps); the row's first step; its buffer at the epoch's end.
-//   sort     histogram per (chunk of 4,096 slots, step) -> exclusive scan over (step, chunk) -> every wavefront scatters its chunk
-//            in slot order (equal tags inside a batch of 64 are ranked by lane with ten ballots: stable).
-//            Every slot travels with the buffer its OPPOSITE row is in at that step (a gather from W in the scatter).
+//            weight buffers with each of its own steps); the row's first step; its buffer at the epoch's end.  By row id.
+//   sort     histogram per (chunk of 4,096 slots -- 1,024 in jobs of short epochs --, step) -> exclusive scan over (step, chunk) -> the
+//            chunk is sorted in LDS and leaves a step's stretch at a time (equal tags inside a batch of 64 are ranked by lane with
+//            ballots: stable).  Every slot travels with the buffer its OPPOSITE row is in at that step (a gather from W in the scatter)
+//            and with its OWN row's buffer and the steps until the row's next own step (idx_own_bits).
 //   mark     the bitmap of run starts of the sorted slots.
-//   items    scan of the run starts -> one entry per run; per step the heavy prefix and its workgroup counts.
+//   items    scan of the run starts -> one entry per run (its buffer and gap copied from the run's first slot); per step the heavy
+//            prefix and its workgroup counts.
 //   advance  every active row from "valid at the end of the last epoch" to "valid at its first step", into buffer 0 (dense, once
 //            per EPOCH; the windows of touch_mode 1 pay it every 64 steps).
 //
@@ -395,24 +397,14 @@ constexpr int kIdxStage = 1024;                 // slots a wavefront sorts in LD
 #define URE_INDEX_STAGED_WAVES 8
 #endif
 constexpr int kIdxStagedWaves = URE_INDEX_STAGED_WAVES;   // wavefronts that sort a chunk of an epoch of 64+ steps together (idx_scatter_staged_kernel)
-#ifndef URE_INDEX_STAGED_COMPACT
-#define URE_INDEX_STAGED_COMPACT 1
-#endif
 
-#ifndef URE_INDEX_SHORT_COMPACT
-#define URE_INDEX_SHORT_COMPACT 1
-#endif
-#ifndef URE_INDEX_SHORT_ROUND
-#define URE_INDEX_SHORT_ROUND 8
-#endif
-// COMPACT: the stage holds a word per slot -- where the slot is among the 1,024, its step, the buffer bit of its opposite row, the bits of its own
-// row's step -- and the record is put together on the way out (loads of lines the wavefront has just read): 4 KB of LDS per wavefront instead of
-// 16, so that the wavefronts a CU holds are bounded by registers, not by LDS (two per SIMD before)
-template <bool COMPACT, int ROUND>
+// The stage holds a word per slot -- where the slot is among the 1,024, its step, the buffer bit of its opposite row, the bits of its own row's
+// step -- and the record is put together on the way out (loads of lines the wavefront has just read): 4 KB of LDS per wavefront, so that the
+// wavefronts a CU holds are bounded by registers (four per SIMD), not by LDS (two with full records in the stage; 5.70 against 5.64 ms per epoch
+// of configs[3]'s shape at k = 16, profiles/r05/NOTES.md 4b).
 __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
 {
-    __shared__ uint4 stage[COMPACT ? 1 : kWavesPerBlock][COMPACT ? 1 : kIdxStage];
-    __shared__ unsigned stage_c[COMPACT ? kWavesPerBlock : 1][COMPACT ? kIdxStage : 1];
+    __shared__ unsigned stage_c[kWavesPerBlock][kIdxStage];
     __shared__ unsigned goff[kWavesPerBlock][64], lcnt[kWavesPerBlock][64], lstart[kWavesPerBlock][64], lfill[kWavesPerBlock][64];
     const ure_shard_t &S = shards[blockIdx.y];
     const shard_aux &A = aux[blockIdx.y];
@@ -421,8 +413,7 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_sha
     const int c = (int)blockIdx.x * kWavesPerBlock + wave;
     if (epoch < 0 || c >= A.idx_chunks) return;
     const int steps = A.steps;                                      // <= 63: a step is its own lane below
-    uint4 *st = stage[COMPACT ? 0 : wave];
-    unsigned *stc = stage_c[COMPACT ? wave : 0];
+    unsigned *stc = stage_c[wave];
     unsigned *g_off = goff[wave], *l_cnt = lcnt[wave], *l_start = lstart[wave], *l_fill = lfill[wave];
     g_off[lane] = lane < steps ? ldg(A.hist + (size_t)c * (steps + 1) + lane) : 0u;
     l_cnt[lane] = 0u;
@@ -431,16 +422,13 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_sha
     const int64_t lo = (int64_t)c * A.idx_chunk, hi = min(lo + A.idx_chunk, S.n_slots);
     const unsigned long long below = (1ull << lane) - 1ull;
     const int n_all = S.n_user + S.n_item;
-    struct Batch { unsigned tag; int oid, idx, row; float r; };
+    struct Batch { unsigned tag; int oid, row; };
     auto fetch = [&](int64_t p) {
-        Batch b{0xFFFFu, 0, 0, 0, 0.f};
+        Batch b{0xFFFFu, 0, 0};
         if (p < hi) {
             b.tag = ldg(ent_tag + p);
             b.oid = ldg(S.ent_oid + p);
-            if (!COMPACT) b.r = ldg(S.ent_r + p);
-            const ure_i2 g = *(const ure_i2 URE_AS1 *)(A.grp_row + 2 * (p >> 3));
-            const int gi = g.x, gr = g.y;
-            b.idx = gi; b.row = gr;
+            b.row = ldg(A.grp_row + 2 * (p >> 3) + 1);
         }
         return b;
     };
@@ -451,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_sha
     };
     // Eight batches at a time: their loads of the row-major arrays go out together, then the eight gathers of the opposite rows' mask
     // words, then the batches are placed one after the other -- the two memory levels are paid once per 512 slots, not per 64.
-    constexpr int kRound = ROUND;
+    constexpr int kRound = 8;
     for (int64_t s0 = lo; s0 < hi; s0 += kIdxStage) {
         const int64_t s1 = min(s0 + kIdxStage, hi);
         // the counts of these 1,024 slots per step (their tags once more: 2 KB, in the caches), then the exclusive prefix over the steps
@@ -502,13 +490,8 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_sha
                     const unsigned base = l_fill[tag];                      // (all peers read before their first lane writes: LDS runs a wave's accesses in order)
                     const int rank = __popcll(peers & below);
                     if (rank == 0) l_fill[tag] = base + (unsigned)__popcll(peers);
-                    if (COMPACT) {
-                        // slot among the 1,024 | step << 10 | opposite row's buffer << 16 | own row's buffer << 17 | gap << 18 (steps, gaps below 64)
-                        stc[base + rank] = (unsigned)(r0 + k * kWave + lane - s0) | tag << 10 | opp << 16 | (own[k] >> kIdxOwnBufBit) << 17;
-                    } else {
-                        const int cls = bt[k].idx < S.n_split ? kIdxSplit : bt[k].idx < S.n_multi ? kIdxHeavy : kIdxLight;
-                        st[base + rank] = make_uint4((unsigned)bt[k].oid | opp << 31, __float_as_uint(bt[k].r), (unsigned)bt[k].row, tag | ((unsigned)cls << 16) | own[k]);
-                    }
+                    // slot among the 1,024 | step << 10 | opposite row's buffer << 16 | own row's buffer << 17 | gap << 18 (steps, gaps below 64)
+                    stc[base + rank] = (unsigned)(r0 + k * kWave + lane - s0) | tag << 10 | opp << 16 | (own[k] >> kIdxOwnBufBit) << 17;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -516,18 +499,13 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_sha
         // the staged slots leave in sorted order: slot i of the stage belongs to the step whose range [l_start, l_start + l_cnt) holds i
         const unsigned total = l_start[63] + l_cnt[63];
         for (unsigned i = lane; i < total; i += kWave) {
-            uint4 rec;
-            if (COMPACT) {
-                const unsigned v = stc[i];
-                const int64_t p = s0 + (int64_t)(v & 1023u);
-                const ure_i2 g = *(const ure_i2 URE_AS1 *)(A.grp_row + 2 * (p >> 3));
-                const int gi = g.x, gr = g.y;
-                const int cls = gi < S.n_split ? kIdxSplit : gi < S.n_multi ? kIdxHeavy : kIdxLight;
-                rec = make_uint4((unsigned)ldg(S.ent_oid + p) | ((v >> 16) & 1u) << 31, __float_as_uint(ldg(S.ent_r + p)), (unsigned)gr,
-                                 ((v >> 10) & 63u) | ((unsigned)cls << 16) | (v >> 17) << kIdxOwnBufBit);
-            } else {
-                rec = st[i];
-            }
+            const unsigned v = stc[i];
+            const int64_t p = s0 + (int64_t)(v & 1023u);
+            const ure_i2 g = *(const ure_i2 URE_AS1 *)(A.grp_row + 2 * (p >> 3));
+            const int gi = g.x, gr = g.y;
+            const int cls = gi < S.n_split ? kIdxSplit : gi < S.n_multi ? kIdxHeavy : kIdxLight;
+            const uint4 rec = make_uint4((unsigned)ldg(S.ent_oid + p) | ((v >> 16) & 1u) << 31, __float_as_uint(ldg(S.ent_r + p)), (unsigned)gr,
+                                         ((v >> 10) & 63u) | ((unsigned)cls << 16) | (v >> 17) << kIdxOwnBufBit);
             const unsigned tag = rec.w & 0xFFFFu;
             stg_u4(A.sslot + (size_t)(g_off[tag] + (i - l_start[tag])), rec);
         }
@@ -545,14 +523,13 @@ __global__ __launch_bounds__(kBlock) void idx_scatter_short_kernel(const ure_sha
 // step), prefix over (step, wave), every wave places its quarter in slot order (the ranks of idx_scatter_kernel: ballots inside a batch of 64,
 // running counters) -- and the chunk leaves in sorted order: a step's 5.5 records are one stretch of 88 bytes, stored by neighbouring lanes.
 // Every slot lands exactly where idx_scatter_kernel puts it.
-template <int WAVES, bool COMPACT>
+template <int WAVES>
 __global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const ure_shard_t *__restrict__ shards, const shard_aux *__restrict__ aux, int64_t tick)
 {
-    // COMPACT: the stage holds a word per slot -- where the slot is in the chunk, its step, the buffer bit of its opposite row -- and the record is
-    // put together when the chunk leaves (three loads of lines this workgroup has just read): 16 KB instead of 64, two workgroups per CU
-    __shared__ uint4 stage[COMPACT ? 1 : kIdxChunk];
-    __shared__ unsigned stage_c[COMPACT ? kIdxChunk : 1];
-    __shared__ uint16_t stage_own[COMPACT ? kIdxChunk : 1];     // ... and the bits of its own row's step (idx_own_bits >> 18), read beside the opposite row's word
+    // the stage holds a word per slot -- where the slot is in the chunk, its step, the buffer bit of its opposite row -- and the record is put
+    // together when the chunk leaves (three loads of lines this workgroup has just read): 16 KB instead of 64 for full records, two workgroups per CU
+    __shared__ unsigned stage_c[kIdxChunk];
+    __shared__ uint16_t stage_own[kIdxChunk];                   // ... and the bits of its own row's step (idx_own_bits >> 18), read beside the opposite row's word
     __shared__ unsigned fill[WAVES][kIdxMaxSteps];              // per (wave, step): count, then where the wave's next record of the step goes
     __shared__ unsigned lstart[kIdxMaxSteps + 1], goff[kIdxMaxSteps];    // a step's first record in the stage / in the sorted array
     __shared__ unsigned wave_tot[WAVES];
@@ -622,16 +599,13 @@ __global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const
     __syncthreads();
     // ---- every wave places its quarter, in slot order
     const unsigned long long below = (1ull << lane) - 1ull;
-    struct Batch { unsigned tag; int oid, idx, row; float r; };
+    struct Batch { unsigned tag; int oid, row; };
     auto fetch = [&](int64_t p) {
-        Batch b{0xFFFFu, 0, 0, 0, 0.f};
+        Batch b{0xFFFFu, 0, 0};
         if (p < w_hi) {
             b.tag = ldg(ent_tag + p);
             b.oid = ldg(S.ent_oid + p);
-            b.r = ldg(S.ent_r + p);
-            const ure_i2 g = *(const ure_i2 URE_AS1 *)(A.grp_row + 2 * (p >> 3));
-            const int gi = g.x, gr = g.y;
-            b.idx = gi; b.row = gr;
+            b.row = ldg(A.grp_row + 2 * (p >> 3) + 1);
         }
         return b;
     };
@@ -658,8 +632,7 @@ __global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const
         for (int k = 0; k < kRound; ++k) {
             const unsigned tag = bt[k].tag;
             const bool valid = tag < (unsigned)steps;
-            const int oid = bt[k].oid | (valid ? idx_buffer_at(wd[k], (int)(tag % kIdxWin)) << 31 : 0);
-            const int cls = bt[k].idx < S.n_split ? kIdxSplit : bt[k].idx < S.n_multi ? kIdxHeavy : kIdxLight;
+            const unsigned opp = valid ? (unsigned)idx_buffer_at(wd[k], (int)(tag % kIdxWin)) : 0u;
             unsigned long long peers = __ballot(valid);
 #pragma unroll
             for (int b = 0; b < 10; ++b) {
@@ -671,11 +644,8 @@ __global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const
                 const unsigned base = mine[tag];                        // (all peers read before their first lane writes: LDS runs a wave's accesses in order)
                 const int rank = __popcll(peers & below);
                 if (rank == 0) mine[tag] = base + (unsigned)__popcll(peers);
-                if (COMPACT) {
-                    stage_c[base + rank] = (unsigned)(r0 + k * kWave + lane - lo) | ((unsigned)oid & 0x80000000u) >> 19 | tag << 13;
-                    stage_own[base + rank] = (uint16_t)(own[k] >> kIdxOwnBufBit);
-                } else
-                    stage[base + rank] = make_uint4((unsigned)oid, __float_as_uint(bt[k].r), (unsigned)bt[k].row, tag | ((unsigned)cls << 16) | own[k]);
+                stage_c[base + rank] = (unsigned)(r0 + k * kWave + lane - lo) | opp << 12 | tag << 13;
+                stage_own[base + rank] = (uint16_t)(own[k] >> kIdxOwnBufBit);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -684,19 +654,14 @@ __global__ __launch_bounds__(WAVES * kWave) void idx_scatter_staged_kernel(const
     // ---- the chunk leaves in sorted order
     const unsigned total = lstart[kIdxMaxSteps];
     for (unsigned i = tid; i < total; i += kThreads) {
-        uint4 rec;
-        if (COMPACT) {
-            const unsigned v = stage_c[i];
-            const int64_t p = lo + (int64_t)(v & 4095u);
-            const unsigned tag = v >> 13;
-            const ure_i2 g = *(const ure_i2 URE_AS1 *)(A.grp_row + 2 * (p >> 3));
-            const int gi = g.x, gr = g.y;
-            const int cls = gi < S.n_split ? kIdxSplit : gi < S.n_multi ? kIdxHeavy : kIdxLight;
-            rec = make_uint4((unsigned)ldg(S.ent_oid + p) | ((v >> 12) & 1u) << 31, __float_as_uint(ldg(S.ent_r + p)), (unsigned)gr, tag | ((unsigned)cls << 16) | (unsigned)stage_own[i] << kIdxOwnBufBit);
-        } else {
-            rec = stage[i];
-        }
-        const unsigned tag = rec.w & 0xFFFFu;
+        const unsigned v = stage_c[i];
+        const int64_t p = lo + (int64_t)(v & 4095u);
+        const unsigned tag = v >> 13;
+        const ure_i2 g = *(const ure_i2 URE_AS1 *)(A.grp_row + 2 * (p >> 3));
+        const int gi = g.x, gr = g.y;
+        const int cls = gi < S.n_split ? kIdxSplit : gi < S.n_multi ? kIdxHeavy : kIdxLight;
+        const uint4 rec = make_uint4((unsigned)ldg(S.ent_oid + p) | ((v >> 12) & 1u) << 31, __float_as_uint(ldg(S.ent_r + p)), (unsigned)gr,
+                                     tag | ((unsigned)cls << 16) | (unsigned)stage_own[i] << kIdxOwnBufBit);
         stg_u4(A.sslot + (size_t)(goff[tag] + (i - lstart[tag])), rec);
     }
 }

@@ -653,9 +653,9 @@ static void launch_index_epoch_start(const ure_job *job, int64_t tick, hipStream
     // (epochs of at most 63 steps: a step's share of 1,024 slots is a run worth sorting in LDS first)
     constexpr bool staged_ok = true;
     if (steps <= kIdxWin && staged_ok)
-        hipLaunchKernelGGL((idx_scatter_short_kernel<URE_INDEX_SHORT_COMPACT != 0, URE_INDEX_SHORT_ROUND>), dim3(wave_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
+        hipLaunchKernelGGL(idx_scatter_short_kernel, dim3(wave_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
     else if (job->scatter_staged)
-        hipLaunchKernelGGL((idx_scatter_staged_kernel<kIdxStagedWaves, URE_INDEX_STAGED_COMPACT != 0>), dim3((unsigned)chunks, n_sh), dim3(kIdxStagedWaves * kWave), 0, st, job->dev, job->dev_aux, tick);
+        hipLaunchKernelGGL((idx_scatter_staged_kernel<kIdxStagedWaves>), dim3((unsigned)chunks, n_sh), dim3(kIdxStagedWaves * kWave), 0, st, job->dev, job->dev_aux, tick);
     else
         hipLaunchKernelGGL(idx_scatter_kernel, dim3(wave_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
     hipLaunchKernelGGL(idx_mark_kernel, dim3(flag_blocks, n_sh), dim3(kBlock), 0, st, job->dev, job->dev_aux, tick);
