@@ -12,7 +12,7 @@ for path in sorted(glob.glob(os.path.join(sys.argv[1], '*', '**', '*counter_coll
             k = row['Kernel_Name']
             if 'ure::' not in k:
                 continue
-            k = k.split('(')[0].replace('void ', '')
+            k = k.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
             c = out[k][row['Counter_Name']]
             c[0] += float(row['Counter_Value']); c[1] += 1
             if (path, row['Dispatch_Id']) not in seen:

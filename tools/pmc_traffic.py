@@ -64,7 +64,7 @@ def main():
                     k = row['Kernel_Name']
                     if 'ure::' not in k:
                         continue
-                    k = k.split('(')[0].replace('void ', '')
+                    k = k.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
                     c = sums[k][row['Counter_Name']]
                     c[0] += float(row['Counter_Value'])
                     c[1] += 1
