@@ -65,7 +65,7 @@ def main():
             t3 = time.perf_counter()
             label, _, obj, aug = nv.ot_assign_warm(dist, pi, want_plan=False)
             t4 = time.perf_counter()
-            order = torch.from_numpy(np.argsort(label, kind='stable').astype(np.int32)).cuda()
+            order = torch.from_numpy(np.argsort(label.astype(np.uint8 if k <= 256 else np.int64), kind='stable').astype(np.int32)).cuda()     # (as method/utils.py: a radix sort)
             off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(label, minlength=k))]).astype(np.int64)).cuda()
             nv.check(L.ure_ot_centroids_members(nv.ptr(Xd), nv.ptr(order), nv.ptr(off), n, k, d, nv.ptr(cent_d), nv.ptr(counts_d), st), 'cent')
             centroid = cent_d.cpu().numpy()

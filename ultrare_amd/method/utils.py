@@ -199,7 +199,9 @@ def _ot_round(Xd, centroid, n, k, d, dist_d, label_d, cent_d, counts_d, pi=None,
     if fast_label is not None:
         mfma_check.append(int((fast_label != label).sum()))
     # utils.py:648 from member lists: a stable sort of the labels (ascending id inside a cluster = numpy's order of addition)
-    order = torch.from_numpy(np.argsort(label, kind='stable').astype(np.int32)).to(Xd.device)
+    # (labels as the narrowest unsigned type: numpy's stable sort of 8- and 16-bit keys is a radix sort -- 0.3 ms instead of 3 at n = 162,000)
+    keys = label.astype(np.uint8 if k <= 256 else np.uint16 if k <= 65536 else np.int64)
+    order = torch.from_numpy(np.argsort(keys, kind='stable').astype(np.int32)).to(Xd.device)
     off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(label, minlength=k))]).astype(np.int64)).to(Xd.device)
     nv.check(L.ure_ot_centroids_members(nv.ptr(Xd), nv.ptr(order), nv.ptr(off), n, k, d, nv.ptr(cent_d), nv.ptr(counts_d), st),
              'ure_ot_centroids_members')
