@@ -22,7 +22,7 @@
 namespace ure {
 
 // numpy pairwise_sum for n <= 128 contiguous fp32 terms t_j = (x_j - c_j)^2.
-__device__ float np_block_sum(const float *__restrict__ x, const float *__restrict__ c, int n)
+__device__ __forceinline__ float np_block_sum(const float *__restrict__ x, const float *__restrict__ c, int n)
 {
     if (n < 8) {
         float res = 0.f;
@@ -64,6 +64,16 @@ __device__ float np_pairwise(const float *__restrict__ x, const float *__restric
     return __fadd_rn(np_pairwise(x, c, n2), np_pairwise(x + n2, c + n2, n - n2));
 }
 
+// The same for n <= 256 (ure_ot_cost's limit) without the recursion: at most one split.  Inlined into its caller, the loads keep their address spaces --
+// as a called function np_pairwise read the LDS tile and the centroid through flat pointers, and ot_cost_tiled_kernel spent its time there.
+__device__ __forceinline__ float np_pairwise_le256(const float *__restrict__ x, const float *__restrict__ c, int n)
+{
+    if (n <= 128) return np_block_sum(x, c, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return __fadd_rn(np_block_sum(x, c, n2), np_block_sum(x + n2, c + n2, n - n2));
+}
+
 __global__ __launch_bounds__(kBlock) void ot_cost_kernel(const float *__restrict__ X, const float *__restrict__ C, int64_t n,
                                                          int k, int d, float *__restrict__ dist)
 {
@@ -90,10 +100,12 @@ __global__ __launch_bounds__(kBlock) void ot_cost_tiled_kernel(const float *__re
     const int rows = (int)min<int64_t>(kCostRows, n - i0);
     for (int t = threadIdx.x; t < rows * d; t += kBlock) tile[(t / d) * ld + (t % d)] = X[i0 * d + t];     // contiguous read
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave's number as a SCALAR: the centroid's values are then read by scalar loads -- as a vector value the compiler cannot know to be uniform it
+    // made every one of them a 64-lane load of one address, 1,024 per wavefront at k = 32, d = 128: the kernel's time)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (lane >= rows) return;
     const float *x = tile + lane * ld;
-    for (int c = wave; c < k; c += kWavesPerBlock) dist[(size_t)c * n + i0 + lane] = np_pairwise(x, C + (size_t)c * d, d);
+    for (int c = wave; c < k; c += kWavesPerBlock) dist[(size_t)c * n + i0 + lane] = np_pairwise_le256(x, C + (size_t)c * d, d);
 }
 
 // ---- MFMA form of the cost matrix: |x|^2 - 2 x.c + |c|^2 with the n x k x d contraction on the matrix cores ------
