@@ -192,10 +192,20 @@ __global__ __launch_bounds__(kBlock) void ot_pot_step_kernel(const float *__rest
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         float best = 3.4e38f, second = 3.4e38f;
         int arg = 0;
-        for (int c = 0; c < k; ++c) {
-            const float v = dist[(size_t)c * n + i] - pi[c];
-            if (v < best) { second = best; best = v; arg = c; }
-            else if (v < second) second = v;
+        // (eight costs requested together, then compared in cluster order: one load, its comparison, the next load was k memory latencies in a row per point)
+        for (int c0 = 0; c0 < k; c0 += 8) {
+            float cost[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cost[u] = dist[(size_t)min(c0 + u, k - 1) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u;
+                if (c < k) {
+                    const float v = cost[u] - pi[c];
+                    if (v < best) { second = best; best = v; arg = c; }
+                    else if (v < second) second = v;
+                }
+            }
         }
         atomicAdd(&hist[arg], 1u);
         gap += (double)(second - best);
