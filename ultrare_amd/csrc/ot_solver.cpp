@@ -31,6 +31,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <cstdint>
 #include <cstdio>
 #include <limits>
@@ -73,8 +75,25 @@ static void parallel_ranges(int64_t n, int64_t grain, F &&body)
     for (auto &th : pool) th.join();
 }
 
+// n k entries that are all written before they are read (the fixed-point costs), or nearly all zero (the flows): std::vector would fill 41 + 21 MB on the calling
+// thread first -- at n = 162,000, k = 32 a fifth of the solver's fixed passes.  malloc leaves the pages to the threads that write (or zero) them.
+template <typename T>
+struct RawBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { std::free(p); }
+    bool alloc(size_t m, bool zero) { std::free(p); p = static_cast<T *>(zero ? std::calloc(std::max<size_t>(m, 1), sizeof(T)) : std::malloc(std::max<size_t>(m, 1) * sizeof(T))); n = m; return p != nullptr; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    T *begin() { return p; }
+    T *end() { return p + n; }
+};
+
 // fp32 costs [k][n] -> int64 [n][k] on a common power-of-two scale (exact unless the dynamic range is absurd)
-static int to_fixed_point(const float *dist, int64_t n, int k, std::vector<int64_t> &cost, int *shift_out)
+static int to_fixed_point(const float *dist, int64_t n, int k, RawBuf<int64_t> &cost, int *shift_out)
 {
     int e_min = std::numeric_limits<int>::max(), e_max = std::numeric_limits<int>::min();
     std::atomic<int64_t> bad{-1};
@@ -106,7 +125,7 @@ static int to_fixed_point(const float *dist, int64_t n, int k, std::vector<int64
         shift = -e_min;
         if (e_max + shift > budget) shift = budget - e_max;       // absurd dynamic range: round the tiniest costs
     }
-    cost.resize((size_t)n * k);
+    if (!cost.alloc((size_t)n * k, false)) return ure::fail(-1, "ure_ot_assign: out of memory (%lld x %d costs)", (long long)n, k);
     const double scale = std::ldexp(1.0, shift);
     parallel_ranges(n, 4096, [&](int64_t b, int64_t e_, int) {      // transposing write, a block of points per thread
         for (int c = 0; c < k; ++c) {
@@ -124,12 +143,14 @@ extern "C" int ure_ot_assign(const float *dist, int64_t n, int k, int32_t *label
         return ure::fail(-1, "ure_ot_assign: bad arguments (n=%lld k=%d)", (long long)n, k);
 
     // ---- fixed-point scale -------------------------------------------------------
-    std::vector<int64_t> cost;
+    RawBuf<int64_t> cost;
     int shift = 0;
     if (int rc = to_fixed_point(dist, n, k, cost, &shift)) return rc;
 
     // ---- initial pseudo-flow -----------------------------------------------------
-    std::vector<int32_t> x((size_t)n * k, 0);
+    RawBuf<int32_t> x;
+    if (!x.alloc((size_t)n * k, false)) return ure::fail(-1, "ure_ot_assign: out of memory (%lld x %d flows)", (long long)n, k);
+    parallel_ranges(n * k, 1 << 20, [&](int64_t b, int64_t e_, int) { std::memset(x.p + b, 0, (size_t)(e_ - b) * sizeof(int32_t)); });     // (zeroed -- and its pages touched -- by the threads)
     std::vector<uint32_t> ver((size_t)n * k, 0);
     std::vector<int64_t> load(k, 0);
     std::vector<std::vector<Entry>> heap((size_t)k * k);
@@ -261,7 +282,7 @@ extern "C" int ure_ot_assign_warm(const float *dist, int64_t n, int k, const dou
         return ure::fail(-1, "ure_ot_assign_warm: bad arguments (n=%lld k=%d)", (long long)n, k);
     if (augmentations) *augmentations = -1;
     if (!pi) return ure_ot_assign(dist, n, k, label, plan_nk, total_cost);
-    std::vector<int64_t> cost;
+    RawBuf<int64_t> cost;
     int shift = 0;
     if (int rc = to_fixed_point(dist, n, k, cost, &shift)) return rc;
     std::vector<int64_t> pot(k);
@@ -272,7 +293,9 @@ extern "C" int ure_ot_assign_warm(const float *dist, int64_t n, int k, const dou
     }
 
     // ---- initial pseudo-flow: cheapest reduced cost (ties: lowest cluster) ---------------------------
-    std::vector<int32_t> x((size_t)n * k, 0);
+    RawBuf<int32_t> x;
+    if (!x.alloc((size_t)n * k, false)) return ure::fail(-1, "ure_ot_assign: out of memory (%lld x %d flows)", (long long)n, k);
+    parallel_ranges(n * k, 1 << 20, [&](int64_t b, int64_t e_, int) { std::memset(x.p + b, 0, (size_t)(e_ - b) * sizeof(int32_t)); });     // (zeroed -- and its pages touched -- by the threads)
     std::vector<int64_t> load(k, 0);
     std::vector<std::vector<int32_t>> members(k);
     for (int c = 0; c < k; ++c) members[c].reserve((size_t)(n / k + n / (4 * k) + 16));
