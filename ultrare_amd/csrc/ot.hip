@@ -55,17 +55,9 @@ __device__ __forceinline__ float np_block_sum(const float *__restrict__ x, const
     return res;
 }
 
-// numpy splits runs longer than 128 in two (first half rounded down to a multiple of 8).
-__device__ float np_pairwise(const float *__restrict__ x, const float *__restrict__ c, int n)
-{
-    if (n <= 128) return np_block_sum(x, c, n);
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    return __fadd_rn(np_pairwise(x, c, n2), np_pairwise(x + n2, c + n2, n - n2));
-}
-
-// The same for n <= 256 (ure_ot_cost's limit) without the recursion: at most one split.  Inlined into its caller, the loads keep their address spaces --
-// as a called function np_pairwise read the LDS tile and the centroid through flat pointers, and ot_cost_tiled_kernel spent its time there.
+// numpy splits runs longer than 128 in two (first half rounded down to a multiple of 8) -- for n <= 256 (ure_ot_cost's limit) that is at most one split, so
+// no recursion.  Inlined into its caller, the loads keep their address spaces: as a called, recursive function (rounds 1-4) it read ot_cost_tiled_kernel's
+// LDS tile and the centroid through flat pointers, and the kernel spent its time there.
 __device__ __forceinline__ float np_pairwise_le256(const float *__restrict__ x, const float *__restrict__ c, int n)
 {
     if (n <= 128) return np_block_sum(x, c, n);
@@ -81,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void ot_cost_kernel(const float *__restrict
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
         const int64_t i = t % n;
         const int c = (int)(t / n);
-        dist[t] = np_pairwise(X + i * d, C + (size_t)c * d, d);
+        dist[t] = np_pairwise_le256(X + i * d, C + (size_t)c * d, d);
     }
 }
 
